@@ -1,0 +1,202 @@
+/*
+ * vgen_hip.h — C ABI of libvgen_hip.so, the MI355X (gfx950) scan engine that stands in for the
+ * wgpu/WGSL backend of oritwoen/vgen.
+ *
+ * The reference has no FFI layer (Cargo.toml:14 forbids unsafe code); its GPU path is entered
+ * through the GpuRunner object and the scan_gpu_with_runner free function.  Each entry point below
+ * names the reference interface it replaces (paths relative to the upstream repo root); the binding
+ * a vgen fork would add is shown in INTEGRATION.md.
+ *
+ * Conventions: every call returns VGEN_OK (0) or a negative vgen_status; nothing throws across the
+ * ABI; a vgen_ctx is bound to one HIP device and must be used from one host thread at a time
+ * (different contexts are independent, as one GpuRunner per adapter would be); all multi-byte keys
+ * are 32-byte BIG-endian scalars exactly as the reference passes them ([u8; 32], src/gpu.rs:535).
+ * The library never falls back to a CPU implementation: without a usable HIP device vgen_create
+ * fails with VGEN_E_NODEVICE.
+ */
+#ifndef VGEN_HIP_H
+#define VGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGEN_ABI_VERSION 1
+
+typedef enum vgen_status {
+    VGEN_OK = 0,
+    VGEN_E_INVALID = -1,   /* bad argument */
+    VGEN_E_NODEVICE = -2,  /* no usable HIP device / device index out of range */
+    VGEN_E_HIP = -3,       /* a HIP runtime call failed (see vgen_last_error) */
+    VGEN_E_NOMEM = -4,
+    VGEN_E_STATE = -5,     /* e.g. vgen_wait on a frame with nothing in flight (gpu.rs:622-625) */
+    VGEN_E_PATTERN = -6,   /* pattern empty / invalid / unsupported syntax (pattern.rs:21-33) */
+    VGEN_E_RANGE = -7,     /* start key is 0 or >= n (SecretKey::from_slice failure, gpu.rs:903) */
+    VGEN_E_UNSUPPORTED = -8
+} vgen_status;
+
+/* AddressFormat, src/address.rs:11-24 (same order). */
+typedef enum vgen_format {
+    VGEN_FMT_P2PKH = 0,
+    VGEN_FMT_P2WPKH = 1,
+    VGEN_FMT_P2SH_P2WPKH = 2,
+    VGEN_FMT_P2TR = 3,
+    VGEN_FMT_P2PKH_UNCOMPRESSED = 4,
+    VGEN_FMT_ETHEREUM = 5
+} vgen_format;
+
+/* Parameters of vgen_create; replaces the arguments of GpuRunner::new(batch_size, backend)
+ * (src/gpu.rs:138) plus the buffer sizing it derives from them (src/gpu.rs:391-500). */
+typedef struct vgen_params {
+    uint32_t struct_size;  /* = sizeof(vgen_params) */
+    int32_t device;        /* HIP device ordinal */
+    uint32_t batch_size;   /* keys per dispatch; reference default 524288 (gpu.rs:83); must be a
+                              multiple of 8192; 0 selects 1048576 */
+    uint32_t format;       /* vgen_format */
+    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 8 */
+    uint32_t match_cap;    /* match records kept per dispatch in filter mode; 0 -> 4096 */
+    uint32_t flags;        /* reserved, 0 */
+} vgen_params;
+
+/* One candidate reported by the device filter.  key = start_key + index.  payload is the 20-byte
+ * hash160 / Ethereum address (memory order, as the reference's output buffer holds it,
+ * src/gpu.rs:644-650) or the 32-byte x-only key for P2TR.  The device filter is a superset of the
+ * pattern; the host confirms with vgen_filter_matches on the encoded address (the reference runs
+ * pattern.matches on every key on the host, src/gpu.rs:1069). */
+typedef struct vgen_match {
+    uint32_t index;
+    uint32_t reserved;
+    uint8_t payload[32];
+} vgen_match;
+
+typedef struct vgen_ctx vgen_ctx;
+typedef struct vgen_filter vgen_filter;
+
+/* ---- library / device -------------------------------------------------------------------------- */
+
+int vgen_abi_version(void);
+/* Number of HIP devices; replaces the adapter enumeration of list_gpus / GpuRunner::new
+ * (src/gpu.rs:149-207, src/lib.rs:979-1036). */
+int vgen_device_count(int *n);
+/* Device name into buf (NUL-terminated, truncated to cap). */
+int vgen_device_name(int device, char *buf, size_t cap);
+
+/* ---- context: GpuRunner (src/gpu.rs:116-131) ------------------------------------------------------ */
+
+/* GpuRunner::new (src/gpu.rs:138-533): binds the device, allocates the frames and builds the shared
+ * offset table (the reference's init_table dispatch, src/gpu.rs:502-517). */
+int vgen_create(const vgen_params *p, vgen_ctx **out);
+void vgen_destroy(vgen_ctx *ctx);
+/* Message of the last failure on this context (or of the last failed vgen_create /
+ * vgen_filter_compile on this thread when ctx is NULL).  Valid until the next call. */
+const char *vgen_last_error(const vgen_ctx *ctx);
+/* The batch size / frame count actually in use (after defaults). */
+int vgen_get_info(const vgen_ctx *ctx, uint32_t *batch_size, uint32_t *frames, uint32_t *match_cap);
+
+/* ---- pattern: Pattern::new / Pattern::matches (src/pattern.rs:21-45) -------------------------------- */
+
+/* Compiles `pattern` (prefixed with "(?i)" when case_insensitive, pattern.rs:26-30) into (a) a DFA
+ * that decides Pattern::matches exactly for ASCII address strings and (b) a device prefilter for
+ * `format`.  Empty or invalid patterns fail with VGEN_E_PATTERN (pattern.rs:22-24,32-33). */
+int vgen_filter_compile(const char *pattern, int case_insensitive, uint32_t format, vgen_filter **out);
+void vgen_filter_free(vgen_filter *f);
+/* Pattern::matches (pattern.rs:43-45): unanchored regex search over the address string. 1 / 0. */
+int vgen_filter_matches(const vgen_filter *f, const char *address);
+/* How the device evaluates this filter: 0 = every key is reported to the host (no usable
+ * prefilter; reference-equivalent host filtering), 1 = hash160 range test (Base58 prefixes),
+ * 2 = masked-bits test (Bech32 / hex prefixes and suffixes), 3 = match-all. */
+int vgen_filter_device_kind(const vgen_filter *f);
+/* Selects the filter for subsequent dispatches; NULL = dump mode (every payload is written,
+ * index order — the reference kernel's behaviour, src/shaders/search.wgsl:2-31). */
+int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
+
+/* ---- dispatch / readback ----------------------------------------------------------------------------- */
+
+/* GpuRunner::dispatch(start_key, frame) (src/gpu.rs:535-600): asynchronously tests the keys
+ * start_key + i, i in [0, batch_size).  Keys >= n yield no result (increment_key -> None,
+ * src/gpu.rs:963).  start_key must be a valid scalar. */
+int vgen_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]);
+/* Arbitrary-scalar mode (the CPU path's "independent random key" shape, src/scanner.rs:151-155):
+ * tests keys_be[32*i], i < n <= batch_size, with a full fixed-base multiplication per key.
+ * Invalid scalars (0 or >= n) yield no result (address.rs:93). */
+int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n);
+/* GpuRunner::await_result(frame) (src/gpu.rs:602-658): blocks until the frame's dispatch is done.
+ * Filter mode: copies up to cap records to out (ascending index), stores the number found in
+ * *n_matches (may exceed cap: the surplus was dropped) and the number of keys tested in *keys_tested.
+ * Dump mode: n_matches = 0; fetch the payloads with vgen_read_dump.  Any pointer may be NULL. */
+int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
+              uint64_t *keys_tested);
+/* Dump mode only, after vgen_wait: copies the frame's payloads (batch_size * 20 bytes, or * 32 for
+ * P2TR; zeroed for invalid keys) — the Vec<[u8;20]> await_result returns (src/gpu.rs:644-650). */
+int vgen_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
+/* Device time of the frame's last completed dispatch, measured with HIP events on the frame's own
+ * stream (kernel only, excluding the host-side base-point computation). */
+int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms);
+
+/* ---- host-side derivation (what the Rust host obtains from rust-bitcoin) ----------------------------- */
+
+/* Address string from a device payload (src/gpu.rs:1034-1060).  Returns length or negative status. */
+int vgen_address_from_payload(uint32_t format, const uint8_t *payload, char *out, size_t cap);
+/* AddressGenerator::bytes_to_wif (src/address.rs:168-172); uncompressed form for
+ * VGEN_FMT_P2PKH_UNCOMPRESSED, hex for Ethereum (address.rs:110).  Returns length or negative status. */
+int vgen_key_to_wif(uint32_t format, const uint8_t key_be[32], char *out, size_t cap);
+/* increment_key (src/gpu.rs:951-968): out = key + amount; VGEN_E_RANGE on overflow or invalid scalar. */
+int vgen_key_add(const uint8_t key_be[32], uint64_t amount, uint8_t out_be[32]);
+/* AddressGenerator::generate (src/address.rs:92-151) on the host, for single keys (verify-style
+ * use and tests). address cap >= 96, wif cap >= 72. VGEN_E_RANGE for an invalid key. */
+int vgen_derive(uint32_t format, const uint8_t key_be[32], char *address, size_t acap, char *wif, size_t wcap);
+
+/* ---- scanner: scan_gpu_with_runner (src/gpu.rs:920-1125) ----------------------------------------------- */
+
+/* ScanConfig (src/scanner.rs:17-46) restricted to the fields the GPU path reads. */
+typedef struct vgen_scan_config {
+    uint32_t struct_size;
+    uint32_t format;
+    uint64_t count;          /* matches to find; UINT64_MAX = unbounded (lib.rs:524) */
+    int32_t case_insensitive;
+    int32_t has_start;       /* 0: random base key (gpu.rs:936-945) drawn from `seed` */
+    uint8_t start[32];
+    int32_t has_end;
+    uint8_t end[32];
+    uint64_t seed;           /* build-side addition (the reference seeds from OS entropy): base key
+                                k0(seed, shard) of BASELINE.md §4; seed 0 = OS entropy */
+    uint32_t shard;          /* this scanner's index among n_shards batch-striped scanners */
+    uint32_t n_shards;       /* 0/1 = single device; >1: this context takes global batches b with
+                                b % n_shards == shard */
+    uint64_t max_batches;    /* stop after this many dispatches per shard (0 = no limit) */
+} vgen_scan_config;
+
+/* GeneratedAddress (src/address.rs:63-72). */
+typedef struct vgen_generated {
+    char address[96];
+    char wif[72];
+    char hex[72];
+    uint32_t format;
+    uint8_t key[32];
+} vgen_generated;
+
+/* ScanResult (src/scanner.rs:50-68). */
+typedef struct vgen_scan_result {
+    vgen_generated *matches;  /* vgen_scan_result_free */
+    uint64_t n_matches;
+    uint64_t operations;
+    double elapsed_secs;
+} vgen_scan_result;
+
+typedef void (*vgen_progress_cb)(uint64_t operations, void *user); /* ProgressCallback, scanner.rs:71 */
+
+/* scan_gpu_with_runner(pattern, config, progress_cb, stop, runner) (src/gpu.rs:920-926): drives the
+ * frames of `ctx` round-robin, confirms device candidates on the host, collects up to count matches
+ * in ascending key order within a batch (gpu.rs:1095-1104), counts batch_size operations per
+ * completed batch (gpu.rs:1106) and honours *stop between batches (gpu.rs:980-984,1007-1011). */
+int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
+              void *user, volatile int32_t *stop, vgen_scan_result *out);
+void vgen_scan_result_free(vgen_scan_result *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+// core_shim.cpp — exposes the single-source core headers (vgen_amd/csrc/core/*.h), compiled for the
+// HOST by g++, to the CPU test-suite through ctypes.  The same headers are what hipcc compiles into
+// the kernels, so arithmetic bugs (limb overflow, magnitude violations) are caught without a GPU.
+#include "../../vgen_amd/csrc/core/fe.h"
+
+using namespace vg;
+
+extern "C" {
+void core_fe_mul(const u32 *a, const u32 *b, u32 *r) {
+    fe x, y, z;
+    for (int i = 0; i < 9; i++) { x.n[i] = a[i]; y.n[i] = b[i]; }
+    fe_mul(z, x, y);
+    for (int i = 0; i < 9; i++) r[i] = z.n[i];
+}
+void core_fe_sqr(const u32 *a, u32 *r) {
+    fe x, z;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    fe_sqr(z, x);
+    for (int i = 0; i < 9; i++) r[i] = z.n[i];
+}
+void core_fe_normalize(const u32 *a, u32 *r, int weak) {
+    fe x;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    if (weak) fe_normalize_weak(x); else fe_normalize(x);
+    for (int i = 0; i < 9; i++) r[i] = x.n[i];
+}
+void core_fe_neg(const u32 *a, u32 m, u32 *r) {
+    fe x, z;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    fe_neg(z, x, m);
+    for (int i = 0; i < 9; i++) r[i] = z.n[i];
+}
+void core_fe_inv(const u32 *a, u32 *r) {
+    fe x, z;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    fe_inv(z, x);
+    for (int i = 0; i < 9; i++) r[i] = z.n[i];
+}
+void core_fe_words(const u32 *a, u32 *w, u32 *back) {
+    fe x, y;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    fe_to_words(x, w);
+    fe_from_words(y, w);
+    for (int i = 0; i < 9; i++) back[i] = y.n[i];
+}
+}
+
+#include "../../vgen_amd/csrc/core/hash.h"
+
+extern "C" {
+// x, y: 32 big-endian bytes each
+static void be32_to_words(const unsigned char *be, u32 w[8]) {
+    for (int i = 0; i < 8; i++)
+        w[i] = ((u32)be[28 - 4 * i] << 24) | ((u32)be[29 - 4 * i] << 16) | ((u32)be[30 - 4 * i] << 8) | be[31 - 4 * i];
+}
+void core_hash160_pub33(u32 prefix, const unsigned char *x_be, unsigned char *out20) {
+    u32 xw[8], sha[8], h[5];
+    be32_to_words(x_be, xw);
+    sha256_pub33(prefix, xw, sha);
+    ripemd160_of_sha(sha, h);
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 4; j++) out20[4 * i + j] = (unsigned char)(h[i] >> (8 * j));
+}
+void core_hash160_pub65(const unsigned char *x_be, const unsigned char *y_be, unsigned char *out20) {
+    u32 xw[8], yw[8], sha[8], h[5];
+    be32_to_words(x_be, xw);
+    be32_to_words(y_be, yw);
+    sha256_pub65(xw, yw, sha);
+    ripemd160_of_sha(sha, h);
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 4; j++) out20[4 * i + j] = (unsigned char)(h[i] >> (8 * j));
+}
+void core_hash160_script22(const unsigned char *h160, unsigned char *out20) {
+    u32 hin[5], sha[8], h[5];
+    for (int i = 0; i < 5; i++) hin[i] = (u32)h160[4 * i] | ((u32)h160[4 * i + 1] << 8) | ((u32)h160[4 * i + 2] << 16) | ((u32)h160[4 * i + 3] << 24);
+    sha256_script22(hin, sha);
+    ripemd160_of_sha(sha, h);
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 4; j++) out20[4 * i + j] = (unsigned char)(h[i] >> (8 * j));
+}
+void core_keccak_addr(const unsigned char *x_be, const unsigned char *y_be, unsigned char *out20) {
+    u32 xw[8], yw[8], h[5];
+    be32_to_words(x_be, xw);
+    be32_to_words(y_be, yw);
+    keccak256_pub64_addr(xw, yw, h);
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 4; j++) out20[4 * i + j] = (unsigned char)(h[i] >> (8 * j));
+}
+}
+
+#include "../../vgen_amd/csrc/host/host_ec.h"
+#include "../../vgen_amd/csrc/host/host_ec.cpp"
+
+extern "C" {
+// key (32 BE bytes) -> x||y (64 BE bytes); returns 0 for k == 0
+int core_mul_gen(const unsigned char *key_be, unsigned char *xy) {
+    Scalar k;
+    scalar_from_be(k, key_be);
+    ge p;
+    if (!host_ec_mul_gen(k, p)) return 0;
+    u32 w[8];
+    fe_to_words(p.x, w);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
+    fe_to_words(p.y, w);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[32 + 4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
+    return 1;
+}
+// stride table entry check: out = x||y of entries
+void core_stride_table(uint64_t first, uint64_t step, uint32_t count, unsigned char *xy) {
+    std::vector<ge> t;
+    host_build_stride_table(first, step, count, t);
+    for (uint32_t e = 0; e < count; e++) {
+        u32 w[8];
+        fe_to_words(t[e].x, w);
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[64 * e + 4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
+        fe_to_words(t[e].y, w);
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[64 * e + 32 + 4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
+    }
+}
+}

@@ -1,0 +1,53 @@
+"""CPU tests of the single-source hash block functions (vgen_amd/csrc/core/hash.h) against the oracle."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import pyoracle as vo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+@pytest.fixture(scope="module")
+def core():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    return ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
+
+
+def pubs():
+    rng = random.Random(21)
+    keys = [1, 2, 3, N - 1, 2**255, 0xFF] + [rng.randrange(1, N) for _ in range(60)]
+    return [vo.pubkey(k) for k in keys]
+
+
+def test_hash160_compressed(core):
+    for p in pubs():
+        out = ctypes.create_string_buffer(20)
+        core.core_hash160_pub33(2 + (p[64] & 1), p[1:33], out)
+        assert out.raw == vo.hash160(bytes([2 + (p[64] & 1)]) + p[1:33])
+
+
+def test_hash160_uncompressed(core):
+    for p in pubs():
+        out = ctypes.create_string_buffer(20)
+        core.core_hash160_pub65(p[1:33], p[33:65], out)
+        assert out.raw == vo.hash160(p)
+
+
+def test_hash160_p2sh_script(core):
+    for p in pubs():
+        h = vo.hash160(bytes([2 + (p[64] & 1)]) + p[1:33])
+        out = ctypes.create_string_buffer(20)
+        core.core_hash160_script22(h, out)
+        assert out.raw == vo.hash160(b"\x00\x14" + h)
+
+
+def test_keccak_address(core):
+    for p in pubs():
+        out = ctypes.create_string_buffer(20)
+        core.core_keccak_addr(p[1:33], p[33:65], out)
+        assert out.raw == vo.keccak256(p[1:])[12:]

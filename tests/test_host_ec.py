@@ -1,0 +1,56 @@
+"""CPU tests of the host-side EC code of libvgen_hip.so (fixed-base multiplication, stride tables)
+against the oracle and the OpenSSL fixtures."""
+import ctypes
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import pyoracle as vo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OSSL = json.load(open(os.path.join(HERE, "golden", "openssl_keys.json")))
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+@pytest.fixture(scope="module")
+def core():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    lib = ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
+    lib.core_stride_table.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
+    return lib
+
+
+def test_mul_gen_against_openssl_fixtures(core):
+    for vec in OSSL["full"]:
+        out = ctypes.create_string_buffer(64)
+        assert core.core_mul_gen(bytes.fromhex(vec["key"]), out) == 1
+        assert out.raw.hex() == vec["pub65"][2:]
+
+
+def test_mul_gen_random_against_oracle(core):
+    rng = random.Random(31)
+    for _ in range(100):
+        k = rng.randrange(1, N)
+        out = ctypes.create_string_buffer(64)
+        assert core.core_mul_gen(k.to_bytes(32, "big"), out) == 1
+        assert out.raw == vo.pubkey(k)[1:]
+    out = ctypes.create_string_buffer(64)
+    assert core.core_mul_gen(bytes(32), out) == 0
+    assert core.core_mul_gen(N.to_bytes(32, "big"), out) == 0  # n*G = infinity
+
+
+def test_stride_table(core):
+    first, step, count = 8, 16, 300
+    buf = ctypes.create_string_buffer(64 * count)
+    core.core_stride_table(first, step, count, buf)
+    for e in list(range(0, 20)) + [count - 1, 137, 256]:
+        assert buf.raw[64 * e:64 * e + 64] == vo.pubkey(first + e * step)[1:]
+    # a chunk boundary (4096) is crossed here
+    count = 4100
+    buf = ctypes.create_string_buffer(64 * count)
+    core.core_stride_table(1, 1, count, buf)
+    for e in (0, 1, 4094, 4095, 4096, 4097, 4099):
+        assert buf.raw[64 * e:64 * e + 64] == vo.pubkey(1 + e)[1:]

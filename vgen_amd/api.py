@@ -1,0 +1,297 @@
+"""ctypes binding of include/vgen_hip.h, shaped like the reference's Rust API.
+
+  AddressFormat        src/address.rs:11-24
+  GeneratedAddress     src/address.rs:63-72
+  Pattern              src/pattern.rs:9-45         (new / matches)
+  ScanConfig/Result    src/scanner.rs:17-68
+  GpuRunner            src/gpu.rs:116-131,138,535,602   (new / dispatch / await_result)
+  scan_gpu_with_runner src/gpu.rs:920-926
+
+The extension is loaded from vgen_amd/libvgen_hip.so (in-tree).  If it is missing the import of
+this module fails loudly — nothing here computes an address in Python.
+"""
+import ctypes
+import enum
+import os
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvgen_hip.so")
+
+
+class VgenError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"[vgen status {status}] {message}")
+        self.status = status
+
+
+def library_path():
+    return _SO
+
+
+if not os.path.exists(_SO):
+    raise ImportError(f"{_SO} not found: build it with `make -C vgen_amd/csrc` (or __graft_entry__.build()); "
+                      "vgen_amd has no pure-Python or CPU fallback")
+_L = ctypes.CDLL(_SO)
+
+OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_PATTERN, E_RANGE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
+
+class AddressFormat(enum.IntEnum):
+    P2pkh = 0
+    P2wpkh = 1
+    P2shP2wpkh = 2
+    P2tr = 3
+    P2pkhUncompressed = 4
+    Ethereum = 5
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("batch_size", ctypes.c_uint32),
+                ("format", ctypes.c_uint32), ("frames", ctypes.c_uint32), ("match_cap", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32)]
+
+
+class _Match(ctypes.Structure):
+    _fields_ = [("index", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("payload", ctypes.c_uint8 * 32)]
+
+
+class _ScanConfig(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("format", ctypes.c_uint32), ("count", ctypes.c_uint64),
+                ("case_insensitive", ctypes.c_int32), ("has_start", ctypes.c_int32), ("start", ctypes.c_uint8 * 32),
+                ("has_end", ctypes.c_int32), ("end", ctypes.c_uint8 * 32), ("seed", ctypes.c_uint64),
+                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("max_batches", ctypes.c_uint64)]
+
+
+class _Generated(ctypes.Structure):
+    _fields_ = [("address", ctypes.c_char * 96), ("wif", ctypes.c_char * 72), ("hex", ctypes.c_char * 72),
+                ("format", ctypes.c_uint32), ("key", ctypes.c_uint8 * 32)]
+
+
+class _ScanResult(ctypes.Structure):
+    _fields_ = [("matches", ctypes.POINTER(_Generated)), ("n_matches", ctypes.c_uint64),
+                ("operations", ctypes.c_uint64), ("elapsed_secs", ctypes.c_double)]
+
+
+_PROGRESS = ctypes.CFUNCTYPE(None, ctypes.c_uint64, ctypes.c_void_p)
+
+_L.vgen_last_error.restype = ctypes.c_char_p
+_L.vgen_last_error.argtypes = [ctypes.c_void_p]
+_L.vgen_create.argtypes = [ctypes.POINTER(_Params), ctypes.POINTER(ctypes.c_void_p)]
+_L.vgen_destroy.argtypes = [ctypes.c_void_p]
+_L.vgen_destroy.restype = None
+_L.vgen_get_info.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint32)] * 3
+_L.vgen_filter_compile.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+_L.vgen_filter_free.argtypes = [ctypes.c_void_p]
+_L.vgen_filter_free.restype = None
+_L.vgen_filter_matches.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+_L.vgen_filter_device_kind.argtypes = [ctypes.c_void_p]
+_L.vgen_set_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+_L.vgen_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
+_L.vgen_dispatch_keys.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
+_L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match), ctypes.c_uint32,
+                         ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
+_L.vgen_read_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+_L.vgen_frame_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
+_L.vgen_address_from_payload.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+_L.vgen_key_to_wif.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+_L.vgen_key_add.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
+_L.vgen_derive.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                           ctypes.c_size_t]
+_L.vgen_device_name.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+_L.vgen_scan.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(_ScanConfig), _PROGRESS, ctypes.c_void_p,
+                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_ScanResult)]
+_L.vgen_scan_result_free.argtypes = [ctypes.POINTER(_ScanResult)]
+_L.vgen_scan_result_free.restype = None
+
+
+def _key(k):
+    return k.to_bytes(32, "big") if isinstance(k, int) else bytes(k)
+
+
+def _check(rc, ctx=None):
+    if rc < 0:
+        msg = _L.vgen_last_error(ctx)
+        raise VgenError(rc, msg.decode() if msg else "")
+    return rc
+
+
+def abi_version():
+    return _L.vgen_abi_version()
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(_L.vgen_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name(device=0):
+    buf = ctypes.create_string_buffer(256)
+    _check(_L.vgen_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+def address_from_payload(fmt, payload):
+    out = ctypes.create_string_buffer(128)
+    _check(_L.vgen_address_from_payload(int(fmt), bytes(payload), out, 128))
+    return out.value.decode()
+
+
+def key_to_wif(fmt, key):
+    out = ctypes.create_string_buffer(128)
+    _check(_L.vgen_key_to_wif(int(fmt), _key(key), out, 128))
+    return out.value.decode()
+
+
+def key_add(key, amount):
+    """increment_key (src/gpu.rs:951-968): None on overflow or an invalid scalar."""
+    out = ctypes.create_string_buffer(32)
+    rc = _L.vgen_key_add(_key(key), amount, out)
+    return None if rc == E_RANGE else int.from_bytes(out.raw, "big")
+
+
+@dataclass
+class GeneratedAddress:
+    address: str
+    wif: str
+    hex: str
+    format: AddressFormat
+
+
+def derive(fmt, key) -> Optional[GeneratedAddress]:
+    """AddressGenerator::generate on the host (src/address.rs:92-151); None for an invalid key."""
+    a, w = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+    rc = _L.vgen_derive(int(fmt), _key(key), a, 128, w, 128)
+    if rc == E_RANGE:
+        return None
+    _check(rc)
+    return GeneratedAddress(a.value.decode(), w.value.decode(), _key(key).hex(), AddressFormat(int(fmt)))
+
+
+class Pattern:
+    """Pattern::new / matches (src/pattern.rs:21-45) plus the device prefilter derived for `fmt`."""
+
+    def __init__(self, pattern: str, case_insensitive: bool = False, fmt: AddressFormat = AddressFormat.P2pkh):
+        self.original, self.case_insensitive, self.format = pattern, case_insensitive, AddressFormat(int(fmt))
+        h = ctypes.c_void_p()
+        _check(_L.vgen_filter_compile(pattern.encode(), int(case_insensitive), int(fmt), ctypes.byref(h)))
+        self._h = h
+
+    def matches(self, address: str) -> bool:
+        return _L.vgen_filter_matches(self._h, address.encode()) == 1
+
+    @property
+    def device_kind(self) -> int:
+        return _L.vgen_filter_device_kind(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _L.vgen_filter_free(self._h)
+            self._h = None
+
+
+@dataclass
+class ScanConfig:
+    """src/scanner.rs:17-46 (fields the GPU path reads) + the build-side seed / shard additions."""
+    format: AddressFormat = AddressFormat.P2pkh
+    count: int = 1
+    gpu_batch_size: Optional[int] = None
+    start: Optional[int] = None
+    end: Optional[int] = None
+    case_insensitive: bool = False
+    seed: int = 0
+    shard: int = 0
+    n_shards: int = 1
+    max_batches: int = 0
+
+
+@dataclass
+class ScanResult:
+    matches: List[GeneratedAddress] = field(default_factory=list)
+    operations: int = 0
+    elapsed_secs: float = 0.0
+
+    def rate(self) -> float:   # src/scanner.rs:61-67
+        return self.operations / self.elapsed_secs if self.elapsed_secs > 0 else 0.0
+
+
+class GpuRunner:
+    """GpuRunner (src/gpu.rs:116-131): one device, `frames` dispatches in flight."""
+
+    def __init__(self, batch_size: int = 1 << 20, fmt: AddressFormat = AddressFormat.P2pkh, device: int = 0,
+                 frames: int = 2, match_cap: int = 4096):
+        p = _Params(ctypes.sizeof(_Params), device, batch_size, int(fmt), frames, match_cap, 0)
+        h = ctypes.c_void_p()
+        _check(_L.vgen_create(ctypes.byref(p), ctypes.byref(h)))
+        self._h = h
+        b, f, m = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        _L.vgen_get_info(h, ctypes.byref(b), ctypes.byref(f), ctypes.byref(m))
+        self.batch_size, self.frames, self.match_cap, self.format = b.value, f.value, m.value, AddressFormat(int(fmt))
+        self._pattern = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _L.vgen_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_filter(self, pattern: Optional[Pattern]):
+        _check(_L.vgen_set_filter(self._h, pattern._h if pattern else None), self._h)
+        self._pattern = pattern
+
+    def dispatch(self, start_key, frame: int):
+        _check(_L.vgen_dispatch(self._h, frame, _key(start_key)), self._h)
+
+    def await_result(self, frame: int):
+        """Filter mode: (list of (index, payload20), n_found, keys_tested).  Dump mode: (bytes, 0, keys_tested)."""
+        recs = (_Match * self.match_cap)()
+        n, tested = ctypes.c_uint32(), ctypes.c_uint64()
+        _check(_L.vgen_wait(self._h, frame, recs, self.match_cap, ctypes.byref(n), ctypes.byref(tested)), self._h)
+        if self._pattern is None:
+            buf = ctypes.create_string_buffer(self.batch_size * 20)
+            _check(_L.vgen_read_dump(self._h, frame, buf, len(buf)), self._h)
+            return buf.raw, 0, tested.value
+        k = min(n.value, self.match_cap)
+        return [(recs[i].index, bytes(recs[i].payload)[:20]) for i in range(k)], n.value, tested.value
+
+    def wait(self, frame: int):
+        """vgen_wait without fetching anything (benchmark loop)."""
+        n, tested = ctypes.c_uint32(), ctypes.c_uint64()
+        _check(_L.vgen_wait(self._h, frame, None, 0, ctypes.byref(n), ctypes.byref(tested)), self._h)
+        return n.value, tested.value
+
+    def kernel_ms(self, frame: int) -> float:
+        ms = ctypes.c_float()
+        _check(_L.vgen_frame_kernel_ms(self._h, frame, ctypes.byref(ms)), self._h)
+        return ms.value
+
+
+def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner: GpuRunner,
+                         progress_cb: Optional[Callable[[int], None]] = None, stop=None) -> ScanResult:
+    """scan_gpu_with_runner (src/gpu.rs:920-926).  `stop` is an optional ctypes.c_int32 flag."""
+    c = _ScanConfig()
+    c.struct_size = ctypes.sizeof(_ScanConfig)
+    c.format = int(config.format)
+    c.count = config.count if config.count is not None else 2**64 - 1
+    c.case_insensitive = int(config.case_insensitive)
+    if config.start is not None:
+        c.has_start = 1
+        c.start = (ctypes.c_uint8 * 32)(*_key(config.start))
+    if config.end is not None:
+        c.has_end = 1
+        c.end = (ctypes.c_uint8 * 32)(*_key(config.end))
+    c.seed, c.shard, c.n_shards, c.max_batches = config.seed, config.shard, config.n_shards, config.max_batches
+    res = _ScanResult()
+    cb = _PROGRESS(lambda ops, _u: progress_cb(ops)) if progress_cb else ctypes.cast(None, _PROGRESS)
+    rc = _L.vgen_scan(runner._h, pattern.encode(), ctypes.byref(c), cb, None,
+                      ctypes.byref(stop) if stop is not None else None, ctypes.byref(res))
+    _check(rc, runner._h)
+    out = ScanResult(operations=res.operations, elapsed_secs=res.elapsed_secs)
+    for i in range(res.n_matches):
+        g = res.matches[i]
+        out.matches.append(GeneratedAddress(g.address.decode(), g.wif.decode(), g.hex.decode(), AddressFormat(g.format)))
+    _L.vgen_scan_result_free(ctypes.byref(res))
+    return out

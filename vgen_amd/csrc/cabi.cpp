@@ -1,0 +1,171 @@
+// cabi.cpp — the extern "C" surface declared in include/vgen_hip.h.
+#include <hip/hip_runtime_api.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/vgen_hip.h"
+#include "host/encode.h"
+#include "host/filter.h"
+#include "host/scalar.h"
+#include "runtime.h"
+
+namespace {
+thread_local std::string g_last_error;
+
+int copy_out(const std::string &s, char *out, size_t cap) {
+    if (!out || cap < s.size() + 1) return VGEN_E_INVALID;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+}  // namespace
+
+extern "C" {
+
+int vgen_abi_version(void) { return VGEN_ABI_VERSION; }
+
+int vgen_device_count(int *n) {
+    if (!n) return VGEN_E_INVALID;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return e == hipErrorNoDevice ? VGEN_OK : VGEN_E_HIP;
+    }
+    *n = c;
+    return VGEN_OK;
+}
+
+int vgen_device_name(int device, char *buf, size_t cap) {
+    if (!buf || cap == 0) return VGEN_E_INVALID;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return VGEN_E_NODEVICE;
+    }
+    std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
+    strncpy(buf, s.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+    return VGEN_OK;
+}
+
+int vgen_create(const vgen_params *p, vgen_ctx **out) {
+    std::string err;
+    int rc = vg::rt_create(p, out, err);
+    if (rc != VGEN_OK) g_last_error = err;
+    return rc;
+}
+
+void vgen_destroy(vgen_ctx *ctx) { vg::rt_destroy(ctx); }
+
+const char *vgen_last_error(const vgen_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int vgen_get_info(const vgen_ctx *ctx, uint32_t *batch_size, uint32_t *frames, uint32_t *match_cap) {
+    if (!ctx) return VGEN_E_INVALID;
+    if (batch_size) *batch_size = ctx->batch;
+    if (frames) *frames = ctx->frames;
+    if (match_cap) *match_cap = ctx->match_cap;
+    return VGEN_OK;
+}
+
+int vgen_filter_compile(const char *pattern, int case_insensitive, uint32_t format, vgen_filter **out) {
+    if (!pattern || !out) return VGEN_E_INVALID;
+    vgen_filter *f = new vgen_filter();
+    std::string err;
+    if (!vg::filter_compile(pattern, case_insensitive != 0, format, *f, err)) {
+        g_last_error = err;
+        delete f;
+        return VGEN_E_PATTERN;
+    }
+    *out = f;
+    return VGEN_OK;
+}
+
+void vgen_filter_free(vgen_filter *f) { delete f; }
+
+int vgen_filter_matches(const vgen_filter *f, const char *address) {
+    if (!f || !address) return VGEN_E_INVALID;
+    return f->dfa.is_match(address) ? 1 : 0;
+}
+
+int vgen_filter_device_kind(const vgen_filter *f) { return f ? (int)f->dev.kind : VGEN_E_INVALID; }
+
+int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_set_filter(ctx, f);
+}
+
+int vgen_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_dispatch(ctx, frame, start_key_be);
+}
+
+int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t, const uint8_t *, uint32_t) {
+    if (!ctx) return VGEN_E_INVALID;
+    return ctx->fail(VGEN_E_UNSUPPORTED, "vgen_dispatch_keys: arbitrary-scalar kernel not built yet");
+}
+
+int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
+              uint64_t *keys_tested) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_wait(ctx, frame, out, cap, n_matches, keys_tested);
+}
+
+int vgen_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_read_dump(ctx, frame, out, out_len);
+}
+
+int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {
+    if (!ctx || !ms || frame >= ctx->frames) return VGEN_E_INVALID;
+    *ms = ctx->fr[frame].last_ms;
+    return VGEN_OK;
+}
+
+int vgen_address_from_payload(uint32_t format, const uint8_t *payload, char *out, size_t cap) {
+    if (!payload) return VGEN_E_INVALID;
+    std::string s = vg::address_from_payload(format, payload);
+    if (s.empty()) return VGEN_E_UNSUPPORTED;
+    return copy_out(s, out, cap);
+}
+
+int vgen_key_to_wif(uint32_t format, const uint8_t key_be[32], char *out, size_t cap) {
+    if (!key_be) return VGEN_E_INVALID;
+    vg::Scalar k;
+    vg::scalar_from_be(k, key_be);
+    if (!vg::scalar_is_valid(k)) return VGEN_E_RANGE;
+    return copy_out(vg::key_to_wif(format, key_be), out, cap);
+}
+
+int vgen_key_add(const uint8_t key_be[32], uint64_t amount, uint8_t out_be[32]) {
+    if (!key_be || !out_be) return VGEN_E_INVALID;
+    vg::Scalar k, r;
+    vg::scalar_from_be(k, key_be);
+    uint32_t carry = vg::scalar_add_u64(r, k, amount);
+    vg::scalar_to_be(r, out_be);
+    return (carry || !vg::scalar_is_valid(r)) ? VGEN_E_RANGE : VGEN_OK;
+}
+
+int vgen_derive(uint32_t format, const uint8_t key_be[32], char *address, size_t acap, char *wif, size_t wcap) {
+    if (!key_be) return VGEN_E_INVALID;
+    uint8_t payload[32];
+    int n = vg::payload_from_key(format, key_be, payload);
+    if (n == 0) {
+        vg::Scalar k;
+        vg::scalar_from_be(k, key_be);
+        return vg::scalar_is_valid(k) ? VGEN_E_UNSUPPORTED : VGEN_E_RANGE;
+    }
+    if (address) {
+        int rc = copy_out(vg::address_from_payload(format, payload), address, acap);
+        if (rc < 0) return rc;
+    }
+    if (wif) {
+        int rc = copy_out(vg::key_to_wif(format, key_be), wif, wcap);
+        if (rc < 0) return rc;
+    }
+    return VGEN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// ec.h — secp256k1 group arithmetic over fe (9x29), single source for host and device.
+//
+// Host use: the per-dispatch base point k0*G (what the reference computes with libsecp256k1 in
+// key_to_affine, src/gpu.rs:901-910), the shared offset tables (the reference builds its table on
+// the device in init.wgsl:3-10 with a 256-step double-and-add per entry) and match confirmation.
+// Device use: the arbitrary-scalar (KEYS) kernel's Jacobian accumulation.
+//
+// Curve: y^2 = x^3 + 7 over F_p.  Jacobian (X, Y, Z) <-> (X/Z^2, Y/Z^3); infinity is an explicit flag.
+// All fe results are magnitude 1 unless stated; inputs must be magnitude 1.
+#pragma once
+#include "fe.h"
+
+namespace vg {
+
+struct ge {          // affine point, canonical coordinates
+    fe x, y;
+};
+
+struct gej {
+    fe x, y, z;
+    u32 inf;         // 1 = point at infinity
+};
+
+// r = a - b for magnitude-1 inputs; result weakly normalised (magnitude 1).
+VG_HD void fe_sub_n(fe &r, const fe &a, const fe &b) {
+    fe nb;
+    fe_neg(nb, b, 1);
+    fe_add(r, a, nb);       // magnitude 3
+    fe_normalize_weak(r);
+}
+
+VG_HD bool fe_is_zero_any(const fe &a) {
+    fe t = a;
+    fe_normalize(t);
+    return fe_is_zero_canonical(t);
+}
+
+VG_HD void gej_set_infinity(gej &r) {
+    fe_set_zero(r.x);
+    fe_set_zero(r.y);
+    fe_set_zero(r.z);
+    r.inf = 1;
+}
+
+VG_HD void gej_from_ge(gej &r, const ge &a) {
+    r.x = a.x;
+    r.y = a.y;
+    fe_set_one(r.z);
+    r.inf = 0;
+}
+
+// r = 2a   (dbl-2009-l, a = 0)
+VG_HD void gej_double(gej &r, const gej &a) {
+    if (a.inf) {
+        gej_set_infinity(r);
+        return;
+    }
+    fe A, B, C, D, E, F, t;
+    fe_sqr(A, a.x);
+    fe_sqr(B, a.y);
+    fe_sqr(C, B);
+    fe_add(t, a.x, B);            // m2
+    fe_normalize_weak(t);
+    fe_sqr(t, t);
+    fe_sub_n(t, t, A);
+    fe_sub_n(t, t, C);
+    fe_add(D, t, t);              // D = 2((X+B)^2 - A - C), m2
+    fe_normalize_weak(D);
+    fe_add(E, A, A);
+    fe_add(E, E, A);              // 3A, m3
+    fe_normalize_weak(E);
+    fe_sqr(F, E);
+    fe x3, y3, z3;
+    fe_sub_n(x3, F, D);
+    fe_sub_n(x3, x3, D);
+    fe_sub_n(t, D, x3);
+    fe_mul(y3, E, t);
+    fe c8;
+    fe_add(c8, C, C);
+    fe_add(c8, c8, c8);           // 4C, m4
+    fe_normalize_weak(c8);
+    fe_add(c8, c8, c8);           // 8C, m2
+    fe_normalize_weak(c8);
+    fe_sub_n(y3, y3, c8);
+    fe_mul(z3, a.y, a.z);
+    fe_add(z3, z3, z3);
+    fe_normalize_weak(z3);
+    r.x = x3;
+    r.y = y3;
+    r.z = z3;
+    r.inf = 0;                    // y = 0 has no solution on this curve (order is odd), so 2a != inf
+}
+
+// r = a + b with b affine (madd-2007-bl shape), all special cases handled.
+VG_HD void gej_add_ge(gej &r, const gej &a, const ge &b) {
+    if (a.inf) {
+        gej_from_ge(r, b);
+        return;
+    }
+    fe z1z1, u2, s2, h, rr, hh, hhh, v, t;
+    fe_sqr(z1z1, a.z);
+    fe_mul(u2, b.x, z1z1);
+    fe_mul(t, a.z, z1z1);
+    fe_mul(s2, b.y, t);
+    fe_sub_n(h, u2, a.x);
+    fe_sub_n(rr, s2, a.y);
+    if (fe_is_zero_any(h)) {
+        if (fe_is_zero_any(rr)) {
+            gej_double(r, a);
+        } else {
+            gej_set_infinity(r);
+        }
+        return;
+    }
+    fe_sqr(hh, h);
+    fe_mul(hhh, hh, h);
+    fe_mul(v, a.x, hh);
+    fe x3, y3, z3;
+    fe_sqr(x3, rr);
+    fe_sub_n(x3, x3, hhh);
+    fe_sub_n(x3, x3, v);
+    fe_sub_n(x3, x3, v);
+    fe_sub_n(t, v, x3);
+    fe_mul(y3, rr, t);
+    fe_mul(t, a.y, hhh);
+    fe_sub_n(y3, y3, t);
+    fe_mul(z3, a.z, h);
+    r.x = x3;
+    r.y = y3;
+    r.z = z3;
+    r.inf = 0;
+}
+
+// Affine result of a single Jacobian point (one field inversion).  Returns false for infinity.
+VG_HD bool ge_from_gej(ge &r, const gej &a) {
+    if (a.inf) return false;
+    fe zi, zi2, zi3;
+    fe_inv(zi, a.z);
+    fe_sqr(zi2, zi);
+    fe_mul(zi3, zi2, zi);
+    fe_mul(r.x, a.x, zi2);
+    fe_mul(r.y, a.y, zi3);
+    fe_normalize(r.x);
+    fe_normalize(r.y);
+    return true;
+}
+
+VG_HD void ge_neg(ge &r, const ge &a) {
+    r.x = a.x;
+    fe_neg(r.y, a.y, 1);
+    fe_normalize(r.y);
+}
+
+// Generator (cross-checked against src/shaders/field.wgsl:346-347 by the CPU tests)
+VG_HD void ge_generator(ge &g) {
+    const u32 gx[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu, 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
+    const u32 gy[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u, 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
+    fe_from_words(g.x, gx);
+    fe_from_words(g.y, gy);
+}
+
+}  // namespace vg

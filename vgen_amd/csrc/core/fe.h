@@ -1,0 +1,273 @@
+// fe.h — arithmetic in F_p, p = 2^256 - 2^32 - 977 (secp256k1 base field), 9 limbs x 29 bits.
+//
+// Single source for the HIP kernels (hipcc, gfx950) and for the host side of libvgen_hip.so
+// (base-point / table construction, match confirmation) and its CPU unit tests (g++).
+//
+// Why 9x29 and not the reference's 8x32 (src/shaders/field.wgsl:18-210): measured on MI355X
+// (tools/ubench_valu.hip, profiles/r01_ubench_valu.jsonl) every carry-flag instruction
+// (v_add_co/v_addc) issues at half rate AND needs a wait state before its consumer, while
+// v_mad_u64_u32 (32x32+64 -> 64) and v_lshl_add_u64 run at the same half rate with no flags.
+// A reduced radix with 3 spare bits per limb lets all 81 partial products of a multiplication
+// be accumulated in 64-bit column sums by chained v_mad_u64_u32 with no carry handling at all,
+// and makes field add/sub/negate nine independent full-rate 32-bit adds.
+//
+// Representation: value = sum n[i] * 2^(29 i).  "magnitude m": n[0..7] <= m*(2^29-1) and
+// n[8] <= m*2^24; m <= 7 always (7*2^29 < 2^32).  Every function states the magnitudes it accepts
+// and returns; products require m_a * m_b <= 6 so that a column sum of nine products of size
+// m_a*m_b*2^58 plus the incoming carry stays below 2^64.  Canonical = magnitude 1 and value < p
+// (fe_normalize).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VG_HD __host__ __device__ __forceinline__
+#else
+#define VG_HD inline
+#endif
+
+namespace vg {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct fe {
+    u32 n[9];
+};
+
+constexpr u32 FE_M29 = 0x1FFFFFFFu;
+constexpr u32 FE_M24 = 0x00FFFFFFu;
+// p in 29-bit limbs
+constexpr u32 FE_P0 = 0x1FFFFC2Fu, FE_P1 = 0x1FFFFFF7u, FE_PM = 0x1FFFFFFFu, FE_P8 = 0x00FFFFFFu;
+// 2^261 mod p = 2^37 + 0x7A20  ->  R1 * 2^29 + R0
+constexpr u32 FE_R0 = 0x7A20u, FE_R1 = 0x100u;
+
+VG_HD void fe_set_zero(fe &r) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.n[i] = 0;
+}
+
+VG_HD void fe_set_one(fe &r) {
+    fe_set_zero(r);
+    r.n[0] = 1;
+}
+
+// r = a + b.  magnitude m_a + m_b.
+VG_HD void fe_add(fe &r, const fe &a, const fe &b) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.n[i] = a.n[i] + b.n[i];
+}
+
+// r = -a for a of magnitude <= m.  Result magnitude m + 1.   ((m+1)*p - a, limb-wise, no borrows)
+VG_HD void fe_neg(fe &r, const fe &a, u32 m) {
+    const u32 k = m + 1;
+    r.n[0] = k * FE_P0 - a.n[0];
+    r.n[1] = k * FE_P1 - a.n[1];
+#pragma unroll
+    for (int i = 2; i < 8; i++) r.n[i] = k * FE_PM - a.n[i];
+    r.n[8] = k * FE_P8 - a.n[8];
+}
+
+// Shared tail of mul/sqr: e[0..16] are 29-bit digits of the product, e[17] the rest (< 2^32 for
+// m_a*m_b <= 6).  Folds digits 9..17 with 2^261 = R1*2^29 + R0 and the bits above 2^256 with
+// 2^256 = 2^32 + 977, leaving magnitude 1 with n[8] <= 2^24 (value < 2^256 + 2^233).
+VG_HD void fe_fold_(fe &r, const u32 *e) {
+    u64 c;
+    u32 f[8];
+    // d_k = e_k + e_{9+k}*R0 + e_{8+k}*R1, carried forward
+    c = (u64)e[9] * FE_R0 + e[0];
+    f[0] = (u32)c & FE_M29; c >>= 29;
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        c += (u64)e[9 + k] * FE_R0 + (u64)e[8 + k] * FE_R1 + e[k];
+        f[k] = (u32)c & FE_M29; c >>= 29;
+    }
+    // top limb (weight 2^232): c < 2^48.  Digit 17's R1 term has weight 2^261 = 2^5 * 2^256 and goes
+    // straight into the overflow word.
+    c += (u64)e[17] * FE_R0 + (u64)e[16] * FE_R1 + e[8];
+    u32 n8 = (u32)c & FE_M24;
+    u64 ov = (c >> 24) + (((u64)e[17] * FE_R1) << 5);   // weight 2^256 == 8*2^29 + 977;  ov < 2^46
+    u64 t0 = ov * 977u + f[0];        // < 2^56
+    u32 r0 = (u32)t0 & FE_M29;
+    u64 t1 = (t0 >> 29) + ov * 8u + f[1];
+    u32 r1 = (u32)t1 & FE_M29;
+    u32 cc = (u32)(t1 >> 29);         // < 2^21
+    r.n[0] = r0;
+    r.n[1] = r1;
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        cc += f[k];
+        r.n[k] = cc & FE_M29;
+        cc >>= 29;
+    }
+    r.n[8] = n8 + cc;                 // <= 2^24
+}
+
+// r = a * b.  Requires m_a * m_b <= 6.  Result magnitude 1.
+VG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
+    u32 e[18];
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 9) c += (u64)a.n[i] * b.n[j];
+        }
+        e[k] = (u32)c & FE_M29;
+        c >>= 29;
+    }
+    e[17] = (u32)c;
+    fe_fold_(r, e);
+}
+
+// r = a^2.  Requires m_a <= 1 (the doubled cross terms use 2*a_i).  Result magnitude 1.
+VG_HD void fe_sqr(fe &r, const fe &a) {
+    u32 e[18];
+    u32 d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 9 && i < j) c += (u64)d[i] * a.n[j];
+            if (j == i) c += (u64)a.n[i] * a.n[i];
+        }
+        e[k] = (u32)c & FE_M29;
+        c >>= 29;
+    }
+    e[17] = (u32)c;
+    fe_fold_(r, e);
+}
+
+// Weak normalisation: any magnitude <= 7 in, magnitude 1 out (value unchanged mod p, < 2^256 + 2^233).
+VG_HD void fe_normalize_weak(fe &r) {
+    u32 c = r.n[0];
+    u32 t[9];
+    t[0] = c & FE_M29; c >>= 29;
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        c += r.n[k];
+        t[k] = c & FE_M29; c >>= 29;
+    }
+    c += r.n[8];
+    u32 ov = c >> 24;                 // < 2^8
+    t[8] = c & FE_M24;
+    c = t[0] + ov * 977u;
+    r.n[0] = c & FE_M29; c >>= 29;
+    c += t[1] + ov * 8u;
+    r.n[1] = c & FE_M29; c >>= 29;
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        c += t[k];
+        r.n[k] = c & FE_M29; c >>= 29;
+    }
+    r.n[8] = t[8] + c;
+}
+
+// Full normalisation to the canonical representative in [0, p).  Any magnitude <= 7 in.
+VG_HD void fe_normalize(fe &r) {
+    fe_normalize_weak(r);             // value < 2^256 + 2^233, limbs in range
+    // one more top fold: n[8] may be exactly 2^24 (bit 24 set)
+    u32 ov = r.n[8] >> 24;
+    r.n[8] &= FE_M24;
+    // now value < 2^256; add ov*C and decide whether value >= p.  Adding C = 2^32+977 and checking
+    // bit 256 of (value + C) tells value >= p, because p + C = 2^256.
+    u32 t[9];
+    u32 c = r.n[0] + ov * 977u;
+    t[0] = c & FE_M29; c >>= 29;
+    c += r.n[1] + ov * 8u;
+    t[1] = c & FE_M29; c >>= 29;
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        c += r.n[k];
+        t[k] = c & FE_M29; c >>= 29;
+    }
+    t[8] = r.n[8] + c;                // < 2^24 + 1; cannot reach 2^25
+    // t < 2^256 + small and t == value (mod p).  If the ov fold pushed bit 24 of t[8] up again it
+    // is still < p + C, handled by the same test below.
+    // u = t + C; if u >= 2^256 then t >= p and the canonical value is u - 2^256.
+    u32 u[9];
+    c = t[0] + 977u;
+    u[0] = c & FE_M29; c >>= 29;
+    c += t[1] + 8u;
+    u[1] = c & FE_M29; c >>= 29;
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        c += t[k];
+        u[k] = c & FE_M29; c >>= 29;
+    }
+    c += t[8];
+    u[8] = c & FE_M24;
+    const bool ge = (c >> 24) != 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.n[k] = ge ? u[k] : t[k];
+}
+
+VG_HD bool fe_is_zero_canonical(const fe &a) {
+    u32 z = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) z |= a.n[i];
+    return z == 0;
+}
+
+VG_HD bool fe_equal_canonical(const fe &a, const fe &b) {
+    u32 z = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) z |= a.n[i] ^ b.n[i];
+    return z == 0;
+}
+
+// Canonical fe -> eight 32-bit words, w[0] least significant (the reference's limb order,
+// src/gpu.rs:891-899).
+VG_HD void fe_to_words(const fe &a, u32 w[8]) {
+    w[0] = a.n[0] | (a.n[1] << 29);
+    w[1] = (a.n[1] >> 3) | (a.n[2] << 26);
+    w[2] = (a.n[2] >> 6) | (a.n[3] << 23);
+    w[3] = (a.n[3] >> 9) | (a.n[4] << 20);
+    w[4] = (a.n[4] >> 12) | (a.n[5] << 17);
+    w[5] = (a.n[5] >> 15) | (a.n[6] << 14);
+    w[6] = (a.n[6] >> 18) | (a.n[7] << 11);
+    w[7] = (a.n[7] >> 21) | (a.n[8] << 8);
+}
+
+VG_HD void fe_from_words(fe &r, const u32 w[8]) {
+    r.n[0] = w[0] & FE_M29;
+    r.n[1] = ((w[0] >> 29) | (w[1] << 3)) & FE_M29;
+    r.n[2] = ((w[1] >> 26) | (w[2] << 6)) & FE_M29;
+    r.n[3] = ((w[2] >> 23) | (w[3] << 9)) & FE_M29;
+    r.n[4] = ((w[3] >> 20) | (w[4] << 12)) & FE_M29;
+    r.n[5] = ((w[4] >> 17) | (w[5] << 15)) & FE_M29;
+    r.n[6] = ((w[5] >> 14) | (w[6] << 18)) & FE_M29;
+    r.n[7] = ((w[6] >> 11) | (w[7] << 21)) & FE_M29;
+    r.n[8] = w[7] >> 8;
+}
+
+// r = a^-1 (a != 0, magnitude 1).  Fermat, a^(p-2), with the standard secp256k1 addition chain
+// (255 squarings + 15 multiplications).  inv(0) = 0.
+VG_HD void fe_sqr_n_(fe &r, int n) {
+    for (int i = 0; i < n; i++) fe_sqr(r, r);
+}
+
+VG_HD void fe_inv(fe &r, const fe &a) {
+    fe x2, x3, x6, x9, x11, x22, x44, x88, x176, x220, x223, t1;
+    fe_sqr(x2, a);        fe_mul(x2, x2, a);
+    fe_sqr(x3, x2);       fe_mul(x3, x3, a);
+    x6 = x3;   fe_sqr_n_(x6, 3);    fe_mul(x6, x6, x3);
+    x9 = x6;   fe_sqr_n_(x9, 3);    fe_mul(x9, x9, x3);
+    x11 = x9;  fe_sqr_n_(x11, 2);   fe_mul(x11, x11, x2);
+    x22 = x11; fe_sqr_n_(x22, 11);  fe_mul(x22, x22, x11);
+    x44 = x22; fe_sqr_n_(x44, 22);  fe_mul(x44, x44, x22);
+    x88 = x44; fe_sqr_n_(x88, 44);  fe_mul(x88, x88, x44);
+    x176 = x88; fe_sqr_n_(x176, 88); fe_mul(x176, x176, x88);
+    x220 = x176; fe_sqr_n_(x220, 44); fe_mul(x220, x220, x44);
+    x223 = x220; fe_sqr_n_(x223, 3);  fe_mul(x223, x223, x3);
+    t1 = x223; fe_sqr_n_(t1, 23);   fe_mul(t1, t1, x22);
+    fe_sqr_n_(t1, 5);    fe_mul(t1, t1, a);
+    fe_sqr_n_(t1, 3);    fe_mul(t1, t1, x2);
+    fe_sqr_n_(t1, 2);    fe_mul(r, t1, a);
+}
+
+}  // namespace vg

@@ -1,0 +1,104 @@
+// filter_eval.h — evaluation of the device prefilter program on one payload; single source for the
+// kernels and for the host (tests run it against the DFA on encoded addresses).
+//
+// In the reference every hash160 crosses PCIe and the host encodes + regex-matches all of them
+// (src/gpu.rs:1030-1093).  Here the device applies a necessary condition derived from the pattern
+// and only candidates are reported; the host confirms them with the exact DFA (filter.cpp).
+#pragma once
+#include "../device/device_types.h"
+#include "hash.h"
+
+namespace vg {
+
+// -1 / 0 / +1 for 160-bit big-endian word arrays
+VG_HD int cmp160(const u32 a[5], const u32 b[5]) {
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        int d = (a[i] > b[i]) - (a[i] < b[i]);
+        c = (c == 0) ? d : c;
+    }
+    return c;
+}
+
+VG_HD u32 bech32_polymod_step(u32 c, u32 v) {
+    const u32 b = c >> 25;
+    c = ((c & 0x1FFFFFFu) << 5) ^ v;
+    c ^= (0u - ((b >> 0) & 1u)) & 0x3b6a57b2u;
+    c ^= (0u - ((b >> 1) & 1u)) & 0x26508e6du;
+    c ^= (0u - ((b >> 2) & 1u)) & 0x1ea119fau;
+    c ^= (0u - ((b >> 3) & 1u)) & 0x3d4233ddu;
+    c ^= (0u - ((b >> 4) & 1u)) & 0x2a1462b3u;
+    return c;
+}
+
+// Bech32 checksum (30 bits; first checksum symbol in bits 29..25) of a v0 witness program given as
+// five big-endian words, hrp "bc".  `witver` is the witness-version symbol; for witver != 0 the
+// Bech32m constant applies (BIP-350).
+VG_HD u32 bech32_checksum_bc20(const u32 H[5], u32 witver) {
+    // polymod over hrp-expand("bc") = {3, 3, 0, 2, 3}
+    u32 c = 1;
+    c = bech32_polymod_step(c, 3);
+    c = bech32_polymod_step(c, 3);
+    c = bech32_polymod_step(c, 0);
+    c = bech32_polymod_step(c, 2);
+    c = bech32_polymod_step(c, 3);
+    c = bech32_polymod_step(c, witver);
+#pragma unroll
+    for (int s = 0; s < 32; s++) {
+        const int bit = 5 * s;           // offset from the most significant bit of H[0]
+        const int w = bit >> 5, o = bit & 31;
+        u32 v;
+        if (o <= 27) {
+            v = (H[w] >> (27 - o)) & 31u;
+        } else {
+            v = ((H[w] << (o - 27)) | (H[w + 1] >> (59 - o))) & 31u;
+        }
+        c = bech32_polymod_step(c, v);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) c = bech32_polymod_step(c, 0);
+    return c ^ (witver == 0 ? 1u : 0x2bc830a3u);
+}
+
+// payload: five words in memory order (little-endian words of the 20-byte string).
+VG_HD bool filter_eval(const DevFilter *f, const u32 payload[5]) {
+    const u32 kind = f->kind;
+    if (kind == DEVF_ALL || kind == DEVF_HOST_ALL) return true;
+    u32 H[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) H[i] = bswap32(payload[i]);
+    const u32 n = f->count;
+    bool hit = false;
+    if (kind == DEVF_RANGES) {
+        for (u32 t = 0; t < n; t++) {
+            const DevFilterTest &T = f->tests[t];
+            hit = hit || (cmp160(H, T.a) >= 0 && cmp160(H, T.b) <= 0);
+        }
+        return hit;
+    }
+    // DEVF_MASKED
+    u32 chk = 0;
+    const bool need_chk = (f->flags & DEVF_FLAG_BECH32_CHK) != 0;
+    bool any_data = false;
+    for (u32 t = 0; t < n; t++) {
+        const DevFilterTest &T = f->tests[t];
+        u32 diff = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) diff |= (H[i] & T.a[i]) ^ T.b[i];
+        any_data = any_data || (diff == 0);
+    }
+    if (!need_chk) return any_data;
+    if (!any_data) return false;         // the (expensive) checksum only for data-part survivors
+    chk = bech32_checksum_bc20(H, f->witver);
+    for (u32 t = 0; t < n; t++) {
+        const DevFilterTest &T = f->tests[t];
+        u32 diff = (chk & T.chk_mask) ^ T.chk_value;
+#pragma unroll
+        for (int i = 0; i < 5; i++) diff |= (H[i] & T.a[i]) ^ T.b[i];
+        hit = hit || (diff == 0);
+    }
+    return hit;
+}
+
+}  // namespace vg

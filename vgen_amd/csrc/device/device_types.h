@@ -1,0 +1,79 @@
+// device_types.h — plain-data structures shared between the HIP kernels and the host runtime.
+#pragma once
+#include <stdint.h>
+
+namespace vg {
+
+// vgen_format values (include/vgen_hip.h), usable as template arguments in device code
+enum : int {
+    VGF_P2PKH = 0,
+    VGF_P2WPKH = 1,
+    VGF_P2SH_P2WPKH = 2,
+    VGF_P2TR = 3,
+    VGF_P2PKH_UNCOMPRESSED = 4,
+    VGF_ETHEREUM = 5
+};
+
+
+// Device-side prefilter program (built by host/filter.cpp from the pattern's DFA).
+// The test runs on the 160-bit payload seen as five BIG-endian words H[0..4] (H[0] = bytes 0..3).
+enum : uint32_t {
+    DEVF_HOST_ALL = 0,   // no usable prefilter: every key is a candidate (dump + host filter)
+    DEVF_RANGES = 1,     // any r:  lo_r <= H <= hi_r           (Base58 prefixes)
+    DEVF_MASKED = 2,     // any t:  (H & mask_t) == value_t     (Bech32 / hex prefixes & suffixes)
+    DEVF_ALL = 3         // pattern accepts every address
+};
+
+constexpr uint32_t DEVF_MAX_TESTS = 64;
+constexpr uint32_t DEVF_FLAG_BECH32_CHK = 1u;   // masked tests also constrain the bech32 checksum
+
+struct DevFilterTest {
+    uint32_t a[5];       // ranges: lo      masked: mask
+    uint32_t b[5];       // ranges: hi      masked: value
+    uint32_t chk_mask;   // bech32 checksum (30 bits, first symbol in bits 29..25)
+    uint32_t chk_value;
+};
+
+struct DevFilter {
+    uint32_t kind;
+    uint32_t count;
+    uint32_t flags;
+    uint32_t witver;     // bech32: witness version symbol (0 for P2WPKH)
+    DevFilterTest tests[DEVF_MAX_TESTS];
+};
+
+// Match ring of one frame (device memory).  count may run past cap; records beyond cap are dropped.
+struct DevMatch {
+    uint32_t index;
+    uint32_t reserved;
+    uint32_t payload[8];
+};
+
+struct DevMatchHeader {
+    uint32_t count;
+    uint32_t cap;
+    uint32_t pad[2];
+};
+
+// Per-dispatch uniform points of the sequential kernel: Q_j = (k0 + N/2 - S/2 + j)*G and the
+// canonical negations of their coordinates, nine 29-bit limbs each.
+struct DevSeqQ {
+    uint32_t qx[9], qy[9], nqx[9], nqy[9];
+};
+
+constexpr uint32_t SEQ_MAX_S = 32;
+
+struct SeqArgs {
+    const uint32_t *rtab;      // offset table, limb-major: [18][lanes]  (x limbs 0..8, y limbs 0..8)
+    const DevSeqQ *q;          // [S]
+    const DevFilter *filter;   // used when dump == nullptr
+    uint32_t *dump;            // dump mode: N * 5 words (or N * 8 for 32-byte payloads)
+    DevMatchHeader *mhdr;      // filter mode
+    DevMatch *mrec;
+    uint32_t lanes;            // N / (2*S)
+    uint32_t n;                // N
+    uint32_t s;                // S
+    uint32_t pad;
+};
+
+}  // namespace vg

@@ -1,0 +1,12 @@
+// launch.h — what the host runtime sees of the kernels (no HIP device code here).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "device_types.h"
+
+namespace vg {
+
+// Enqueues the sequential-range scan on `stream`.  a.lanes must be a multiple of 256.
+hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream);
+
+}  // namespace vg

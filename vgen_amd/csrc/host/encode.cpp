@@ -1,0 +1,263 @@
+// encode.cpp — see encode.h.
+#include "encode.h"
+
+#include <string.h>
+
+#include <vector>
+
+#include "../core/hash.h"
+#include "../device/device_types.h"
+#include "host_ec.h"
+
+namespace vg {
+
+// ---- general-length hashing on top of the single-source block functions ------------------------------
+
+void host_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
+    u32 st[8];
+    for (int i = 0; i < 8; i++) st[i] = SHA256_IV[i];
+    std::vector<uint8_t> buf(msg, msg + len);
+    buf.push_back(0x80);
+    while (buf.size() % 64 != 56) buf.push_back(0);
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 7; i >= 0; i--) buf.push_back((uint8_t)(bits >> (8 * i)));
+    for (size_t off = 0; off < buf.size(); off += 64) {
+        u32 w[16];
+        for (int i = 0; i < 16; i++) {
+            const uint8_t *p = &buf[off + 4 * i];
+            w[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | p[3];
+        }
+        sha256_compress(st, w);
+    }
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (uint8_t)(st[i] >> 24);
+        out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+        out[4 * i + 2] = (uint8_t)(st[i] >> 8);
+        out[4 * i + 3] = (uint8_t)st[i];
+    }
+}
+
+void host_ripemd160(const uint8_t *msg, size_t len, uint8_t out[20]) {
+    u32 st[5];
+    for (int i = 0; i < 5; i++) st[i] = RMD160_IV[i];
+    std::vector<uint8_t> buf(msg, msg + len);
+    buf.push_back(0x80);
+    while (buf.size() % 64 != 56) buf.push_back(0);
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(bits >> (8 * i)));
+    for (size_t off = 0; off < buf.size(); off += 64) {
+        u32 x[16];
+        for (int i = 0; i < 16; i++) {
+            const uint8_t *p = &buf[off + 4 * i];
+            x[i] = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+        }
+        ripemd160_compress(st, x);
+    }
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 4; j++) out[4 * i + j] = (uint8_t)(st[i] >> (8 * j));
+}
+
+void host_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]) {
+    const size_t RATE = 136;
+    u64 a[25];
+    memset(a, 0, sizeof a);
+    std::vector<uint8_t> buf(msg, msg + len);
+    buf.push_back(0x01);
+    while (buf.size() % RATE != 0) buf.push_back(0);
+    buf.back() |= 0x80;
+    for (size_t off = 0; off < buf.size(); off += RATE) {
+        for (size_t i = 0; i < RATE / 8; i++) {
+            u64 w = 0;
+            for (int j = 7; j >= 0; j--) w = (w << 8) | buf[off + 8 * i + j];
+            a[i] ^= w;
+        }
+        keccak_f1600(a);
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(a[i] >> (8 * j));
+}
+
+void host_hash160(const uint8_t *msg, size_t len, uint8_t out[20]) {
+    uint8_t d[32];
+    host_sha256(msg, len, d);
+    host_ripemd160(d, 32, out);
+}
+
+// ---- encoders --------------------------------------------------------------------------------------------
+
+static const char B58[] = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz";
+static const char BECH32[] = "qpzry9x8gf2tvdw0s3jn54khce6mua7l";
+
+std::string base58_encode(const uint8_t *data, size_t len) {
+    size_t zeros = 0;
+    while (zeros < len && data[zeros] == 0) zeros++;
+    std::vector<uint8_t> digits;   // little-endian base 58
+    for (size_t i = zeros; i < len; i++) {
+        uint32_t carry = data[i];
+        for (auto &d : digits) {
+            carry += (uint32_t)d << 8;
+            d = (uint8_t)(carry % 58);
+            carry /= 58;
+        }
+        while (carry) {
+            digits.push_back((uint8_t)(carry % 58));
+            carry /= 58;
+        }
+    }
+    std::string out(zeros, '1');
+    for (size_t i = digits.size(); i-- > 0;) out.push_back(B58[digits[i]]);
+    return out;
+}
+
+std::string base58check(const uint8_t *payload, size_t len) {
+    std::vector<uint8_t> buf(payload, payload + len);
+    uint8_t d1[32], d2[32];
+    host_sha256(payload, len, d1);
+    host_sha256(d1, 32, d2);
+    buf.insert(buf.end(), d2, d2 + 4);
+    return base58_encode(buf.data(), buf.size());
+}
+
+static uint32_t polymod_step(uint32_t c, uint32_t v) {
+    static const uint32_t GEN[5] = {0x3b6a57b2u, 0x26508e6du, 0x1ea119fau, 0x3d4233ddu, 0x2a1462b3u};
+    uint32_t b = c >> 25;
+    c = ((c & 0x1FFFFFFu) << 5) ^ v;
+    for (int i = 0; i < 5; i++)
+        if ((b >> i) & 1) c ^= GEN[i];
+    return c;
+}
+
+std::string segwit_address(const char *hrp, int witver, const uint8_t *prog, size_t len) {
+    std::vector<uint8_t> data;
+    data.push_back((uint8_t)witver);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = 0; i < len; i++) {
+        acc = (acc << 8) | prog[i];
+        bits += 8;
+        while (bits >= 5) {
+            bits -= 5;
+            data.push_back((acc >> bits) & 31);
+        }
+    }
+    if (bits) data.push_back((acc << (5 - bits)) & 31);
+    uint32_t c = 1;
+    std::string h(hrp);
+    for (char ch : h) c = polymod_step(c, (uint8_t)ch >> 5);
+    c = polymod_step(c, 0);
+    for (char ch : h) c = polymod_step(c, ch & 31);
+    for (uint8_t d : data) c = polymod_step(c, d);
+    for (int i = 0; i < 6; i++) c = polymod_step(c, 0);
+    c ^= witver == 0 ? 1u : 0x2bc830a3u;
+    std::string out = h + "1";
+    for (uint8_t d : data) out.push_back(BECH32[d]);
+    for (int i = 0; i < 6; i++) out.push_back(BECH32[(c >> (5 * (5 - i))) & 31]);
+    return out;
+}
+
+std::string hex_lower(const uint8_t *data, size_t len) {
+    static const char HX[] = "0123456789abcdef";
+    std::string s;
+    s.reserve(2 * len);
+    for (size_t i = 0; i < len; i++) {
+        s.push_back(HX[data[i] >> 4]);
+        s.push_back(HX[data[i] & 15]);
+    }
+    return s;
+}
+
+std::string eip55_address(const uint8_t addr20[20]) {
+    std::string lower = hex_lower(addr20, 20);
+    uint8_t h[32];
+    host_keccak256((const uint8_t *)lower.data(), 40, h);
+    std::string out = "0x";
+    for (int i = 0; i < 40; i++) {
+        int nib = (i & 1) ? (h[i / 2] & 15) : (h[i / 2] >> 4);
+        char c = lower[i];
+        if (nib >= 8 && c >= 'a' && c <= 'f') c = (char)(c - 'a' + 'A');
+        out.push_back(c);
+    }
+    return out;
+}
+
+std::string address_from_payload(uint32_t format, const uint8_t *payload) {
+    uint8_t buf[21];
+    switch (format) {
+    case VGF_P2PKH:
+    case VGF_P2PKH_UNCOMPRESSED:
+        buf[0] = 0x00;
+        memcpy(buf + 1, payload, 20);
+        return base58check(buf, 21);
+    case VGF_P2SH_P2WPKH:
+        buf[0] = 0x05;
+        memcpy(buf + 1, payload, 20);
+        return base58check(buf, 21);
+    case VGF_P2WPKH:
+        return segwit_address("bc", 0, payload, 20);
+    case VGF_P2TR:
+        return segwit_address("bc", 1, payload, 32);
+    case VGF_ETHEREUM:
+        return eip55_address(payload);
+    default:
+        return std::string();
+    }
+}
+
+std::string key_to_wif(uint32_t format, const uint8_t key_be[32]) {
+    if (format == VGF_ETHEREUM) return hex_lower(key_be, 32);
+    uint8_t buf[34];
+    buf[0] = 0x80;
+    memcpy(buf + 1, key_be, 32);
+    size_t n = 33;
+    if (format != VGF_P2PKH_UNCOMPRESSED) buf[n++] = 0x01;
+    return base58check(buf, n);
+}
+
+static void fe_to_be32(const fe &a, uint8_t out[32]) {
+    u32 w[8];
+    fe_to_words(a, w);
+    for (int i = 0; i < 8; i++) {
+        out[4 * (7 - i)] = (uint8_t)(w[i] >> 24);
+        out[4 * (7 - i) + 1] = (uint8_t)(w[i] >> 16);
+        out[4 * (7 - i) + 2] = (uint8_t)(w[i] >> 8);
+        out[4 * (7 - i) + 3] = (uint8_t)w[i];
+    }
+}
+
+int payload_from_key(uint32_t format, const uint8_t key_be[32], uint8_t out[32]) {
+    Scalar k;
+    scalar_from_be(k, key_be);
+    if (!scalar_is_valid(k)) return 0;
+    ge p;
+    if (!host_ec_mul_gen(k, p)) return 0;
+    uint8_t pub65[65], pub33[33], h[20], script[22], kk[32];
+    pub65[0] = 0x04;
+    fe_to_be32(p.x, pub65 + 1);
+    fe_to_be32(p.y, pub65 + 33);
+    pub33[0] = (pub65[64] & 1) ? 0x03 : 0x02;
+    memcpy(pub33 + 1, pub65 + 1, 32);
+    switch (format) {
+    case VGF_P2PKH:
+    case VGF_P2WPKH:
+        host_hash160(pub33, 33, out);
+        return 20;
+    case VGF_P2PKH_UNCOMPRESSED:
+        host_hash160(pub65, 65, out);
+        return 20;
+    case VGF_P2SH_P2WPKH:
+        host_hash160(pub33, 33, h);
+        script[0] = 0x00;
+        script[1] = 0x14;
+        memcpy(script + 2, h, 20);
+        host_hash160(script, 22, out);
+        return 20;
+    case VGF_ETHEREUM:
+        host_keccak256(pub65 + 1, 64, kk);
+        memcpy(out, kk + 12, 20);
+        return 20;
+    default:
+        return 0;   // P2TR: next
+    }
+}
+
+}  // namespace vg

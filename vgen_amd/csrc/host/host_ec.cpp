@@ -1,0 +1,106 @@
+// host_ec.cpp — see host_ec.h.
+#include "host_ec.h"
+
+#include <mutex>
+
+namespace vg {
+
+namespace {
+
+// 64 windows x 16 digits of a 4-bit fixed-base table: tbl[w][d] = d * 16^w * G (d = 0 unused).
+ge g_gen_table[64][16];
+std::once_flag g_gen_once;
+
+void build_gen_table() {
+    std::vector<gej> jac;
+    jac.reserve(64 * 15);
+    ge g;
+    ge_generator(g);
+    gej base;
+    gej_from_ge(base, g);
+    for (int w = 0; w < 64; w++) {
+        // the window base must be affine for the mixed additions below
+        ge base_aff;
+        ge_from_gej(base_aff, base);
+        gej acc;
+        gej_set_infinity(acc);
+        for (int d = 1; d < 16; d++) {
+            gej_add_ge(acc, acc, base_aff);
+            jac.push_back(acc);
+        }
+        for (int k = 0; k < 4; k++) gej_double(base, base);
+    }
+    std::vector<ge> aff(jac.size());
+    host_batch_to_affine(jac.data(), aff.data(), jac.size());
+    for (int w = 0; w < 64; w++)
+        for (int d = 1; d < 16; d++) g_gen_table[w][d] = aff[(size_t)w * 15 + (d - 1)];
+}
+
+}  // namespace
+
+void host_batch_to_affine(const gej *in, ge *out, size_t n) {
+    if (n == 0) return;
+    std::vector<fe> pre(n);
+    pre[0] = in[0].z;
+    for (size_t i = 1; i < n; i++) fe_mul(pre[i], pre[i - 1], in[i].z);
+    fe inv;
+    fe_inv(inv, pre[n - 1]);
+    for (size_t i = n; i-- > 0;) {
+        fe zi;
+        if (i > 0) {
+            fe_mul(zi, inv, pre[i - 1]);
+            fe_mul(inv, inv, in[i].z);
+        } else {
+            zi = inv;
+        }
+        fe zi2, zi3;
+        fe_sqr(zi2, zi);
+        fe_mul(zi3, zi2, zi);
+        fe_mul(out[i].x, in[i].x, zi2);
+        fe_mul(out[i].y, in[i].y, zi3);
+        fe_normalize(out[i].x);
+        fe_normalize(out[i].y);
+    }
+}
+
+bool host_ec_mul_gen(const Scalar &k, ge &out) {
+    std::call_once(g_gen_once, build_gen_table);
+    gej acc;
+    gej_set_infinity(acc);
+    for (int w = 0; w < 64; w++) {
+        uint32_t d = (k.w[w >> 3] >> ((w & 7) * 4)) & 15u;
+        if (d) gej_add_ge(acc, acc, g_gen_table[w][d]);
+    }
+    return ge_from_gej(out, acc);
+}
+
+void host_build_stride_table(uint64_t first, uint64_t step, uint32_t count, std::vector<ge> &out) {
+    out.resize(count);
+    if (count == 0) return;
+    Scalar s;
+    memset(&s, 0, sizeof s);
+    s.w[0] = (uint32_t)first;
+    s.w[1] = (uint32_t)(first >> 32);
+    ge p0, st;
+    host_ec_mul_gen(s, p0);
+    s.w[0] = (uint32_t)step;
+    s.w[1] = (uint32_t)(step >> 32);
+    host_ec_mul_gen(s, st);
+
+    const uint32_t CHUNK = 4096;
+    std::vector<gej> jac(CHUNK);
+    gej cur;
+    gej_from_ge(cur, p0);
+    for (uint32_t done = 0; done < count;) {
+        uint32_t n = count - done < CHUNK ? count - done : CHUNK;
+        for (uint32_t i = 0; i < n; i++) {
+            jac[i] = cur;
+            gej_add_ge(cur, cur, st);
+        }
+        host_batch_to_affine(jac.data(), out.data() + done, n);
+        // restart the chain from an affine point to keep Z small-degree (not required, but cheap)
+        done += n;
+    }
+}
+
+}  // namespace vg

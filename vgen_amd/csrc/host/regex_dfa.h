@@ -1,0 +1,37 @@
+// regex_dfa.h — pattern front end of libvgen_hip.so: regex subset -> NFA -> DFA.
+//
+// Stands in for regex::Regex as the reference uses it (src/pattern.rs:21-45): Pattern::new compiles
+// "(?i)"+pattern when case-insensitive, Pattern::matches is an UNANCHORED is_match over the address
+// string.  Address strings are ASCII, so the DFA works on bytes; syntax the subset does not cover
+// (\b, \p{..}, class set operations, flags other than i) is rejected with an error instead of being
+// approximated.  The DFA is used (a) on the host to confirm every device candidate exactly and
+// (b) by filter.cpp to derive the device prefilter (accepted prefixes / fixed suffixes).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace vg {
+
+struct Dfa {
+    // byte -> symbol class (bytes >= 128 share one class that only '.' and negated classes accept)
+    uint8_t cls[256];
+    uint32_t n_cls = 0;
+    // trans[state * n_cls + class]; state 0 = start
+    std::vector<uint32_t> trans;
+    // flags per state
+    std::vector<uint8_t> match_now;     // pattern already matched (absorbing)
+    std::vector<uint8_t> match_at_end;  // matches if the haystack ends here
+    std::vector<uint8_t> dead;          // no match reachable any more
+    uint32_t n_states = 0;
+
+    bool is_match(const char *text) const;
+    bool is_match(const std::string &s) const { return is_match(s.c_str()); }
+};
+
+// Compiles `pattern`; returns false and sets err on empty/invalid/unsupported patterns
+// ("Pattern cannot be empty" / "Invalid regex pattern: ..." as in src/pattern.rs:22-33).
+bool regex_compile(const std::string &pattern, bool case_insensitive, Dfa &out, std::string &err);
+
+}  // namespace vg

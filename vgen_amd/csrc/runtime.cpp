@@ -1,0 +1,273 @@
+// runtime.cpp — see runtime.h.
+#include "runtime.h"
+
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "device/launch.h"
+#include "host/host_ec.h"
+
+namespace vg {
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return (ctx)->fail(VGEN_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+constexpr uint32_t FIRST_COPY = 256;   // match records fetched together with the header
+
+size_t match_bytes(uint32_t n) { return sizeof(DevMatchHeader) + (size_t)n * sizeof(DevMatch); }
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    long x = strtol(v, nullptr, 10);
+    return x > 0 ? (uint32_t)x : dflt;
+}
+
+void fe_canon_neg(fe &r, const fe &a) {
+    fe_neg(r, a, 1);
+    fe_normalize(r);
+}
+
+}  // namespace
+
+int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
+    if (!p || !out || p->struct_size != sizeof(vgen_params)) {
+        err = "vgen_create: bad parameter block";
+        return VGEN_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        err = "no HIP device available (libvgen_hip has no CPU fallback)";
+        return VGEN_E_NODEVICE;
+    }
+    if (p->device < 0 || p->device >= ndev) {
+        err = "device index out of range";
+        return VGEN_E_NODEVICE;
+    }
+    if (p->format > VGF_ETHEREUM) {
+        err = "unknown address format";
+        return VGEN_E_INVALID;
+    }
+    if (p->format == VGF_P2TR) {
+        err = "P2TR is not implemented on the device yet";
+        return VGEN_E_UNSUPPORTED;
+    }
+    vgen_ctx *c = new vgen_ctx();
+    c->device = p->device;
+    c->batch = p->batch_size ? p->batch_size : (1u << 20);
+    c->frames = p->frames ? p->frames : 2;
+    c->match_cap = p->match_cap ? p->match_cap : 4096;
+    c->format = p->format;
+    c->S = env_u32("VGEN_SEQ_S", 8);
+    auto bail = [&](int st, const std::string &m) {
+        err = m;
+        rt_destroy(c);
+        return st;
+    };
+    if (c->frames > 8) return bail(VGEN_E_INVALID, "frames must be <= 8");
+    if (c->S < 1 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two <= 32");
+    if (c->batch % 8192 != 0 || c->batch % (512 * c->S) != 0 || c->batch < 8192)
+        return bail(VGEN_E_INVALID, "batch_size must be a multiple of 8192 (and of 512*S)");
+    if (c->match_cap < FIRST_COPY) c->match_cap = FIRST_COPY;
+    c->lanes = c->batch / (2 * c->S);
+
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return bail(VGEN_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+    // offset table R_u = (u*S + S/2) * G, uploaded limb-major ([18][lanes]) for coalesced reads.
+    // S = 1 would need half-points; use first = 1, step = 1 convention instead: require S >= 2.
+    if (c->S < 2) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be >= 2");
+    {
+        std::vector<ge> tab;
+        host_build_stride_table(c->S / 2, c->S, c->lanes, tab);
+        std::vector<uint32_t> lm((size_t)18 * c->lanes);
+        for (uint32_t u = 0; u < c->lanes; u++)
+            for (int i = 0; i < 9; i++) {
+                lm[(size_t)i * c->lanes + u] = tab[u].x.n[i];
+                lm[(size_t)(9 + i) * c->lanes + u] = tab[u].y.n[i];
+            }
+        e = hipMalloc((void **)&c->d_rtab, lm.size() * sizeof(uint32_t));
+        if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(rtab): ") + hipGetErrorString(e));
+        e = hipMemcpy(c->d_rtab, lm.data(), lm.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(VGEN_E_HIP, std::string("hipMemcpy(rtab): ") + hipGetErrorString(e));
+    }
+    e = hipMalloc((void **)&c->d_filter, sizeof(DevFilter));
+    if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(filter): ") + hipGetErrorString(e));
+
+    c->fr.resize(c->frames);
+    for (auto &f : c->fr) {
+        if ((e = hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreate(&f.ev_start)) != hipSuccess || (e = hipEventCreate(&f.ev_stop)) != hipSuccess ||
+            (e = hipMalloc((void **)&f.d_q, sizeof(DevSeqQ) * SEQ_MAX_S)) != hipSuccess ||
+            (e = hipHostMalloc((void **)&f.h_q, sizeof(DevSeqQ) * SEQ_MAX_S, hipHostMallocDefault)) != hipSuccess ||
+            (e = hipMalloc((void **)&f.d_match, match_bytes(c->match_cap))) != hipSuccess ||
+            (e = hipHostMalloc((void **)&f.h_match, match_bytes(c->match_cap) + sizeof(DevMatchHeader),
+                               hipHostMallocDefault)) != hipSuccess)
+            return bail(VGEN_E_NOMEM, std::string("frame allocation: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return VGEN_OK;
+}
+
+void rt_destroy(vgen_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto &f : c->fr) {
+        if (f.stream) (void)hipStreamSynchronize(f.stream);
+        if (f.d_q) (void)hipFree(f.d_q);
+        if (f.h_q) (void)hipHostFree(f.h_q);
+        if (f.d_dump) (void)hipFree(f.d_dump);
+        if (f.d_match) (void)hipFree(f.d_match);
+        if (f.h_match) (void)hipHostFree(f.h_match);
+        if (f.ev_start) (void)hipEventDestroy(f.ev_start);
+        if (f.ev_stop) (void)hipEventDestroy(f.ev_stop);
+        if (f.stream) (void)hipStreamDestroy(f.stream);
+    }
+    if (c->d_rtab) (void)hipFree(c->d_rtab);
+    if (c->d_filter) (void)hipFree(c->d_filter);
+    delete c;
+}
+
+int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (auto &fr : c->fr)
+        if (fr.in_flight) return c->fail(VGEN_E_STATE, "vgen_set_filter while a dispatch is in flight");
+    if (!f) {
+        c->have_filter = false;
+        return VGEN_OK;
+    }
+    if (f->format != c->format) return c->fail(VGEN_E_INVALID, "filter was compiled for another address format");
+    c->h_filter = f->dev;
+    HIP_TRY(c, hipMemcpy(c->d_filter, &c->h_filter, sizeof(DevFilter), hipMemcpyHostToDevice));
+    c->have_filter = true;
+    return VGEN_OK;
+}
+
+int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
+    if (frame >= c->frames || !start_key_be) return c->fail(VGEN_E_INVALID, "bad frame index / key");
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
+    Scalar k0;
+    scalar_from_be(k0, start_key_be);
+    if (!scalar_is_valid(k0)) return c->fail(VGEN_E_RANGE, "start key is not a valid secp256k1 scalar");
+    // The batched affine additions have no exceptional cases as long as every scalar involved stays
+    // below n (SURVEY.md §7 "hard parts"): k0 + N + S < n.  Batches that reach the top of the scalar
+    // range need the complete-formula path.
+    if (scalar_distance_to_n(k0) <= (uint64_t)c->batch + c->S)
+        return c->fail(VGEN_E_UNSUPPORTED, "dispatch reaches the group order n: not supported by the sequential kernel yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    // Q_j = (k0 + N/2 - S/2 + j) * G, j < S
+    const uint32_t S = c->S;
+    Scalar kb;
+    scalar_add_u64(kb, k0, (uint64_t)c->batch / 2 - S / 2);
+    ge base, g;
+    if (!host_ec_mul_gen(kb, base)) return c->fail(VGEN_E_RANGE, "base point at infinity");
+    ge_generator(g);
+    gej jac[SEQ_MAX_S];
+    ge aff[SEQ_MAX_S];
+    gej_from_ge(jac[0], base);
+    for (uint32_t j = 1; j < S; j++) gej_add_ge(jac[j], jac[j - 1], g);
+    host_batch_to_affine(jac, aff, S);
+    for (uint32_t j = 0; j < S; j++) {
+        DevSeqQ &q = f.h_q[j];
+        fe nx, ny;
+        fe_canon_neg(nx, aff[j].x);
+        fe_canon_neg(ny, aff[j].y);
+        for (int i = 0; i < 9; i++) {
+            q.qx[i] = aff[j].x.n[i];
+            q.qy[i] = aff[j].y.n[i];
+            q.nqx[i] = nx.n[i];
+            q.nqy[i] = ny.n[i];
+        }
+    }
+    HIP_TRY(c, hipMemcpyAsync(f.d_q, f.h_q, sizeof(DevSeqQ) * S, hipMemcpyHostToDevice, f.stream));
+
+    SeqArgs a;
+    memset(&a, 0, sizeof a);
+    a.rtab = c->d_rtab;
+    a.q = f.d_q;
+    a.filter = c->d_filter;
+    a.lanes = c->lanes;
+    a.n = c->batch;
+    a.s = S;
+    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
+    if (dump) {
+        if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
+        a.dump = f.d_dump;
+    } else {
+        // the upload source must stay valid until the copy ran: a pinned header behind the mirror
+        DevMatchHeader *src = reinterpret_cast<DevMatchHeader *>(f.h_match + match_bytes(c->match_cap));
+        src->count = 0;
+        src->cap = c->match_cap;
+        src->pad[0] = src->pad[1] = 0;
+        HIP_TRY(c, hipMemcpyAsync(f.d_match, src, sizeof(DevMatchHeader), hipMemcpyHostToDevice, f.stream));
+        a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
+        a.mrec = reinterpret_cast<DevMatch *>(f.d_match + sizeof(DevMatchHeader));
+    }
+    HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
+    HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream));
+    HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
+    if (!dump)
+        HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
+    f.in_flight = true;
+    f.dumped = dump;
+    f.start = k0;
+    return VGEN_OK;
+}
+
+int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches, uint64_t *keys_tested) {
+    if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (!f.in_flight) return c->fail(VGEN_E_STATE, "No pending operation on frame " + std::to_string(frame));
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(f.stream));
+    f.in_flight = false;
+    (void)hipEventElapsedTime(&f.last_ms, f.ev_start, f.ev_stop);
+    if (keys_tested) *keys_tested = c->batch;
+    uint32_t found = 0;
+    if (!f.dumped) {
+        const DevMatchHeader *hdr = reinterpret_cast<const DevMatchHeader *>(f.h_match);
+        found = hdr->count;
+        uint32_t stored = std::min(found, c->match_cap);
+        if (stored > FIRST_COPY)
+            HIP_TRY(c, hipMemcpy(f.h_match + match_bytes(FIRST_COPY), f.d_match + match_bytes(FIRST_COPY),
+                                 (size_t)(stored - FIRST_COPY) * sizeof(DevMatch), hipMemcpyDeviceToHost));
+        DevMatch *rec = reinterpret_cast<DevMatch *>(f.h_match + sizeof(DevMatchHeader));
+        // ascending index, the order the reference's par_iter().enumerate() collect yields (gpu.rs:1030-1093)
+        std::sort(rec, rec + stored, [](const DevMatch &x, const DevMatch &y) { return x.index < y.index; });
+        if (out) {
+            uint32_t n = std::min(stored, cap);
+            for (uint32_t i = 0; i < n; i++) {
+                out[i].index = rec[i].index;
+                out[i].reserved = 0;
+                memcpy(out[i].payload, rec[i].payload, 32);
+            }
+        }
+    }
+    if (n_matches) *n_matches = found;
+    return VGEN_OK;
+}
+
+int rt_read_dump(vgen_ctx *c, uint32_t frame, uint8_t *out, size_t out_len) {
+    if (frame >= c->frames || !out) return c->fail(VGEN_E_INVALID, "bad frame index / buffer");
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (f.in_flight) return c->fail(VGEN_E_STATE, "vgen_read_dump before vgen_wait");
+    if (!f.dumped || !f.d_dump) return c->fail(VGEN_E_STATE, "frame's last dispatch was not in dump mode");
+    const size_t need = (size_t)c->batch * c->payload_words * sizeof(uint32_t);
+    if (out_len < need) return c->fail(VGEN_E_INVALID, "output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(out, f.d_dump, need, hipMemcpyDeviceToHost));
+    return VGEN_OK;
+}
+
+}  // namespace vg

@@ -1,0 +1,59 @@
+// runtime.h — the HIP runtime object behind vgen_ctx: device binding, frames (stream + buffers +
+// events), offset table, dispatch and readback.  MI355X-native stand-in for the reference's
+// GpuRunner / Frame pair (src/gpu.rs:101-131): hipMalloc'ed buffers sized once, one stream per frame
+// so that consecutive dispatches overlap on the device, pinned host staging for the small
+// per-dispatch uploads and the rare match records, hipEvents around every launch.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vgen_hip.h"
+#include "device/device_types.h"
+#include "host/filter.h"
+#include "host/scalar.h"
+
+struct vgen_ctx {
+    int device = 0;
+    uint32_t batch = 0, frames = 0, match_cap = 0, format = 0;
+    uint32_t S = 0, lanes = 0;
+    uint32_t payload_words = 5;
+
+    uint32_t *d_rtab = nullptr;          // [18][lanes]
+    vg::DevFilter *d_filter = nullptr;   // current device filter program
+    bool have_filter = false;            // false = dump mode
+    vg::DevFilter h_filter{};
+
+    struct Frame {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+        vg::DevSeqQ *d_q = nullptr, *h_q = nullptr;
+        uint32_t *d_dump = nullptr;
+        uint8_t *d_match = nullptr;      // DevMatchHeader followed by match_cap DevMatch
+        uint8_t *h_match = nullptr;      // pinned mirror
+        bool in_flight = false;
+        bool dumped = false;             // last dispatch ran in dump mode
+        vg::Scalar start{};
+        float last_ms = 0.f;
+    };
+    std::vector<Frame> fr;
+    std::string err;
+
+    int fail(int status, const std::string &msg) {
+        err = msg;
+        return status;
+    }
+};
+
+namespace vg {
+
+int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
+void rt_destroy(vgen_ctx *ctx);
+int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
+int rt_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]);
+int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
+            uint64_t *keys_tested);
+int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
+
+}  // namespace vg

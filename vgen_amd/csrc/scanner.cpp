@@ -1,0 +1,250 @@
+// scanner.cpp — vgen_scan: the host loop of the GPU scan, mirroring scan_gpu_with_runner
+// (reference src/gpu.rs:920-1125) above the C ABI.
+//
+// Same control flow as the reference: pick the base key (config.start, or a random valid scalar —
+// gpu.rs:933-945), prime every frame (gpu.rs:973-995), then round-robin: await a frame, immediately
+// re-dispatch it with the next batch (gpu.rs:1003-1028), turn that frame's results into matches
+// (gpu.rs:1030-1104), add batch_size to the operation count and call the progress callback
+// (gpu.rs:1106-1109); stop when `count` matches exist and nothing more was dispatched (gpu.rs:1111).
+// Differences, all on the host side of the boundary: candidates arrive pre-filtered by the device and
+// are confirmed with the exact DFA (the reference encodes and regex-matches all batch_size hashes on
+// rayon); the base key can be seeded; batches can be striped over several contexts (multi-GPU).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <deque>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../include/vgen_hip.h"
+#include "host/encode.h"
+#include "host/filter.h"
+#include "host/scalar.h"
+#include "runtime.h"
+
+namespace vg {
+
+// k0(seed, shard) = SHA-256("vgen-mi355x" || u64le(seed) || u32le(shard)) mod n, re-drawn if 0
+// (BASELINE.md §4).
+void seed_key(uint64_t seed, uint32_t shard, Scalar &out) {
+    uint32_t redraw = 0;
+    for (;;) {
+        uint8_t buf[11 + 8 + 4 + 4];
+        size_t n = 11;
+        memcpy(buf, "vgen-mi355x", 11);
+        for (int i = 0; i < 8; i++) buf[n++] = (uint8_t)(seed >> (8 * i));
+        for (int i = 0; i < 4; i++) buf[n++] = (uint8_t)(shard >> (8 * i));
+        if (redraw)
+            for (int i = 0; i < 4; i++) buf[n++] = (uint8_t)(redraw >> (8 * i));
+        uint8_t d[32];
+        host_sha256(buf, n, d);
+        scalar_from_be(out, d);
+        if (scalar_cmp_words(out.w, SCALAR_N) >= 0) {
+            // digest < 2^256 < 2n: one subtraction reduces it
+            int64_t b = 0;
+            for (int i = 0; i < 8; i++) {
+                int64_t t = (int64_t)out.w[i] - SCALAR_N[i] + b;
+                out.w[i] = (uint32_t)t;
+                b = t >> 32;
+            }
+        }
+        if (!scalar_is_zero(out)) return;
+        redraw++;
+    }
+}
+
+namespace {
+
+struct Pending {
+    Scalar start;
+    bool valid = false;
+};
+
+void random_valid_key(Scalar &k) {
+    std::random_device rd;
+    for (;;) {
+        for (int i = 0; i < 8; i++) k.w[i] = rd();
+        if (scalar_is_valid(k)) return;   // rejection sampling, gpu.rs:938-944
+    }
+}
+
+bool make_match(const vgen_filter &flt, uint32_t format, const Scalar &batch_start, uint32_t index,
+                const uint8_t *payload, const Scalar *end, vgen_generated &g) {
+    std::string addr = address_from_payload(format, payload);
+    if (addr.empty() || !flt.dfa.is_match(addr)) return false;          // pattern.matches, gpu.rs:1069
+    Scalar k;
+    if (scalar_add_u64(k, batch_start, index) || !scalar_is_valid(k)) return false;   // increment_key -> None
+    if (end && scalar_cmp(k, *end) > 0) return false;                   // gpu.rs:1074-1078
+    uint8_t kb[32];
+    scalar_to_be(k, kb);
+    memset(&g, 0, sizeof g);
+    std::string wif = key_to_wif(format, kb), hex = hex_lower(kb, 32);
+    strncpy(g.address, addr.c_str(), sizeof g.address - 1);
+    strncpy(g.wif, wif.c_str(), sizeof g.wif - 1);
+    strncpy(g.hex, hex.c_str(), sizeof g.hex - 1);
+    g.format = format;
+    memcpy(g.key, kb, 32);
+    return true;
+}
+
+}  // namespace
+}  // namespace vg
+
+using namespace vg;
+
+extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
+                         void *user, volatile int32_t *stop, vgen_scan_result *out) {
+    if (!ctx || !pattern || !cfg || !out || cfg->struct_size != sizeof(vgen_scan_config)) return VGEN_E_INVALID;
+    memset(out, 0, sizeof *out);
+    if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
+    const auto t0 = std::chrono::steady_clock::now();
+
+    vgen_filter flt;
+    std::string err;
+    if (!filter_compile(pattern, cfg->case_insensitive != 0, cfg->format, flt, err))
+        return ctx->fail(VGEN_E_PATTERN, err);
+
+    const uint32_t N = ctx->batch;
+    const uint32_t shards = cfg->n_shards > 1 ? cfg->n_shards : 1;
+    const uint32_t shard = cfg->n_shards > 1 ? cfg->shard : 0;
+    if (shard >= shards) return ctx->fail(VGEN_E_INVALID, "shard >= n_shards");
+
+    // device prefilter or host filtering of full dumps: too permissive a prefilter would overflow the
+    // match ring, so it is only used when a batch is expected to produce few candidates
+    bool host_all = flt.dev.kind == DEVF_HOST_ALL ||
+                    (flt.dev.kind != DEVF_HOST_ALL && flt.selectivity * (double)N > (double)ctx->match_cap / 8);
+    int rc = vgen_set_filter(ctx, host_all ? nullptr : &flt);
+    if (rc != VGEN_OK) return rc;
+
+    Scalar current;
+    if (cfg->has_start) {
+        scalar_from_be(current, cfg->start);
+    } else if (cfg->seed) {
+        seed_key(cfg->seed, 0, current);   // one base; shards stripe it (deterministic multi-GPU)
+    } else {
+        random_valid_key(current);
+    }
+    if (!scalar_is_valid(current)) return ctx->fail(VGEN_E_RANGE, "start key is not a valid secp256k1 scalar");
+    Scalar end_key;
+    const Scalar *end = nullptr;
+    if (cfg->has_end) {
+        scalar_from_be(end_key, cfg->end);
+        end = &end_key;
+    }
+    // batch striping: this context takes global batches shard, shard + shards, ...
+    bool exhausted = false;
+    if (shard) exhausted = scalar_add_u64(current, current, (uint64_t)shard * N) || !scalar_is_valid(current);
+    const uint64_t stride = (uint64_t)shards * N;
+
+    std::vector<vgen_generated> matches;
+    uint64_t total_ops = 0, dispatched = 0;
+    const uint64_t count = cfg->count;
+    const uint32_t nf = ctx->frames;
+    std::vector<Pending> pend(nf);
+    std::vector<vgen_match> recs(ctx->match_cap);
+    std::vector<uint8_t> dumpbuf;
+    uint32_t in_flight = 0;
+    int status = VGEN_OK;
+
+    auto stopped = [&]() { return stop && *stop; };
+    auto in_range = [&]() { return !exhausted && (!end || scalar_cmp(current, *end) <= 0); };
+    auto can_dispatch = [&]() { return in_range() && (!cfg->max_batches || dispatched < cfg->max_batches); };
+    auto dispatch = [&](uint32_t frame) -> int {
+        uint8_t kb[32];
+        scalar_to_be(current, kb);
+        int r = vgen_dispatch(ctx, frame, kb);
+        if (r != VGEN_OK) return r;
+        pend[frame].start = current;
+        pend[frame].valid = true;
+        dispatched++;
+        Scalar nx;
+        if (scalar_add_u64(nx, current, stride) || !scalar_is_valid(nx)) exhausted = true;   // key space exhausted
+        else current = nx;
+        return VGEN_OK;
+    };
+
+    for (uint32_t i = 0; i < nf; i++) {
+        if (!can_dispatch() || stopped() || matches.size() >= count) break;
+        if ((status = dispatch(i)) != VGEN_OK) break;
+        in_flight++;
+    }
+
+    uint32_t frame = 0;
+    while (status == VGEN_OK && in_flight > 0) {
+        uint32_t n_found = 0;
+        uint64_t tested = 0;
+        if ((status = vgen_wait(ctx, frame, recs.data(), (uint32_t)recs.size(), &n_found, &tested)) != VGEN_OK) break;
+        in_flight--;
+        const Scalar batch_start = pend[frame].start;
+        pend[frame].valid = false;
+        const bool dumped = ctx->fr[frame].dumped;
+        if (dumped) {
+            dumpbuf.resize((size_t)N * 20);
+            if ((status = vgen_read_dump(ctx, frame, dumpbuf.data(), dumpbuf.size())) != VGEN_OK) break;
+        }
+
+        bool dispatched_next = false;
+        if (!stopped() && matches.size() < count && can_dispatch()) {
+            if ((status = dispatch(frame)) != VGEN_OK) break;
+            in_flight++;
+            dispatched_next = true;
+        }
+
+        if (dumped) {
+            // host filtering of the whole batch (the reference's only mode, gpu.rs:1030-1093), in
+            // parallel chunks, results kept in ascending index order
+            unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+            std::vector<std::vector<vgen_generated>> part(nt);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    uint32_t lo = (uint32_t)((uint64_t)N * t / nt), hi = (uint32_t)((uint64_t)N * (t + 1) / nt);
+                    vgen_generated g;
+                    for (uint32_t i = lo; i < hi; i++)
+                        if (make_match(flt, cfg->format, batch_start, i, &dumpbuf[(size_t)i * 20], end, g))
+                            part[t].push_back(g);
+                });
+            for (auto &x : th) x.join();
+            for (auto &p : part)
+                for (auto &g : p)
+                    if (matches.size() < count) matches.push_back(g);
+        } else {
+            if (n_found > recs.size()) {
+                status = ctx->fail(VGEN_E_STATE, "device match ring overflowed; raise match_cap or use a more selective pattern");
+                break;
+            }
+            vgen_generated g;
+            for (uint32_t i = 0; i < n_found && matches.size() < count; i++)
+                if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) matches.push_back(g);
+        }
+
+        total_ops += N;                              // gpu.rs:1106
+        if (cb) cb(total_ops, user);
+        if (matches.size() >= count && !dispatched_next) break;   // gpu.rs:1111
+        frame = (frame + 1) % nf;
+    }
+    // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
+    for (uint32_t f = 0; f < nf; f++)
+        if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
+    if (status != VGEN_OK) return status;
+
+    out->n_matches = matches.size();
+    out->operations = total_ops;
+    if (!matches.empty()) {
+        out->matches = (vgen_generated *)malloc(matches.size() * sizeof(vgen_generated));
+        if (!out->matches) return ctx->fail(VGEN_E_NOMEM, "out of memory");
+        memcpy(out->matches, matches.data(), matches.size() * sizeof(vgen_generated));
+    }
+    out->elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return VGEN_OK;
+}
+
+extern "C" void vgen_scan_result_free(vgen_scan_result *r) {
+    if (!r) return;
+    free(r->matches);
+    memset(r, 0, sizeof *r);
+}
