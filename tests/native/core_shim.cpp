@@ -85,7 +85,6 @@ void core_keccak_addr(const unsigned char *x_be, const unsigned char *y_be, unsi
 }
 
 #include "../../vgen_amd/csrc/host/host_ec.h"
-#include "../../vgen_amd/csrc/host/host_ec.cpp"
 
 extern "C" {
 // key (32 BE bytes) -> x||y (64 BE bytes); returns 0 for k == 0
@@ -112,5 +111,48 @@ void core_stride_table(uint64_t first, uint64_t step, uint32_t count, unsigned c
         fe_to_words(t[e].y, w);
         for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[64 * e + 32 + 4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
     }
+}
+}
+
+#include <string.h>
+#include <string>
+#include "../../vgen_amd/csrc/core/filter_eval.h"
+#include "../../vgen_amd/csrc/host/encode.h"
+#include "../../vgen_amd/csrc/host/filter.h"
+
+extern "C" {
+// Compiles pattern for `format`; evaluates the DEVICE prefilter program (the same filter_eval the
+// kernel runs) and the exact DFA on the encoded address of `payload`.
+// returns: bit0 = device prefilter hit, bit1 = exact match, or -1 on pattern error. kind_out = device kind.
+int core_filter_check(const char *pattern, int ci, unsigned format, const unsigned char *payloads, int n,
+                      unsigned char *out_flags, int *kind_out, double *sel_out) {
+    vgen_filter f;
+    std::string err;
+    if (!filter_compile(pattern, ci != 0, format, f, err)) return -1;
+    *kind_out = (int)f.dev.kind;
+    *sel_out = f.selectivity;
+    for (int i = 0; i < n; i++) {
+        u32 pl[5];
+        for (int w = 0; w < 5; w++) {
+            const unsigned char *p = payloads + 20 * i + 4 * w;
+            pl[w] = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+        }
+        int dev = filter_eval(&f.dev, pl) ? 1 : 0;
+        std::string addr = address_from_payload(format, payloads + 20 * i);
+        int exact = f.dfa.is_match(addr) ? 1 : 0;
+        out_flags[i] = (unsigned char)(dev | (exact << 1));
+    }
+    return 0;
+}
+int core_regex_match(const char *pattern, int ci, const char *text) {
+    Dfa d;
+    std::string err;
+    if (!regex_compile(pattern, ci != 0, d, err)) return -1;
+    return d.is_match(text) ? 1 : 0;
+}
+int core_address(unsigned format, const unsigned char *payload, char *out) {
+    std::string s = address_from_payload(format, payload);
+    strcpy(out, s.c_str());
+    return (int)s.size();
 }
 }

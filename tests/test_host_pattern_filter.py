@@ -1,0 +1,136 @@
+"""CPU tests of the product's pattern front end (vgen_amd/csrc/host/regex_dfa.cpp, filter.cpp) and of
+the device prefilter program, evaluated on the host by the same filter_eval() the kernel runs.
+
+Contract under test: (1) the DFA decides exactly what the oracle's regex and Python's `re` decide;
+(2) the device prefilter NEVER rejects an address the exact DFA accepts (superset), and for
+prefix/suffix patterns it is tight.
+"""
+import ctypes
+import json
+import os
+import random
+import re
+import subprocess
+
+import pytest
+
+from oracle import pyoracle as vo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+
+
+@pytest.fixture(scope="module")
+def core():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    lib = ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
+    lib.core_filter_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_char_p, ctypes.c_int,
+                                      ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+    return lib
+
+
+def rmatch(core, pat, ci, text):
+    return core.core_regex_match(pat.encode(), int(ci), text.encode())
+
+
+def test_reference_pattern_cases(core):
+    for p in KAT["pattern"]["valid"]:
+        assert rmatch(core, p, False, "x") >= 0
+    for p in KAT["pattern"]["invalid"]:
+        assert rmatch(core, p, False, "x") == -1
+    for c in KAT["pattern"]["cases"]:
+        assert rmatch(core, c["pattern"], c["ci"], c["text"]) == int(c["match"]), c
+
+
+PATTERNS = [
+    "^1Cat", "dead$", "^bc1q.*dead$", "1[Oo]ri", "^1[a-z]{3}7", "(?i)^1cat", "^1(Cat|Dog)s?",
+    "^0x[0-9a-f]{4}dead", "a{2,3}b", "^1.*z$", "x+y*z?", "[^a-z]{5}$", "^(1|3)[A-H]", "\\d{3}",
+    "^bc1q(aa|zz)+", "q$|^1A", "(?i)DEAD$", "^1[^0-9]+9", "\\w\\d\\w$", "^.{34}$", "(ab)*c", "a|",
+    "^$", "^1(?i:cat)X", "$^", "a{0}b", "(a|b){2,}c$", "^1A?B?C?D", ".", "^x*$",
+]
+
+
+def test_dfa_agrees_with_oracle_and_python_re(core):
+    rng = random.Random(13)
+    alphabet = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz0x"
+    texts = ["", "1", "1Cat", "bc1qdead", "0xdeadbeef", "1CATX", "x", "xx", "ab", "abab", "ababc", "b"]
+    for _ in range(250):
+        texts.append("".join(rng.choice(alphabet) for _ in range(rng.randrange(1, 45))))
+    texts += ["1Cat" + t for t in texts[12:40]] + [t + "dead" for t in texts[40:80]]
+    texts += ["bc1q" + t + "dead" for t in texts[80:100]] + ["1" + t + "z" for t in texts[100:120]]
+    for pat in PATTERNS:
+        for ci in (False, True):
+            oracle = vo.Regex(pat, ci)
+            py = re.compile(("(?i)" if ci else "") + pat.replace("\\d", "[0-9]").replace("\\w", "[0-9A-Za-z_]").replace("$", "\\Z"))
+            for t in texts:
+                got = rmatch(core, pat, ci, t)
+                assert got == int(oracle.matches(t)) == int(py.search(t) is not None), (pat, ci, t)
+
+
+def test_unsupported_syntax_rejected(core):
+    for pat in ["\\bfoo", "\\p{L}", "[a-z&&[^b]]", "(?m)^a", "a{,3}", "*a", "(a", "a)", "", "[z-a]", "\\"]:
+        assert rmatch(core, pat, False, "x") == -1, pat
+
+
+def check(core, pat, ci, fmt, payloads):
+    flags = ctypes.create_string_buffer(len(payloads))
+    kind, sel = ctypes.c_int(), ctypes.c_double()
+    blob = b"".join(payloads)
+    assert core.core_filter_check(pat.encode(), int(ci), fmt, blob, len(payloads), flags, ctypes.byref(kind),
+                                  ctypes.byref(sel)) == 0
+    dev = [b & 1 for b in flags.raw]
+    exact = [(b >> 1) & 1 for b in flags.raw]
+    return kind.value, sel.value, dev, exact
+
+
+def address(core, fmt, payload):
+    out = ctypes.create_string_buffer(128)
+    core.core_address(fmt, payload, out)
+    return out.value.decode()
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2, 4, 5])
+def test_prefilter_is_a_tight_superset_for_prefixes_and_suffixes(core, fmt):
+    rng = random.Random(100 + fmt)
+    payloads = [bytes(rng.randrange(256) for _ in range(20)) for _ in range(3000)]
+    # leading-zero payloads change Base58 address lengths ('11...' prefixes)
+    payloads += [bytes(k) + bytes(rng.randrange(256) for _ in range(20 - k)) for k in (1, 2, 3, 5) for _ in range(50)]
+    payloads += [bytes(20), bytes([255] * 20)]
+    addrs = [address(core, fmt, p) for p in payloads]
+    for a, p in zip(addrs, payloads):
+        assert a == vo.address_from_hash160(fmt, p)   # product encoder == oracle encoder
+    head = {0: 1, 4: 1, 2: 1, 1: 4, 5: 2}[fmt]        # characters every address of the format shares
+    pats = []
+    for a in rng.sample(addrs, 40):
+        k = rng.randrange(1, 5)
+        pats.append(("^" + re.escape(a[:head + k]), False))
+        if fmt in (1, 5):
+            pats.append((re.escape(a[-k:]) + "$", fmt == 5))
+            pats.append(("^" + re.escape(a[:head + 1]) + ".*" + re.escape(a[-2:]) + "$", fmt == 5))
+    pats += [("^" + re.escape(addrs[0][:head + 2]) + "|^" + re.escape(addrs[1][:head + 3]), False)]
+    if fmt in (0, 4):
+        pats += [("^11", False), ("^111", False), ("^1[1-3]", False)]
+    if fmt == 5:
+        pats += [("^0xDEAD", False), ("^0xdead", True), ("(?i)^0xAbC", False)]
+    for pat, ci in pats:
+        kind, sel, dev, exact = check(core, pat, ci, fmt, payloads)
+        assert kind in (1, 2, 3), (pat, kind)
+        for d, e, a in zip(dev, exact, addrs):
+            assert d or not e, f"prefilter rejected a real match: {pat} {a}"
+        oracle = vo.Regex(pat, ci)
+        assert exact == [int(oracle.matches(a)) for a in addrs], pat
+        assert sum(dev) <= 3 * sum(exact) + 12, (pat, sum(dev), sum(exact))
+
+
+def test_unanchored_and_base58_suffix_patterns_fall_back_to_host_filtering(core):
+    payloads = [bytes(20)]
+    for pat, fmt in [("Cat", 0), ("abc$", 0), ("dead", 1), ("[0-9]{6}", 5)]:
+        kind, sel, dev, exact = check(core, pat, False, fmt, payloads)
+        assert kind == 0 or all(dev), (pat, kind)     # never a device filter that could drop matches
+    for pat, fmt in [(".", 0), ("^1", 0), ("^bc1q", 1), ("^0x", 5), ("^3", 2)]:
+        kind, sel, dev, exact = check(core, pat, False, fmt, payloads)
+        assert kind == 3 and all(dev) and all(exact)
+    kind, sel, dev, exact = check(core, "^1Cat", False, 0, payloads)
+    assert kind == 1 and 1e-7 < sel < 1e-4            # ~ 58^-3 plus length variants
+    kind, sel, dev, exact = check(core, "^3Cat", False, 0, payloads)   # impossible for P2PKH
+    assert not any(dev) and not any(exact)
