@@ -5,7 +5,9 @@ Metric (BASELINE.json): Mkeys/s = keys tested per second, whole job over all GPU
 Workload at N=1 (BASELINE configs[1]): P2PKH, pattern "^1Cat", 2^20 keys per dispatch, compressed
 public keys, sequential scalars k0(seed=42) + i, inputs resident on the device (the only per-dispatch
 upload is the 1-2 KB of base points).  A "step" is one dispatch of the hot path over 2^20 keys;
-`frames` dispatches are kept in flight exactly as the reference's scan loop keeps 2 (src/gpu.rs:399).
+`frames` dispatches are kept in flight the way the reference's scan loop keeps 2 (src/gpu.rs:399); the
+default here is 6, one HIP stream / hardware queue each, so that one dispatch's serial root inversion
+overlaps the others' full-chip stages.
 For N>1 (python -m torch.distributed.run ... bench.py --gpus N) every rank drives its own GPU over
 batch-striped disjoint scalar ranges — no data-path collective; torch.distributed only provides the
 barriers and the max-over-ranks of the elapsed time.
@@ -23,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One hardware queue per frame stream (the HIP default of 4 makes frames share queues and serialise);
+# must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_ORDER = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 FORMATS = {"p2pkh": 0, "p2wpkh": 1, "p2sh-p2wpkh": 2, "p2pkh-uncompressed": 4, "ethereum": 5}
@@ -47,10 +52,22 @@ def seed_key(seed, shard=0):
     return k
 
 
+def usable_cores():
+    """CPU threads this process may really use: affinity mask, capped by a cgroup-v2 quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
     """The oracle's restatement of scan_range_cpu (reference src/scanner.rs:211-330) on this host's cores."""
     from oracle import pyoracle as vo
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     fmt = FORMATS[fmt_name]
     start = seed_key(42, 0)
     probe = vo.scan_range(fmt, pattern, start, start + 20000 * cores - 1, count=10**9, ci=ci, threads=cores)
@@ -69,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1 << 20, help="keys per dispatch (BASELINE config: 2^20)")
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "2")))
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "6")))
     ap.add_argument("--format", default="p2pkh", choices=sorted(FORMATS))
     ap.add_argument("--pattern", default="^1Cat")
     ap.add_argument("--ci", action="store_true")

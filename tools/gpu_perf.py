@@ -15,23 +15,27 @@ def run(batch, frames, steps, fmt=0, pattern="^1Cat", ci=False):
         r.wait(f)
     t0 = time.perf_counter()
     nf = 0
+    td = 0.0
     for i in range(frames):
         r.dispatch(key, i); key += batch
     done = 0; f = 0; kms = []
     while done < steps:
         n, _ = r.wait(f); nf += n; kms.append(r.kernel_ms(f)); done += 1
         if done + frames - 1 < steps:
-            r.dispatch(key, f); key += batch
+            t1 = time.perf_counter(); r.dispatch(key, f); td += time.perf_counter() - t1; key += batch
         f = (f + 1) % frames
     # note: the last frames-1 waits above already consumed
     dt = time.perf_counter() - t0
     kms.sort()
-    print("S=%s batch=2^%d frames=%d steps=%d: %.1f Mkeys/s  (%.3f ms/step wall, kernel median %.3f ms) cand=%d" % (
-        os.environ.get("VGEN_SEQ_S", "8"), batch.bit_length() - 1, frames, steps, steps * batch / dt / 1e6, dt / steps * 1e3,
-        kms[len(kms) // 2], nf), flush=True)
+    print("S=%s WG=%s PREG=%s batch=2^%d frames=%d steps=%d: %.1f Mkeys/s  (%.3f ms/step wall, kernel median %.3f ms) cand=%d host-dispatch %.3f ms/step" % (
+        os.environ.get("VGEN_SEQ_S", "4"), "256", "-", batch.bit_length() - 1, frames, steps, steps * batch / dt / 1e6, dt / steps * 1e3,
+        kms[len(kms) // 2], nf, td / max(1, steps - frames) * 1e3), flush=True)
     r.close()
 
 if __name__ == "__main__":
     fmt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    for batch, frames, steps in [(1 << 20, 1, 64), (1 << 20, 2, 128), (1 << 20, 4, 128), (1 << 20, 8, 256), (1 << 22, 2, 32), (1 << 24, 2, 16)]:
+    sweep = [(1 << 20, 1, 64), (1 << 20, 2, 128), (1 << 20, 4, 128), (1 << 20, 8, 256), (1 << 24, 2, 16)]
+    if len(sys.argv) > 2:
+        sweep = [(1 << 20, int(f), 256) for f in sys.argv[2].split(",")]
+    for batch, frames, steps in sweep:
         run(batch, frames, steps, fmt)

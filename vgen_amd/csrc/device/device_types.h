@@ -61,19 +61,25 @@ struct DevSeqQ {
     uint32_t qx[9], qy[9], nqx[9], nqy[9];
 };
 
-constexpr uint32_t SEQ_MAX_S = 32;
+constexpr uint32_t SEQ_MAX_S = 16;   // keeps SeqArgs (passed by value as kernel arguments) under 4 KB
+constexpr int SEQ_WG = 256;          // lanes per workgroup of the seq_* kernels
 
 struct SeqArgs {
     const uint32_t *rtab;      // offset table, limb-major: [18][lanes]  (x limbs 0..8, y limbs 0..8)
-    const DevSeqQ *q;          // [S]
     const DevFilter *filter;   // used when dump == nullptr
-    uint32_t *dump;            // dump mode: N * 5 words (or N * 8 for 32-byte payloads)
-    DevMatchHeader *mhdr;      // filter mode
-    DevMatch *mrec;
+    uint32_t *dump;            // dump mode: N * 5 words
+    DevMatchHeader *mhdr;      // filter mode: monotonic candidate counter ...
+    DevMatch *mrec;            // ... and this frame's record ring
+    uint32_t *pre;             // scratch: prefix products [S][9][lanes]
+    uint32_t *tree;            // scratch: product-tree nodes [groups][9][SEQ_WG]
+    uint32_t *root;            // scratch: tree roots / their inverses [9][groups]
     uint32_t lanes;            // N / (2*S)
+    uint32_t groups;           // lanes / SEQ_WG
     uint32_t n;                // N
     uint32_t s;                // S
-    uint32_t pad;
+    uint32_t match_base;       // value of mhdr->count when this dispatch was enqueued
+    uint32_t match_cap;
+    DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 
 }  // namespace vg

@@ -1,24 +1,29 @@
 // kernels.hip — the HIP kernels of libvgen_hip.so (gfx950 / CDNA4 only).
 //
-// seq_scan_kernel replaces the reference's single-pass search kernel `main`
-// (src/shaders/search.wgsl:2-31): for every key k0 + i of a dispatch it produces the address payload
-// (hash160 or Keccak address) — and, unlike the reference, applies the pattern prefilter on the
-// device so that only candidates leave the GPU.
+// Together the three seq_* kernels replace the reference's single-pass search kernel `main`
+// (src/shaders/search.wgsl:2-31): for every key k0 + i of a dispatch they produce the address payload
+// (hash160 or Keccak address) — and, unlike the reference, apply the pattern prefilter on the device
+// so that only candidates leave the GPU.
 //
 // Design (MI355X-first, not a translation of the WGSL):
-//   * One inversion per WORKGROUP, not per key.  The reference spends 505 of its 521 field
-//     multiplications per key in a per-thread Fermat inverse (field.wgsl:195-210).  Here every key is
-//     an affine addition  Q_j (+/-) R_u  of a per-dispatch uniform point Q_j (S of them, read through
-//     the scalar cache) and a per-lane table point R_u = (u*S + S/2)*G; the +R and -R results share
-//     one denominator, each lane chains its S denominators into one product (prefix products parked
-//     in LDS), the 256 lane products are combined in an LDS product tree, ONE Fermat inversion is
-//     done per workgroup, and the tree is walked back down.  Cost per key: ~4.5 field
-//     multiplications + 1/(512*S) of an inversion.
+//   * One field inversion per 64 WORKGROUPS' worth of keys instead of one per key.  The reference
+//     spends 505 of its 521 field multiplications per key in a per-thread Fermat inverse
+//     (field.wgsl:195-210).  Here every key is an affine addition  Q_j (+/-) R_u  of a per-dispatch
+//     uniform point Q_j (S of them, passed as kernel arguments and read through the scalar cache) and
+//     a per-lane table point R_u = (u*S + S/2)*G.  The +R and -R results share one denominator; each
+//     lane chains its S denominators (prefix products parked in L2-resident global scratch); the 256
+//     lane products of a workgroup are combined by an LDS product tree whose ROOT is written out
+//     (seq_fwd_kernel).  seq_inv_kernel then inverts the roots of all workgroups with one root per
+//     LANE — a 270-multiplication Fermat chain is a serial dependency no matter what, so it only pays
+//     when all 64 lanes of the wave carry different roots.  seq_bwd_kernel walks the trees back down
+//     and runs the per-key tail.  Cost per key: ~4.5 field multiplications; the inversion is noise.
+//     (A fused single kernel with the inversion inside was measured first: the lone inverting wave
+//     stalled its workgroup for 0.2 ms of a 0.33 ms dispatch — profiles/r01_*.)
 //   * Field arithmetic in 9x29-bit limbs on v_mad_u64_u32 with no carry flags (core/fe.h).
 //   * SHA-256 / RIPEMD-160 / Keccak as straight-line register code (core/hash.h); no MFMA anywhere:
 //     this is integer work bound by VALU issue, not a contraction.
-//   * Output: dump mode writes 20 B per key (parity / reference-equivalent mode); filter mode
-//     writes only candidate records through a wave-aggregated atomic slot counter.
+//   * Output: dump mode writes 20 B per key (parity / reference-equivalent mode); filter mode writes
+//     only candidate records through a wave-aggregated atomic slot counter.
 #include <hip/hip_runtime.h>
 
 #include "../core/ec.h"
@@ -29,7 +34,7 @@
 
 namespace vg {
 
-constexpr int WG = 256;
+constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 
 // ---- payload per format -----------------------------------------------------------------------------
 
@@ -57,81 +62,140 @@ __device__ __forceinline__ void payload_from_point(const u32 xw[8], const fe &y_
     }
 }
 
-// ---- LDS helpers ---------------------------------------------------------------------------------------
-// All LDS arrays are limb-major ([limb][lane]) so that a wave's access is 64 consecutive dwords.
+// ---- LDS / lane helpers ---------------------------------------------------------------------------------
+// All arrays are limb-major ([limb][lane]) so that a wave's access is 64 consecutive dwords.
 
-__device__ __forceinline__ void lds_store_fe(u32 *base, int stride, int lane, const fe &a) {
+__device__ __forceinline__ void lds_store_fe(u32 *base, int stride, int col, const fe &a) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) base[i * stride + lane] = a.n[i];
+    for (int i = 0; i < 9; i++) base[i * stride + col] = a.n[i];
 }
 
-__device__ __forceinline__ void lds_load_fe(const u32 *base, int stride, int lane, fe &a) {
+__device__ __forceinline__ void lds_load_fe(const u32 *base, int stride, int col, fe &a) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) a.n[i] = base[i * stride + lane];
+    for (int i = 0; i < 9; i++) a.n[i] = base[i * stride + col];
 }
 
-// Inverts the WG per-lane values v (magnitude 1, non-zero) with ONE field inversion: an LDS product
-// tree over the 256 lanes.  tree: 9 * 512 dwords, node k at column k (heap order: root = 1,
-// leaves = 256..511).  Every thread of the workgroup must call this.
-__device__ __forceinline__ void wg_batch_inverse(fe &v, u32 *tree) {
-    const int tid = threadIdx.x;
-    constexpr int ST = 2 * WG;
-    lds_store_fe(tree, ST, WG + tid, v);
-    __syncthreads();
-    // up-sweep: node[k] = node[2k] * node[2k+1]
-    for (int width = WG / 2; width >= 1; width >>= 1) {
-        if (tid < width) {
-            const int k = width + tid;
-            fe a, b, p;
-            lds_load_fe(tree, ST, 2 * k, a);
-            lds_load_fe(tree, ST, 2 * k + 1, b);
-            fe_mul(p, a, b);
-            lds_store_fe(tree, ST, k, p);
-        }
-        __syncthreads();
-    }
-    // root inverse, computed redundantly by the 64 lanes of wave 0 (same cost as one lane) so that
-    // no lane-divergent branch wraps the 270-multiplication chain
-    if (tid < 64) {
-        fe r, ri;
-        lds_load_fe(tree, ST, 1, r);
-        fe_inv(ri, r);
-        if (tid == 0) lds_store_fe(tree, ST, 1, ri);
-    }
-    __syncthreads();
-    // down-sweep: inv[2k] = inv[k] * node[2k+1], inv[2k+1] = inv[k] * node[2k]
-    for (int width = 1; width <= WG / 2; width <<= 1) {
-        if (tid < width) {
-            const int k = width + tid;
-            fe ik, a, b, ia, ib;
-            lds_load_fe(tree, ST, k, ik);
-            lds_load_fe(tree, ST, 2 * k, a);
-            lds_load_fe(tree, ST, 2 * k + 1, b);
-            fe_mul(ia, ik, b);
-            fe_mul(ib, ik, a);
-            lds_store_fe(tree, ST, 2 * k, ia);
-            lds_store_fe(tree, ST, 2 * k + 1, ib);
-        }
-        __syncthreads();
-    }
-    lds_load_fe(tree, ST, WG + tid, v);
+__device__ __forceinline__ void shfl_xor_fe(fe &r, const fe &a, int mask) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.n[i] = (u32)__shfl_xor((int)a.n[i], mask);
 }
 
-// ---- sequential-range scan ----------------------------------------------------------------------------
+// Scratch layout (global, one region per frame), for a dispatch of `lanes` lanes in lanes/WG groups:
+//   pre  : [S][9][lanes]        prefix products p_0 .. p_{S-1} of every lane (p_{S-1} = lane product)
+//   tree : [groups][9][WG]      product-tree nodes of each workgroup, heap order: columns 1..WG/2-1
+//                               internal, WG/2 .. WG-1 the pair products; column 0 unused
+//   root : [9][groups]          tree roots (seq_fwd) -> their inverses in place (seq_inv)
 
-template <int FMT>
-__global__ void __launch_bounds__(WG) seq_scan_kernel(const SeqArgs args) {
-    extern __shared__ u32 lds[];
+// ---- stage 1: denominators, per-lane products, workgroup product tree ---------------------------------
+
+__global__ void __launch_bounds__(WG) seq_fwd_kernel(const SeqArgs args) {
+    __shared__ u32 tree[9 * WG];
     const int tid = threadIdx.x;
     const u32 S = args.s;
     const u32 lanes = args.lanes;
-    // LDS carve: prefix products [S][9][WG], then the inversion tree [9][2*WG]
-    u32 *pre = lds;
-    u32 *tree = lds + (size_t)S * 9 * WG;
+    const u32 u = blockIdx.x * WG + tid;   // lanes is a multiple of WG
 
-    u32 u = blockIdx.x * WG + tid;
-    const bool active = u < lanes;
-    if (!active) u = lanes - 1;   // keep every lane in the workgroup-wide inversion; results discarded
+    fe rx;
+#pragma unroll
+    for (int i = 0; i < 9; i++) rx.n[i] = args.rtab[(size_t)i * lanes + u];
+
+    u32 *pre = args.pre + u;
+    fe acc;
+#pragma unroll 1
+    for (u32 j = 0; j < S; j++) {
+        fe dx;
+#pragma unroll
+        for (int i = 0; i < 9; i++) dx.n[i] = rx.n[i] + args.q[j].nqx[i];   // R.x - Q_j.x, magnitude 2
+        if (j == 0) {
+            acc = dx;
+            fe_normalize_weak(acc);
+        } else {
+            fe_mul(acc, acc, dx);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) pre[(size_t)(j * 9 + i) * lanes] = acc.n[i];
+    }
+
+    // product tree; the leaf level is exchanged by a lane shuffle
+    fe sib, pair;
+    shfl_xor_fe(sib, acc, 1);
+    fe_mul(pair, acc, sib);
+    if ((tid & 1) == 0) lds_store_fe(tree, WG, WG / 2 + (tid >> 1), pair);
+    __syncthreads();
+    for (int width = WG / 4; width >= 1; width >>= 1) {
+        if (tid < width) {
+            const int k = width + tid;
+            fe a, b, p;
+            lds_load_fe(tree, WG, 2 * k, a);
+            lds_load_fe(tree, WG, 2 * k + 1, b);
+            fe_mul(p, a, b);
+            lds_store_fe(tree, WG, k, p);
+        }
+        __syncthreads();
+    }
+    // write the tree out (coalesced) and the root into the root vector
+    u32 *tg = args.tree + (size_t)blockIdx.x * 9 * WG;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tg[i * WG + tid] = tree[i * WG + tid];
+    if (tid < 9) args.root[(size_t)tid * args.groups + blockIdx.x] = tree[tid * WG + 1];
+}
+
+// ---- stage 2: invert every workgroup's root, one root per lane -----------------------------------------
+
+__global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
+    const u32 g = blockIdx.x * 64 + threadIdx.x;
+    const u32 gg = g < groups ? g : groups - 1;
+    fe r, ri;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.n[i] = root[(size_t)i * groups + gg];
+    fe_inv(ri, r);
+    if (g < groups) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) root[(size_t)i * groups + g] = ri.n[i];
+    }
+}
+
+// ---- stage 3: walk the tree down, finish the additions, hash, filter ---------------------------------------
+
+template <int FMT>
+__global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
+    __shared__ u32 tree[9 * WG];
+    const int tid = threadIdx.x;
+    const u32 S = args.s;
+    const u32 lanes = args.lanes;
+    const u32 u = blockIdx.x * WG + tid;
+
+    const u32 *tg = args.tree + (size_t)blockIdx.x * 9 * WG;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tree[i * WG + tid] = tg[i * WG + tid];
+    __syncthreads();
+    if (tid < 9) tree[tid * WG + 1] = args.root[(size_t)tid * args.groups + blockIdx.x];   // root^-1
+    __syncthreads();
+    // down-sweep: inv[2k] = inv[k] * node[2k+1], inv[2k+1] = inv[k] * node[2k]
+    for (int width = 1; width <= WG / 4; width <<= 1) {
+        if (tid < width) {
+            const int k = width + tid;
+            fe ik, a, b, ia, ib;
+            lds_load_fe(tree, WG, k, ik);
+            lds_load_fe(tree, WG, 2 * k, a);
+            lds_load_fe(tree, WG, 2 * k + 1, b);
+            fe_mul(ia, ik, b);
+            fe_mul(ib, ik, a);
+            lds_store_fe(tree, WG, 2 * k, ia);
+            lds_store_fe(tree, WG, 2 * k + 1, ib);
+        }
+        __syncthreads();
+    }
+    const u32 *pre = args.pre + u;
+    fe inv;
+    {
+        // 1/acc = 1/(acc * sib) * sib, sib = the neighbouring lane's product p_{S-1}
+        fe ip, sib;
+        lds_load_fe(tree, WG, WG / 2 + (tid >> 1), ip);
+#pragma unroll
+        for (int i = 0; i < 9; i++) sib.n[i] = args.pre[(size_t)((S - 1) * 9 + i) * lanes + (u ^ 1u)];
+        fe_mul(inv, ip, sib);
+    }
 
     fe rx, ry, nrx, nry;
 #pragma unroll
@@ -142,40 +206,19 @@ __global__ void __launch_bounds__(WG) seq_scan_kernel(const SeqArgs args) {
     fe_neg(nrx, rx, 1);   // magnitude 2
     fe_neg(nry, ry, 1);
 
-    const DevSeqQ *__restrict__ q = args.q;
-
-    // forward pass: acc = prod_j (R.x - Q_j.x); prefix products parked in LDS
-    fe acc;
-#pragma unroll 1
-    for (u32 j = 0; j < S; j++) {
-        fe dx;
-#pragma unroll
-        for (int i = 0; i < 9; i++) dx.n[i] = rx.n[i] + q[j].nqx[i];   // magnitude 2
-        if (j == 0) {
-            acc = dx;
-            fe_normalize_weak(acc);
-        } else {
-            fe_mul(acc, acc, dx);
-        }
-        lds_store_fe(pre + (size_t)j * 9 * WG, WG, tid, acc);
-    }
-
-    // one inversion for the whole workgroup
-    fe inv = acc;
-    wg_batch_inverse(inv, tree);
-
     const u32 half = args.n >> 1;
     const bool dump = args.dump != nullptr;
 
-    // backward pass
 #pragma unroll 1
     for (int j = (int)S - 1; j >= 0; j--) {
+        const DevSeqQ &q = args.q[j];
         fe dx, idx;
 #pragma unroll
-        for (int i = 0; i < 9; i++) dx.n[i] = rx.n[i] + q[j].nqx[i];
+        for (int i = 0; i < 9; i++) dx.n[i] = rx.n[i] + q.nqx[i];
         if (j > 0) {
             fe pj;
-            lds_load_fe(pre + (size_t)(j - 1) * 9 * WG, WG, tid, pj);
+#pragma unroll
+            for (int i = 0; i < 9; i++) pj.n[i] = pre[(size_t)((j - 1) * 9 + i) * lanes];
             fe_mul(idx, inv, pj);
             fe_mul(inv, inv, dx);
         } else {
@@ -186,18 +229,18 @@ __global__ void __launch_bounds__(WG) seq_scan_kernel(const SeqArgs args) {
             // +R: dy = R.y - Q.y ; -R: dy = -R.y - Q.y
             fe dy, lam, x3, t, y3;
 #pragma unroll
-            for (int i = 0; i < 9; i++) dy.n[i] = (sgn ? nry.n[i] : ry.n[i]) + q[j].nqy[i];   // magnitude <= 3
+            for (int i = 0; i < 9; i++) dy.n[i] = (sgn ? nry.n[i] : ry.n[i]) + q.nqy[i];   // magnitude <= 3
             fe_mul(lam, dy, idx);
             fe_sqr(x3, lam);
 #pragma unroll
-            for (int i = 0; i < 9; i++) x3.n[i] += nrx.n[i] + q[j].nqx[i];                    // magnitude 4
+            for (int i = 0; i < 9; i++) x3.n[i] += nrx.n[i] + q.nqx[i];                    // magnitude 4
             fe_normalize(x3);
             fe_neg(t, x3, 1);
 #pragma unroll
-            for (int i = 0; i < 9; i++) t.n[i] += q[j].qx[i];                                  // magnitude 3
+            for (int i = 0; i < 9; i++) t.n[i] += q.qx[i];                                  // magnitude 3
             fe_mul(y3, lam, t);
 #pragma unroll
-            for (int i = 0; i < 9; i++) y3.n[i] += q[j].nqy[i];                                // magnitude 2
+            for (int i = 0; i < 9; i++) y3.n[i] += q.nqy[i];                                // magnitude 2
             fe_normalize(y3);
 
             u32 xw[8], pl[5];
@@ -205,53 +248,52 @@ __global__ void __launch_bounds__(WG) seq_scan_kernel(const SeqArgs args) {
             payload_from_point<FMT>(xw, y3, pl);
 
             const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
-            if (active) {
-                if (dump) {
-                    u32 *o = args.dump + (size_t)index * 5;
+            if (dump) {
+                u32 *o = args.dump + (size_t)index * 5;
 #pragma unroll
-                    for (int i = 0; i < 5; i++) o[i] = pl[i];
-                } else if (filter_eval(args.filter, pl)) {
-                    const u32 slot = atomicAdd(&args.mhdr->count, 1u);
-                    if (slot < args.mhdr->cap) {
-                        DevMatch *m = args.mrec + slot;
-                        m->index = index;
-                        m->reserved = 0;
+                for (int i = 0; i < 5; i++) o[i] = pl[i];
+            } else if (filter_eval(args.filter, pl)) {
+                // monotonic counter: no per-dispatch reset; this dispatch's slots start at match_base
+                const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+                if (slot < args.match_cap) {
+                    DevMatch *m = args.mrec + slot;
+                    m->index = index;
+                    m->reserved = 0;
 #pragma unroll
-                        for (int i = 0; i < 5; i++) m->payload[i] = pl[i];
-                        m->payload[5] = m->payload[6] = m->payload[7] = 0;
-                    }
+                    for (int i = 0; i < 5; i++) m->payload[i] = pl[i];
+                    m->payload[5] = m->payload[6] = m->payload[7] = 0;
                 }
             }
         }
     }
 }
 
-// ---- launch wrappers (called from runtime.cpp) ----------------------------------------------------------
+// ---- launch (called from runtime.cpp) ---------------------------------------------------------------------
 
 template <int FMT>
-static hipError_t launch_seq_fmt(const SeqArgs &a, hipStream_t stream) {
-    const u32 blocks = (a.lanes + WG - 1) / WG;
-    const size_t lds_bytes = ((size_t)a.s * 9 * WG + 9 * 2 * WG) * sizeof(u32);
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seq_scan_kernel<FMT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(seq_scan_kernel<FMT>, dim3(blocks), dim3(WG), lds_bytes, stream, a);
+static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(seq_bwd_kernel<FMT>, dim3(a.groups), dim3(WG), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream) {
+    if (a.lanes % WG != 0 || a.groups != a.lanes / WG || a.s < 2 || a.s > SEQ_MAX_S) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seq_fwd_kernel, dim3(a.groups), dim3(WG), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
     switch (fmt) {
     case VGF_P2PKH:
     case VGF_P2WPKH:
-        return launch_seq_fmt<VGF_P2PKH>(a, stream);
+        return launch_bwd<VGF_P2PKH>(a, stream);
     case VGF_P2SH_P2WPKH:
-        return launch_seq_fmt<VGF_P2SH_P2WPKH>(a, stream);
+        return launch_bwd<VGF_P2SH_P2WPKH>(a, stream);
     case VGF_P2PKH_UNCOMPRESSED:
-        return launch_seq_fmt<VGF_P2PKH_UNCOMPRESSED>(a, stream);
+        return launch_bwd<VGF_P2PKH_UNCOMPRESSED>(a, stream);
     case VGF_ETHEREUM:
-        return launch_seq_fmt<VGF_ETHEREUM>(a, stream);
+        return launch_bwd<VGF_ETHEREUM>(a, stream);
     default:
         return hipErrorInvalidValue;
     }

@@ -104,3 +104,97 @@ void host_build_stride_table(uint64_t first, uint64_t step, uint32_t count, std:
 }
 
 }  // namespace vg
+
+namespace vg {
+
+namespace {
+
+// out[j] = q[j] + d for affine points, one shared inversion.  false on an exceptional pair (equal x).
+bool batch_affine_add(const ge *q, const ge &d, uint32_t S, ge *out) {
+    fe dx[32], pre[32];
+    for (uint32_t j = 0; j < S; j++) {
+        fe_sub_n(dx[j], d.x, q[j].x);
+        if (fe_is_zero_any(dx[j])) return false;
+        if (j == 0) pre[0] = dx[0];
+        else fe_mul(pre[j], pre[j - 1], dx[j]);
+    }
+    fe inv;
+    fe_inv(inv, pre[S - 1]);
+    for (uint32_t j = S; j-- > 0;) {
+        fe idx;
+        if (j > 0) {
+            fe_mul(idx, inv, pre[j - 1]);
+            fe_mul(inv, inv, dx[j]);
+        } else {
+            idx = inv;
+        }
+        fe dy, lam, x3, t, y3;
+        fe_sub_n(dy, d.y, q[j].y);
+        fe_mul(lam, dy, idx);
+        fe_sqr(x3, lam);
+        fe_sub_n(x3, x3, q[j].x);
+        fe_sub_n(x3, x3, d.x);
+        fe_sub_n(t, q[j].x, x3);
+        fe_mul(y3, lam, t);
+        fe_sub_n(y3, y3, q[j].y);
+        fe_normalize(x3);
+        fe_normalize(y3);
+        out[j].x = x3;
+        out[j].y = y3;
+    }
+    return true;
+}
+
+bool seq_points_full(const Scalar &kb, uint32_t S, ge *out) {
+    ge base, g;
+    if (!host_ec_mul_gen(kb, base)) return false;
+    ge_generator(g);
+    gej jac[32];
+    gej_from_ge(jac[0], base);
+    for (uint32_t j = 1; j < S; j++) {
+        gej_add_ge(jac[j], jac[j - 1], g);
+        if (jac[j].inf) return false;
+    }
+    host_batch_to_affine(jac, out, S);
+    return true;
+}
+
+}  // namespace
+
+bool host_seq_points(SeqBaseCache &c, const Scalar &kb, uint32_t S, ge *out) {
+    bool done = false;
+    if (c.valid && c.S == S && scalar_cmp(kb, c.kb) > 0) {
+        // diff = kb - cache.kb, must fit 64 bits
+        Scalar diff;
+        int64_t b = 0;
+        for (int i = 0; i < 8; i++) {
+            int64_t t = (int64_t)kb.w[i] - c.kb.w[i] + b;
+            diff.w[i] = (uint32_t)t;
+            b = t >> 32;
+        }
+        bool small = true;
+        for (int i = 2; i < 8; i++) small = small && diff.w[i] == 0;
+        if (small) {
+            uint64_t d = ((uint64_t)diff.w[1] << 32) | diff.w[0];
+            if (!c.dvalid || c.delta != d) {
+                Scalar ds{};
+                ds.w[0] = diff.w[0];
+                ds.w[1] = diff.w[1];
+                c.dvalid = host_ec_mul_gen(ds, c.dpt);
+                c.delta = d;
+            }
+            if (c.dvalid) done = batch_affine_add(c.q, c.dpt, S, out);
+        }
+    }
+    if (!done && !seq_points_full(kb, S, out)) {
+        c.valid = false;
+        return false;
+    }
+    c.valid = true;
+    c.S = S;
+    c.kb = kb;
+    for (uint32_t j = 0; j < S; j++) c.q[j] = out[j];
+    return true;
+}
+
+}  // namespace vg

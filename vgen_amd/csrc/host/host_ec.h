@@ -22,3 +22,24 @@ void host_batch_to_affine(const gej *in, ge *out, size_t n);
 void host_build_stride_table(uint64_t first, uint64_t step, uint32_t count, std::vector<ge> &out);
 
 }  // namespace vg
+
+namespace vg {
+
+// Per-context cache for the per-dispatch uniform points Q_j = (kb + j)*G, j < S.  A scan walks its
+// base scalar forward by a constant stride, so after the first dispatch the S points are advanced by
+// ONE shared-inversion batch of affine additions with the cached stride point instead of a fresh
+// fixed-base multiplication.
+struct SeqBaseCache {
+    bool valid = false;
+    uint32_t S = 0;
+    Scalar kb{};
+    ge q[32];
+    bool dvalid = false;
+    uint64_t delta = 0;
+    ge dpt;
+};
+
+// out[j] = (kb + j)*G for j < S.  false if any point is the point at infinity (kb + j == 0 mod n).
+bool host_seq_points(SeqBaseCache &cache, const Scalar &kb, uint32_t S, ge *out);
+
+}  // namespace vg

@@ -32,6 +32,11 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
     return x > 0 ? (uint32_t)x : dflt;
 }
 
+// pre [S][9][lanes] | tree [groups][9][WG] | root [9][groups]
+size_t scratch_words(const vgen_ctx *c) {
+    return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
+}
+
 void fe_canon_neg(fe &r, const fe &a) {
     fe_neg(r, a, 1);
     fe_normalize(r);
@@ -74,18 +79,17 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         return st;
     };
     if (c->frames > 8) return bail(VGEN_E_INVALID, "frames must be <= 8");
-    if (c->S < 1 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two <= 32");
-    if (c->batch % 8192 != 0 || c->batch % (512 * c->S) != 0 || c->batch < 8192)
+    if (c->S < 2 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two in [2, 16]");
+    if (c->batch % 8192 != 0 || c->batch % (2 * SEQ_WG * c->S) != 0 || c->batch < 8192)
         return bail(VGEN_E_INVALID, "batch_size must be a multiple of 8192 (and of 512*S)");
     if (c->match_cap < FIRST_COPY) c->match_cap = FIRST_COPY;
     c->lanes = c->batch / (2 * c->S);
+    c->groups = c->lanes / SEQ_WG;
 
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return bail(VGEN_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
 
-    // offset table R_u = (u*S + S/2) * G, uploaded limb-major ([18][lanes]) for coalesced reads.
-    // S = 1 would need half-points; use first = 1, step = 1 convention instead: require S >= 2.
-    if (c->S < 2) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be >= 2");
+    // offset table R_u = (u*S + S/2) * G, uploaded limb-major ([18][lanes]) for coalesced reads
     {
         std::vector<ge> tab;
         host_build_stride_table(c->S / 2, c->S, c->lanes, tab);
@@ -107,11 +111,10 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     for (auto &f : c->fr) {
         if ((e = hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreate(&f.ev_start)) != hipSuccess || (e = hipEventCreate(&f.ev_stop)) != hipSuccess ||
-            (e = hipMalloc((void **)&f.d_q, sizeof(DevSeqQ) * SEQ_MAX_S)) != hipSuccess ||
-            (e = hipHostMalloc((void **)&f.h_q, sizeof(DevSeqQ) * SEQ_MAX_S, hipHostMallocDefault)) != hipSuccess ||
+            (e = hipMalloc((void **)&f.d_scratch, scratch_words(c) * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc((void **)&f.d_match, match_bytes(c->match_cap))) != hipSuccess ||
-            (e = hipHostMalloc((void **)&f.h_match, match_bytes(c->match_cap) + sizeof(DevMatchHeader),
-                               hipHostMallocDefault)) != hipSuccess)
+            (e = hipMemset(f.d_match, 0, match_bytes(c->match_cap))) != hipSuccess ||
+            (e = hipHostMalloc((void **)&f.h_match, match_bytes(c->match_cap), hipHostMallocDefault)) != hipSuccess)
             return bail(VGEN_E_NOMEM, std::string("frame allocation: ") + hipGetErrorString(e));
     }
     *out = c;
@@ -123,9 +126,8 @@ void rt_destroy(vgen_ctx *c) {
     (void)hipSetDevice(c->device);
     for (auto &f : c->fr) {
         if (f.stream) (void)hipStreamSynchronize(f.stream);
-        if (f.d_q) (void)hipFree(f.d_q);
-        if (f.h_q) (void)hipHostFree(f.h_q);
         if (f.d_dump) (void)hipFree(f.d_dump);
+        if (f.d_scratch) (void)hipFree(f.d_scratch);
         if (f.d_match) (void)hipFree(f.d_match);
         if (f.h_match) (void)hipHostFree(f.h_match);
         if (f.ev_start) (void)hipEventDestroy(f.ev_start);
@@ -166,20 +168,17 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         return c->fail(VGEN_E_UNSUPPORTED, "dispatch reaches the group order n: not supported by the sequential kernel yet");
     HIP_TRY(c, hipSetDevice(c->device));
 
-    // Q_j = (k0 + N/2 - S/2 + j) * G, j < S
+    // Q_j = (k0 + N/2 - S/2 + j) * G, j < S, passed by value in the kernel arguments
     const uint32_t S = c->S;
     Scalar kb;
     scalar_add_u64(kb, k0, (uint64_t)c->batch / 2 - S / 2);
-    ge base, g;
-    if (!host_ec_mul_gen(kb, base)) return c->fail(VGEN_E_RANGE, "base point at infinity");
-    ge_generator(g);
-    gej jac[SEQ_MAX_S];
-    ge aff[SEQ_MAX_S];
-    gej_from_ge(jac[0], base);
-    for (uint32_t j = 1; j < S; j++) gej_add_ge(jac[j], jac[j - 1], g);
-    host_batch_to_affine(jac, aff, S);
+    ge aff[32];
+    if (!host_seq_points(c->base_cache, kb, S, aff)) return c->fail(VGEN_E_RANGE, "base point at infinity");
+
+    SeqArgs a;
+    memset(&a, 0, sizeof a);
     for (uint32_t j = 0; j < S; j++) {
-        DevSeqQ &q = f.h_q[j];
+        DevSeqQ &q = a.q[j];
         fe nx, ny;
         fe_canon_neg(nx, aff[j].x);
         fe_canon_neg(ny, aff[j].y);
@@ -190,14 +189,13 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
             q.nqy[i] = ny.n[i];
         }
     }
-    HIP_TRY(c, hipMemcpyAsync(f.d_q, f.h_q, sizeof(DevSeqQ) * S, hipMemcpyHostToDevice, f.stream));
-
-    SeqArgs a;
-    memset(&a, 0, sizeof a);
     a.rtab = c->d_rtab;
-    a.q = f.d_q;
     a.filter = c->d_filter;
+    a.pre = f.d_scratch;
+    a.tree = a.pre + (size_t)S * 9 * c->lanes;
+    a.root = a.tree + (size_t)c->groups * 9 * SEQ_WG;
     a.lanes = c->lanes;
+    a.groups = c->groups;
     a.n = c->batch;
     a.s = S;
     const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
@@ -205,14 +203,10 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
         a.dump = f.d_dump;
     } else {
-        // the upload source must stay valid until the copy ran: a pinned header behind the mirror
-        DevMatchHeader *src = reinterpret_cast<DevMatchHeader *>(f.h_match + match_bytes(c->match_cap));
-        src->count = 0;
-        src->cap = c->match_cap;
-        src->pad[0] = src->pad[1] = 0;
-        HIP_TRY(c, hipMemcpyAsync(f.d_match, src, sizeof(DevMatchHeader), hipMemcpyHostToDevice, f.stream));
         a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
         a.mrec = reinterpret_cast<DevMatch *>(f.d_match + sizeof(DevMatchHeader));
+        a.match_base = f.match_base;   // the counter is monotonic: no reset, no upload
+        a.match_cap = c->match_cap;
     }
     HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
     HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream));
@@ -237,7 +231,8 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
     uint32_t found = 0;
     if (!f.dumped) {
         const DevMatchHeader *hdr = reinterpret_cast<const DevMatchHeader *>(f.h_match);
-        found = hdr->count;
+        found = hdr->count - f.match_base;   // mod 2^32
+        f.match_base = hdr->count;
         uint32_t stored = std::min(found, c->match_cap);
         if (stored > FIRST_COPY)
             HIP_TRY(c, hipMemcpy(f.h_match + match_bytes(FIRST_COPY), f.d_match + match_bytes(FIRST_COPY),

@@ -12,12 +12,14 @@
 #include "../../include/vgen_hip.h"
 #include "device/device_types.h"
 #include "host/filter.h"
+#include "host/host_ec.h"
 #include "host/scalar.h"
 
 struct vgen_ctx {
     int device = 0;
     uint32_t batch = 0, frames = 0, match_cap = 0, format = 0;
-    uint32_t S = 0, lanes = 0;
+    uint32_t S = 0, lanes = 0, groups = 0;
+    vg::SeqBaseCache base_cache;         // host-side incremental base points (host_ec.h)
     uint32_t payload_words = 5;
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
@@ -28,8 +30,9 @@ struct vgen_ctx {
     struct Frame {
         hipStream_t stream = nullptr;
         hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-        vg::DevSeqQ *d_q = nullptr, *h_q = nullptr;
         uint32_t *d_dump = nullptr;
+        uint32_t *d_scratch = nullptr;   // pre | tree | root (device_types.h / kernels.hip)
+        uint32_t match_base = 0;         // candidate counter value when the last dispatch was enqueued
         uint8_t *d_match = nullptr;      // DevMatchHeader followed by match_cap DevMatch
         uint8_t *h_match = nullptr;      // pinned mirror
         bool in_flight = false;
