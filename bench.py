@@ -157,8 +157,17 @@ def main():
     keys = world * args.steps * N
     value = keys / elapsed / 1e6
     w_key = W_IMUL[args.format] * R_MUL + W_IOP[args.format]
+    # the dominant kernel (seq_bwd_kernel) does everything except the per-lane prefix products of
+    # seq_fwd_kernel (half an F_p multiplication per key: 74 imul + 60 iop per multiplication)
+    w_bwd = w_key - (74 * R_MUL + 60) // 2
     avg_ms = sum(kms) / len(kms)
-    achieved = N * w_key / (avg_ms * 1e-3) / 1e12
+    achieved = N * w_bwd / (avg_ms * 1e-3) / 1e12
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC passes (profiles/, FETCH_SIZE x2 per the guide)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        traffic = pm.get(f"{args.format}:{N}", {}).get("seq_bwd_kernel_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
     out = {
         "metric": "Mkeys/s (keys tried per second)", "value": round(value, 2), "unit": "Mkeys/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -169,14 +178,15 @@ def main():
                    "keys_per_dispatch": N, "frames_in_flight": F, "parallelism": f"range-striped x{world}",
                    "device_filter_kind": pat.device_kind, "candidates_reported": cand},
         "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1),
-                     "unit": "Tlaneop/s", "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": None,
-                     "kernel": "seq_scan_kernel", "avg_launch_ms": round(avg_ms, 4), "launches_overlapped": F,
-                     "work_per_key": w_key,
+                     "unit": "Tlaneop/s", "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": traffic,
+                     "kernel": "seq_bwd_kernel", "avg_launch_ms": round(avg_ms, 4), "launches_overlapped": F,
+                     "work_per_key": w_bwd, "work_per_key_whole_path": w_key,
                      "chip_achieved": round(value * 1e6 / world * w_key / 1e12, 3),
                      "chip_frac": round(value * 1e6 / world * w_key / 1e12 / PEAK_TLANEOPS, 4),
-                     "note": "integer-VALU bound path (no MFMA; HBM traffic ~0 in filter mode); achieved = "
-                             "algorithmic lane-op-equivalents of one launch / its HIP-event duration; launches of "
-                             "different frames overlap on the device, chip_* uses whole-run wall time instead"},
+                     "note": "integer-VALU bound path (no MFMA; HBM traffic is a few % of peak); achieved = "
+                             "algorithmic lane-op-equivalents of one seq_bwd_kernel launch / its HIP-event duration; "
+                             "launches of different frames overlap on the device (each then runs longer), so chip_* "
+                             "gives the same ratio from whole-run wall time over all kernels"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.format, args.pattern, args.ci)

@@ -132,9 +132,11 @@ int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint
 /* Dump mode only, after vgen_wait: copies the frame's payloads (batch_size * 20 bytes, or * 32 for
  * P2TR; zeroed for invalid keys) — the Vec<[u8;20]> await_result returns (src/gpu.rs:644-650). */
 int vgen_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
-/* Device time of the frame's last completed dispatch, measured with HIP events on the frame's own
- * stream (kernel only, excluding the host-side base-point computation). */
+/* Device time of the dominant kernel (seq_bwd_kernel: tree walk-down, point additions, hashes,
+ * filter) of the frame's last completed dispatch, from HIP events on the frame's own stream. */
 int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms);
+/* Device time of the whole dispatch (seq_fwd + seq_inv + seq_bwd kernels incl. the gaps between them). */
+int vgen_frame_dispatch_ms(vgen_ctx *ctx, uint32_t frame, float *ms);
 
 /* ---- host-side derivation (what the Rust host obtains from rust-bitcoin) ----------------------------- */
 

@@ -94,6 +94,7 @@ _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match
                          ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
 _L.vgen_read_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
 _L.vgen_frame_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
+_L.vgen_frame_dispatch_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
 _L.vgen_address_from_payload.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_key_to_wif.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_key_add.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
@@ -264,8 +265,15 @@ class GpuRunner:
         return n.value, tested.value
 
     def kernel_ms(self, frame: int) -> float:
+        """HIP-event duration of the dominant kernel (seq_bwd_kernel) of the frame's last dispatch."""
         ms = ctypes.c_float()
         _check(_L.vgen_frame_kernel_ms(self._h, frame, ctypes.byref(ms)), self._h)
+        return ms.value
+
+    def dispatch_ms(self, frame: int) -> float:
+        """HIP-event duration of the whole last dispatch (fwd + inv + bwd kernels)."""
+        ms = ctypes.c_float()
+        _check(_L.vgen_frame_dispatch_ms(self._h, frame, ctypes.byref(ms)), self._h)
         return ms.value
 
 

@@ -124,6 +124,12 @@ int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {
     return VGEN_OK;
 }
 
+int vgen_frame_dispatch_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {
+    if (!ctx || !ms || frame >= ctx->frames) return VGEN_E_INVALID;
+    *ms = ctx->fr[frame].last_total_ms;
+    return VGEN_OK;
+}
+
 int vgen_address_from_payload(uint32_t format, const uint8_t *payload, char *out, size_t cap) {
     if (!payload) return VGEN_E_INVALID;
     std::string s = vg::address_from_payload(format, payload);

@@ -276,7 +276,7 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream) {
+hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream, hipEvent_t before_bwd) {
     if (a.lanes % WG != 0 || a.groups != a.lanes / WG || a.s < 2 || a.s > SEQ_MAX_S) return hipErrorInvalidValue;
     hipLaunchKernelGGL(seq_fwd_kernel, dim3(a.groups), dim3(WG), 0, stream, a);
     hipError_t e = hipGetLastError();
@@ -284,6 +284,7 @@ hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (before_bwd && (e = hipEventRecord(before_bwd, stream)) != hipSuccess) return e;
     switch (fmt) {
     case VGF_P2PKH:
     case VGF_P2WPKH:

@@ -7,6 +7,7 @@
 namespace vg {
 
 // Enqueues the sequential-range scan on `stream`.  a.lanes must be a multiple of 256.
-hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream);
+// `before_bwd` (optional) is recorded between the inversion stage and the backward stage.
+hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream, hipEvent_t before_bwd);
 
 }  // namespace vg

@@ -29,7 +29,7 @@ struct vgen_ctx {
 
     struct Frame {
         hipStream_t stream = nullptr;
-        hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+        hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;   // before fwd / before bwd / after bwd
         uint32_t *d_dump = nullptr;
         uint32_t *d_scratch = nullptr;   // pre | tree | root (device_types.h / kernels.hip)
         uint32_t match_base = 0;         // candidate counter value when the last dispatch was enqueued
@@ -38,7 +38,8 @@ struct vgen_ctx {
         bool in_flight = false;
         bool dumped = false;             // last dispatch ran in dump mode
         vg::Scalar start{};
-        float last_ms = 0.f;
+        float last_ms = 0.f;             // dominant kernel (seq_bwd) of the last completed dispatch
+        float last_total_ms = 0.f;       // whole dispatch: fwd + inv + bwd
     };
     std::vector<Frame> fr;
     std::string err;
