@@ -156,3 +156,42 @@ int core_address(unsigned format, const unsigned char *payload, char *out) {
     return (int)s.size();
 }
 }
+
+extern "C" {
+// Fixed-window accumulation exactly as keys_scan_kernel does it (unsigned 4-bit windows, low to high,
+// gej_add_ge_nz without special cases) -> x||y big-endian; returns 0 for k == 0.
+int core_mul_windows_nz(const unsigned char *key_be, unsigned char *xy) {
+    Scalar k;
+    scalar_from_be(k, key_be);
+    ge g;
+    ge_generator(g);
+    gej base;
+    gej_from_ge(base, g);
+    gej acc;
+    gej_set_infinity(acc);
+    for (int w = 0; w < 64; w++) {
+        unsigned d = (k.w[w >> 3] >> ((w & 7) * 4)) & 15u;
+        if (d) {
+            // d * 16^w * G by repeated generic addition (reference for the table entry)
+            gej e;
+            gej_set_infinity(e);
+            ge ba;
+            ge_from_gej(ba, base);
+            for (unsigned t = 0; t < d; t++) gej_add_ge(e, e, ba);
+            ge ea;
+            ge_from_gej(ea, e);
+            if (acc.inf) gej_from_ge(acc, ea);
+            else gej_add_ge_nz(acc, acc, ea);
+        }
+        for (int t = 0; t < 4; t++) gej_double(base, base);
+    }
+    ge p;
+    if (!ge_from_gej(p, acc)) return 0;
+    u32 wv[8];
+    fe_to_words(p.x, wv);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[4 * (7 - i) + j] = (unsigned char)(wv[i] >> (24 - 8 * j));
+    fe_to_words(p.y, wv);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[32 + 4 * (7 - i) + j] = (unsigned char)(wv[i] >> (24 - 8 * j));
+    return 1;
+}
+}

@@ -188,3 +188,50 @@ def test_errors_are_loud(vg):
     with pytest.raises(vg.VgenError):
         vg.Pattern("[invalid", False)
     r.close()
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_keys_mode_arbitrary_scalars(vg, vo, fmt):
+    """vgen_dispatch_keys: independent scalars, full fixed-base multiplication per key (the shape of the
+    reference CPU loop, scanner.rs:151-155); invalid scalars yield nothing (address.rs:93)."""
+    import random
+    rng = random.Random(1000 + fmt)
+    batch = 8192
+    keys = [1, 2, 3, N - 1, N - 2, 0, N, N + 1, 2**256 - 1, 15, 16, 2**252, 0x1000000000000000000000000000000]
+    keys += [rng.randrange(1, N) for _ in range(3000 - len(keys))]
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt))
+    r.set_filter(None)
+    r.dispatch_keys(keys, 0)
+    blob, _, tested = r.await_result(0)
+    assert tested == len(keys)
+    for i, k in enumerate(keys):
+        want = vo.payload(fmt, k) if vo.key_valid(k) else bytes(20)
+        assert blob[20 * i:20 * i + 20] == want, (i, hex(k))
+    assert blob[20 * len(keys):] == bytes(20 * (batch - len(keys)))
+    # filter mode on the same keys: candidates are exactly the keys whose address matches
+    pat = {0: "^1[A-D]", 1: "^bc1q[qp]", 2: "^3[A-D]", 4: "^1[A-D]", 5: "^0x[0-3]"}[fmt]
+    p = vg.Pattern(pat, False, vg.AddressFormat(fmt))
+    oracle_re = vo.Regex(pat, False)
+    r.set_filter(p)
+    r.dispatch_keys(keys, 1)
+    recs, n_found, _ = r.await_result(1)
+    got = [i for i, pl in recs if p.matches(vg.address_from_payload(fmt, pl))]
+    want = [i for i, k in enumerate(keys) if vo.key_valid(k) and oracle_re.matches(vo.generate(fmt, k)["address"])]
+    assert got == want and len(want) > 50
+    r.close()
+
+
+def test_sequential_batch_that_reaches_the_group_order(vg, vo):
+    """Keys >= n yield no result (increment_key -> None, gpu.rs:963): the batch goes through the complete
+    per-key kernel and must still agree with the oracle key by key."""
+    batch = 8192
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh)
+    for start in (N - 5000, N - batch, N - 1, N - batch - 3):
+        got = dump(r, start)
+        assert got == vo.payload_seq(0, start, batch), hex(start)
+    # and a range scan ending at n-1 reports the last valid keys
+    cfg = vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=10**9, start=N - 20000, end=N - 1)
+    res = vg.scan_gpu_with_runner("^1[1-9A-F]", cfg, r)
+    ref = vo.scan_range(0, "^1[1-9A-F]", N - 20000, N - 1, count=10**9)
+    assert [m.hex for m in res.matches] == [x["hex"] for x in ref["matches"]]
+    r.close()

@@ -54,3 +54,14 @@ def test_stride_table(core):
     core.core_stride_table(1, 1, count, buf)
     for e in (0, 1, 4094, 4095, 4096, 4097, 4099):
         assert buf.raw[64 * e:64 * e + 64] == vo.pubkey(1 + e)[1:]
+
+
+def test_branch_free_window_accumulation_used_by_keys_kernel(core):
+    """gej_add_ge_nz (no special-case handling) is safe for low-to-high unsigned windows of a valid key."""
+    rng = random.Random(77)
+    keys = [1, 2, 15, 16, 17, 0xF0, 0x100, N - 1, N - 2, 2**255, 0x1111111111111111, (1 << 252) - 1] + \
+           [rng.randrange(1, N) for _ in range(12)]
+    for k in keys:
+        out = ctypes.create_string_buffer(64)
+        assert core.core_mul_windows_nz(k.to_bytes(32, "big"), out) == 1
+        assert out.raw == vo.pubkey(k)[1:], hex(k)

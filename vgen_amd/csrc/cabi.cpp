@@ -102,9 +102,9 @@ int vgen_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32])
     return vg::rt_dispatch(ctx, frame, start_key_be);
 }
 
-int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t, const uint8_t *, uint32_t) {
+int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n) {
     if (!ctx) return VGEN_E_INVALID;
-    return ctx->fail(VGEN_E_UNSUPPORTED, "vgen_dispatch_keys: arbitrary-scalar kernel not built yet");
+    return vg::rt_dispatch_keys(ctx, frame, keys_be, n);
 }
 
 int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,

@@ -160,3 +160,48 @@ VG_HD void ge_generator(ge &g) {
 }
 
 }  // namespace vg
+
+namespace vg {
+
+// r = a + b for a Jacobian point a (not infinity, coordinates magnitude 1) and an affine point b
+// (canonical), assuming a != +/-b.  3 squarings + 8 multiplications, no branches: the device
+// fixed-window accumulation never meets the exceptional cases (see keys_scan_kernel).
+VG_HD void gej_add_ge_nz(gej &r, const gej &a, const ge &b) {
+    fe z1z1, u2, s2, h, rr, hh, j, v, t, x3, y3, z3;
+    fe_sqr(z1z1, a.z);
+    fe_mul(u2, b.x, z1z1);
+    fe_mul(t, a.z, z1z1);
+    fe_mul(s2, b.y, t);
+    fe_neg(t, a.x, 1);
+    fe_add(h, u2, t);             // magnitude 3
+    fe_normalize_weak(h);
+    fe_neg(t, a.y, 1);
+    fe_add(rr, s2, t);
+    fe_normalize_weak(rr);
+    fe_sqr(hh, h);
+    fe_mul(j, h, hh);
+    fe_mul(v, a.x, hh);
+    fe_sqr(x3, rr);
+    // x3 = rr^2 - j - 2v
+    fe_neg(t, j, 1);              // m2
+    fe_add(x3, x3, t);            // m3
+    fe_neg(t, v, 1);              // m2
+    fe_add(x3, x3, t);            // m5
+    fe_add(x3, x3, t);            // m7
+    fe_normalize_weak(x3);
+    // y3 = rr*(v - x3) - y1*j
+    fe_neg(t, x3, 1);
+    fe_add(t, t, v);              // m3
+    fe_mul(y3, rr, t);
+    fe_mul(t, a.y, j);
+    fe_neg(t, t, 1);
+    fe_add(y3, y3, t);            // m3
+    fe_normalize_weak(y3);
+    fe_mul(z3, a.z, h);
+    r.x = x3;
+    r.y = y3;
+    r.z = z3;
+    r.inf = 0;
+}
+
+}  // namespace vg

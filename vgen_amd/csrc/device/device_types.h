@@ -82,4 +82,23 @@ struct SeqArgs {
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 
+// Arbitrary-scalar kernel (keys_scan_kernel): one key per lane, full fixed-base multiplication with a
+// 4-bit window table (64 windows x 15 points x 18 limbs = 69 120 B) staged in LDS.
+constexpr int KEYS_WG = 256;
+constexpr uint32_t KEYS_TABLE_WORDS = 64 * 15 * 18;
+
+struct KeysArgs {
+    const uint32_t *gtab;      // [64][15][18]: x limbs 0..8, y limbs 0..8 of d * 16^w * G (d = 1..15)
+    const uint8_t *keys_be;    // n * 32 bytes big-endian, or nullptr: key i = base + i
+    const DevFilter *filter;
+    uint32_t *dump;            // dump mode: n * 5 words (zeroed for invalid keys)
+    DevMatchHeader *mhdr;
+    DevMatch *mrec;
+    uint32_t base[8];          // sequential variant: little-endian words of the first key
+    uint32_t n;
+    uint32_t match_base;
+    uint32_t match_cap;
+    uint32_t pad;
+};
+
 }  // namespace vg

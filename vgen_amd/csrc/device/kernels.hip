@@ -268,6 +268,152 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
     }
 }
 
+// ---- arbitrary scalars: full fixed-base multiplication per key ------------------------------------------------
+//
+// The shape of the reference's CPU path (an independent key per iteration, src/scanner.rs:151-155,
+// full ec_pubkey_create each time) on the device: one key per lane, 4-bit fixed windows processed from
+// the least significant one, the 64 x 15 point table staged in LDS (69 KB; entries of one window are
+// 18 dwords apart, i.e. on distinct even banks, identical digits broadcast).  Accumulating low to high
+// with unsigned digits means the running sum is always smaller than the next addend's scalar, so the
+// mixed addition never meets P = +/-Q and needs no branches; the only special case is "still at
+// infinity", handled by a select.  One Fermat inverse per key (this mode is ~45x the work of the
+// sequential mode per key; it also serves the rare sequential batches that touch the group order).
+
+constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
+                            0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+
+template <int FMT>
+__global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args) {
+    extern __shared__ u32 tab[];   // KEYS_TABLE_WORDS
+    const int tid = threadIdx.x;
+    for (u32 i = tid; i < KEYS_TABLE_WORDS; i += KEYS_WG) tab[i] = args.gtab[i];
+    __syncthreads();
+
+    const u32 idx = blockIdx.x * KEYS_WG + tid;
+    const bool in_range = idx < args.n;
+    // scalar as eight little-endian words
+    u32 k[8];
+    if (args.keys_be) {
+        const u32 *src = reinterpret_cast<const u32 *>(args.keys_be) + (size_t)(in_range ? idx : 0) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = bswap32(src[7 - i]);
+    } else {
+        u64 c = idx;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            c += args.base[i];
+            k[i] = (u32)c;
+            c >>= 32;
+        }
+        if (c) {   // wrapped past 2^256: not a key
+#pragma unroll
+            for (int i = 0; i < 8; i++) k[i] = 0;
+        }
+    }
+    // valid iff 0 < k < n (SecretKey::from_slice, src/address.rs:93)
+    u32 nz = 0;
+    int cmp = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        nz |= k[i];
+        const int d = (k[i] > ORDER_N[i]) - (k[i] < ORDER_N[i]);
+        cmp = cmp == 0 ? d : cmp;
+    }
+    const bool valid = in_range && nz != 0 && cmp < 0;
+    if (!valid) {   // keep the lane busy with a harmless scalar; its result is discarded
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = 0;
+        k[0] = 1;
+    }
+
+    gej acc;
+    gej_set_infinity(acc);
+#pragma unroll 1
+    for (int w = 0; w < 64; w++) {
+        const u32 d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+        const u32 e = (d ? d : 1u) - 1u;
+        const u32 *ent = tab + ((u32)w * 15u + e) * 18u;
+        ge t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            t.x.n[i] = ent[i];
+            t.y.n[i] = ent[9 + i];
+        }
+        gej sum;
+        gej_add_ge_nz(sum, acc, t);      // garbage while acc is at infinity; replaced below
+        const bool take_table = acc.inf != 0;
+        const bool skip = d == 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const u32 nx = take_table ? t.x.n[i] : sum.x.n[i];
+            const u32 ny = take_table ? t.y.n[i] : sum.y.n[i];
+            const u32 nzl = take_table ? (i == 0 ? 1u : 0u) : sum.z.n[i];
+            acc.x.n[i] = skip ? acc.x.n[i] : nx;
+            acc.y.n[i] = skip ? acc.y.n[i] : ny;
+            acc.z.n[i] = skip ? acc.z.n[i] : nzl;
+        }
+        acc.inf = skip ? acc.inf : 0u;
+    }
+
+    // to affine (per-lane Fermat inverse), canonical coordinates
+    fe zi, zi2, zi3, x, y;
+    fe_inv(zi, acc.z);
+    fe_sqr(zi2, zi);
+    fe_mul(zi3, zi2, zi);
+    fe_mul(x, acc.x, zi2);
+    fe_mul(y, acc.y, zi3);
+    fe_normalize(x);
+    fe_normalize(y);
+
+    u32 xw[8], pl[5];
+    fe_to_words(x, xw);
+    payload_from_point<FMT>(xw, y, pl);
+
+    if (!in_range) return;
+    if (args.dump) {
+        u32 *o = args.dump + (size_t)idx * 5;
+#pragma unroll
+        for (int i = 0; i < 5; i++) o[i] = valid ? pl[i] : 0u;
+    } else if (valid && filter_eval(args.filter, pl)) {
+        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+        if (slot < args.match_cap) {
+            DevMatch *m = args.mrec + slot;
+            m->index = idx;
+            m->reserved = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) m->payload[i] = pl[i];
+            m->payload[5] = m->payload[6] = m->payload[7] = 0;
+        }
+    }
+}
+
+template <int FMT>
+static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream) {
+    const size_t lds_bytes = KEYS_TABLE_WORDS * sizeof(u32);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&keys_scan_kernel<FMT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(keys_scan_kernel<FMT>, dim3((a.n + KEYS_WG - 1) / KEYS_WG), dim3(KEYS_WG), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream) {
+    if (a.n == 0) return hipSuccess;
+    switch (fmt) {
+    case VGF_P2PKH:
+    case VGF_P2WPKH:
+        return launch_keys_fmt<VGF_P2PKH>(a, stream);
+    case VGF_P2SH_P2WPKH:
+        return launch_keys_fmt<VGF_P2SH_P2WPKH>(a, stream);
+    case VGF_P2PKH_UNCOMPRESSED:
+        return launch_keys_fmt<VGF_P2PKH_UNCOMPRESSED>(a, stream);
+    case VGF_ETHEREUM:
+        return launch_keys_fmt<VGF_ETHEREUM>(a, stream);
+    default:
+        return hipErrorInvalidValue;
+    }
+}
+
 // ---- launch (called from runtime.cpp) ---------------------------------------------------------------------
 
 template <int FMT>

@@ -11,3 +11,8 @@ namespace vg {
 hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream, hipEvent_t before_bwd);
 
 }  // namespace vg
+
+namespace vg {
+// Enqueues the arbitrary-scalar scan (one key per lane, full fixed-base multiplication).
+hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream);
+}  // namespace vg

@@ -198,3 +198,18 @@ bool host_seq_points(SeqBaseCache &c, const Scalar &kb, uint32_t S, ge *out) {
 }
 
 }  // namespace vg
+
+namespace vg {
+void host_gen_table_limbs(std::vector<uint32_t> &out) {
+    std::call_once(g_gen_once, build_gen_table);
+    out.resize((size_t)64 * 15 * 18);
+    for (int w = 0; w < 64; w++)
+        for (int d = 1; d < 16; d++) {
+            uint32_t *p = &out[((size_t)w * 15 + (d - 1)) * 18];
+            for (int i = 0; i < 9; i++) {
+                p[i] = g_gen_table[w][d].x.n[i];
+                p[9 + i] = g_gen_table[w][d].y.n[i];
+            }
+        }
+}
+}  // namespace vg

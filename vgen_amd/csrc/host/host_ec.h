@@ -43,3 +43,9 @@ struct SeqBaseCache {
 bool host_seq_points(SeqBaseCache &cache, const Scalar &kb, uint32_t S, ge *out);
 
 }  // namespace vg
+
+namespace vg {
+// The 4-bit fixed-window generator table as the device wants it: [64][15][18] limbs
+// (x limbs 0..8 then y limbs 0..8 of d * 16^w * G, d = 1..15).
+void host_gen_table_limbs(std::vector<uint32_t> &out);
+}  // namespace vg

@@ -128,6 +128,7 @@ void rt_destroy(vgen_ctx *c) {
     for (auto &f : c->fr) {
         if (f.stream) (void)hipStreamSynchronize(f.stream);
         if (f.d_dump) (void)hipFree(f.d_dump);
+        if (f.d_keys) (void)hipFree(f.d_keys);
         if (f.d_scratch) (void)hipFree(f.d_scratch);
         if (f.d_match) (void)hipFree(f.d_match);
         if (f.h_match) (void)hipHostFree(f.h_match);
@@ -137,6 +138,7 @@ void rt_destroy(vgen_ctx *c) {
         if (f.stream) (void)hipStreamDestroy(f.stream);
     }
     if (c->d_rtab) (void)hipFree(c->d_rtab);
+    if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_filter) (void)hipFree(c->d_filter);
     delete c;
 }
@@ -156,6 +158,49 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
     return VGEN_OK;
 }
 
+namespace {
+
+// Enqueues the arbitrary-scalar kernel on frame f: explicit keys (keys_dev != nullptr) or base + i.
+int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
+    if (!c->d_gtab) {
+        std::vector<uint32_t> tab;
+        host_gen_table_limbs(tab);
+        HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    KeysArgs a;
+    memset(&a, 0, sizeof a);
+    a.gtab = c->d_gtab;
+    a.keys_be = keys_dev;
+    if (base)
+        for (int i = 0; i < 8; i++) a.base[i] = base->w[i];
+    a.filter = c->d_filter;
+    a.n = n;
+    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
+    if (dump) {
+        if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
+        if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.stream));
+        a.dump = f.d_dump;
+    } else {
+        a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
+        a.mrec = reinterpret_cast<DevMatch *>(f.d_match + sizeof(DevMatchHeader));
+        a.match_base = f.match_base;
+        a.match_cap = c->match_cap;
+    }
+    HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
+    HIP_TRY(c, hipEventRecord(f.ev_mid, f.stream));
+    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.stream));
+    HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
+    if (!dump)
+        HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
+    f.in_flight = true;
+    f.dumped = dump;
+    f.keys_tested = n;
+    return VGEN_OK;
+}
+
+}  // namespace
+
 int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     if (frame >= c->frames || !start_key_be) return c->fail(VGEN_E_INVALID, "bad frame index / key");
     vgen_ctx::Frame &f = c->fr[frame];
@@ -163,12 +208,13 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     Scalar k0;
     scalar_from_be(k0, start_key_be);
     if (!scalar_is_valid(k0)) return c->fail(VGEN_E_RANGE, "start key is not a valid secp256k1 scalar");
-    // The batched affine additions have no exceptional cases as long as every scalar involved stays
-    // below n (SURVEY.md §7 "hard parts"): k0 + N + S < n.  Batches that reach the top of the scalar
-    // range need the complete-formula path.
-    if (scalar_distance_to_n(k0) <= (uint64_t)c->batch + c->S)
-        return c->fail(VGEN_E_UNSUPPORTED, "dispatch reaches the group order n: not supported by the sequential kernel yet");
     HIP_TRY(c, hipSetDevice(c->device));
+    f.start = k0;
+    // The batched affine additions have no exceptional cases as long as every scalar involved stays
+    // below n (SURVEY.md §7 "hard parts"): k0 + N + S < n.  The (astronomically rare) batches that touch
+    // the top of the scalar range go through the complete per-key kernel instead; keys >= n yield nothing
+    // there (increment_key -> None, src/gpu.rs:963).
+    if (scalar_distance_to_n(k0) <= (uint64_t)c->batch + c->S) return enqueue_keys(c, f, nullptr, &k0, c->batch);
 
     // Q_j = (k0 + N/2 - S/2 + j) * G, j < S, passed by value in the kernel arguments
     const uint32_t S = c->S;
@@ -217,8 +263,20 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
     f.in_flight = true;
     f.dumped = dump;
-    f.start = k0;
+    f.keys_tested = c->batch;
     return VGEN_OK;
+}
+
+int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32_t n) {
+    if (frame >= c->frames || !keys_be) return c->fail(VGEN_E_INVALID, "bad frame index / key buffer");
+    if (n == 0 || n > c->batch) return c->fail(VGEN_E_INVALID, "vgen_dispatch_keys: n must be in [1, batch_size]");
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!f.d_keys) HIP_TRY(c, hipMalloc((void **)&f.d_keys, (size_t)c->batch * 32));
+    HIP_TRY(c, hipMemcpyAsync(f.d_keys, keys_be, (size_t)n * 32, hipMemcpyHostToDevice, f.stream));
+    memset(&f.start, 0, sizeof f.start);
+    return enqueue_keys(c, f, f.d_keys, nullptr, n);
 }
 
 int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches, uint64_t *keys_tested) {
@@ -230,7 +288,7 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
     f.in_flight = false;
     (void)hipEventElapsedTime(&f.last_ms, f.ev_mid, f.ev_stop);
     (void)hipEventElapsedTime(&f.last_total_ms, f.ev_start, f.ev_stop);
-    if (keys_tested) *keys_tested = c->batch;
+    if (keys_tested) *keys_tested = f.keys_tested;
     uint32_t found = 0;
     if (!f.dumped) {
         const DevMatchHeader *hdr = reinterpret_cast<const DevMatchHeader *>(f.h_match);

@@ -23,6 +23,7 @@ struct vgen_ctx {
     uint32_t payload_words = 5;
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
+    uint32_t *d_gtab = nullptr;          // 4-bit fixed-window generator table (keys kernel), built on first use
     vg::DevFilter *d_filter = nullptr;   // current device filter program
     bool have_filter = false;            // false = dump mode
     vg::DevFilter h_filter{};
@@ -31,6 +32,8 @@ struct vgen_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;   // before fwd / before bwd / after bwd
         uint32_t *d_dump = nullptr;
+        uint8_t *d_keys = nullptr;       // explicit keys of vgen_dispatch_keys
+        uint64_t keys_tested = 0;
         uint32_t *d_scratch = nullptr;   // pre | tree | root (device_types.h / kernels.hip)
         uint32_t match_base = 0;         // candidate counter value when the last dispatch was enqueued
         uint8_t *d_match = nullptr;      // DevMatchHeader followed by match_cap DevMatch
@@ -56,6 +59,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
 void rt_destroy(vgen_ctx *ctx);
 int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 int rt_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]);
+int rt_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n);
 int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
             uint64_t *keys_tested);
 int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
