@@ -196,6 +196,13 @@ typedef void (*vgen_progress_cb)(uint64_t operations, void *user); /* ProgressCa
  * completed batch (gpu.rs:1106) and honours *stop between batches (gpu.rs:980-984,1007-1011). */
 int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
               void *user, volatile int32_t *stop, vgen_scan_result *out);
+/* The same scan over several contexts (one per GPU of the node; the reference is single-adapter,
+ * src/gpu.rs:161-165): one host thread per context, global batch b goes to context b mod n_ctx, a
+ * shared match counter / stop flag, matches merged in ascending key order and truncated to count,
+ * operations summed.  No device-to-device traffic.  All contexts must share batch_size
+ * and format; cfg->shard / n_shards are ignored. */
+int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *pattern, const vgen_scan_config *cfg,
+                    vgen_progress_cb cb, void *user, volatile int32_t *stop, vgen_scan_result *out);
 void vgen_scan_result_free(vgen_scan_result *r);
 
 #ifdef __cplusplus

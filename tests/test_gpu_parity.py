@@ -235,3 +235,56 @@ def test_sequential_batch_that_reaches_the_group_order(vg, vo):
     ref = vo.scan_range(0, "^1[1-9A-F]", N - 20000, N - 1, count=10**9)
     assert [m.hex for m in res.matches] == [x["hex"] for x in ref["matches"]]
     r.close()
+
+
+def test_multi_context_striped_scan_equals_single_scan(vg, vo):
+    """vgen_scan_multi: batch striping over several contexts (here three contexts on the one GPU of the
+    test box) gives the single-context result; operations are whole batches summed over shards."""
+    batch = 8192
+    rs = [vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2) for _ in range(3)]
+    cfg = vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=10**9, start=0x10000, end=0x10000 + 20 * batch - 1)
+    multi = vg.scan_gpu_with_runner("^1[A-C]", cfg, rs)
+    single = vg.scan_gpu_with_runner("^1[A-C]", cfg, rs[0])
+    ref = vo.scan_range(0, "^1[A-C]", 0x10000, 0x10000 + 20 * batch - 1, count=10**9)
+    want = [(x["address"], x["wif"]) for x in ref["matches"]]
+    assert [(m.address, m.wif) for m in single.matches] == want
+    assert [(m.address, m.wif) for m in multi.matches] == want
+    assert multi.operations == single.operations == 20 * batch
+    # count-limited: the first `count` matches in key order
+    cfg.count = 5
+    multi = vg.scan_gpu_with_runner("^1[A-C]", cfg, rs)
+    assert len(multi.matches) == 5
+    assert all(re.match("^1[A-C]", m.address) for m in multi.matches)
+    for r in rs:
+        r.close()
+
+
+def test_cli_generate_and_range(vg, vo, tmp_path):
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(vg.library_path()), "vgen-hip")
+    out = subprocess.run([exe, "generate", "-p", "^1Cat", "--seed", "42", "-o", "json", "--no-tui"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout)
+    assert list(d.keys()) == ["address", "wif", "private_key_hex", "format", "pattern", "operations", "elapsed_secs", "rate"]
+    assert d["address"].startswith("1Cat") and d["format"] == "P2PKH" and d["pattern"] == "^1Cat"
+    g = vo.generate(0, int(d["private_key_hex"], 16))
+    assert (g["address"], g["wif"]) == (d["address"], d["wif"])
+    # range --range 1:FFFF, count 0 = whole range (lib.rs:524), csv writer
+    out = subprocess.run([exe, "range", "--range", "1:FFFF", "-p", "^1[A-C]", "-c", "0", "-o", "csv",
+                          "--gpu-batch-size", "8192", "-q"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "address,wif,private_key_hex,format,pattern,operations,elapsed_secs,rate"
+    ref = vo.scan_range(0, "^1[A-C]", 1, 0xFFFF, count=10**9)
+    assert [l.split(",")[:3] for l in lines[1:]] == [[x["address"], x["wif"], x["hex"]] for x in ref["matches"]]
+    # puzzle range parsing + exact pattern + minimal writer
+    target = 2**9 + 77
+    addr = vo.generate(0, target)["address"]
+    out = subprocess.run([exe, "range", "--puzzle", "10", "-p", "^" + addr + "$", "-o", "minimal",
+                          "--gpu-batch-size", "8192"], capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == vo.wif(target)
+    out = subprocess.run([exe, "generate", "-p", "^1Cat", "--no-gpu"], capture_output=True, text=True)
+    assert out.returncode != 0 and "no CPU" in out.stderr

@@ -134,3 +134,15 @@ def test_unanchored_and_base58_suffix_patterns_fall_back_to_host_filtering(core)
     assert kind == 1 and 1e-7 < sel < 1e-4            # ~ 58^-3 plus length variants
     kind, sel, dev, exact = check(core, "^3Cat", False, 0, payloads)   # impossible for P2PKH
     assert not any(dev) and not any(exact)
+
+
+def test_suffix_prefilter_uses_the_whole_literal(core):
+    payloads = [bytes(20)]
+    kind, sel, _, _ = check(core, "dead$", False, 1, payloads)          # BASELINE config 3
+    assert kind == 2 and abs(sel - 32.0 ** -4) < 1e-9
+    kind, sel, _, _ = check(core, "deadbeef$", True, 5, payloads)
+    assert kind == 2 and abs(sel - 16.0 ** -8) < 1e-12
+    kind, sel, _, _ = check(core, "^bc1qq.*xyz$", False, 1, payloads)    # prefix x suffix
+    assert kind == 2 and abs(sel - 32.0 ** -4) < 1e-9
+    kind, sel, _, _ = check(core, "(aa|zz)$", False, 1, payloads)
+    assert kind == 2 and abs(sel - 2 * 32.0 ** -2) < 1e-9

@@ -103,6 +103,9 @@ _L.vgen_derive.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ct
 _L.vgen_device_name.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_scan.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(_ScanConfig), _PROGRESS, ctypes.c_void_p,
                          ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_ScanResult)]
+_L.vgen_scan_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_char_p,
+                               ctypes.POINTER(_ScanConfig), _PROGRESS, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
+                               ctypes.POINTER(_ScanResult)]
 _L.vgen_scan_result_free.argtypes = [ctypes.POINTER(_ScanResult)]
 _L.vgen_scan_result_free.restype = None
 
@@ -283,9 +286,13 @@ class GpuRunner:
         return ms.value
 
 
-def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner: GpuRunner,
+def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
                          progress_cb: Optional[Callable[[int], None]] = None, stop=None) -> ScanResult:
-    """scan_gpu_with_runner (src/gpu.rs:920-926).  `stop` is an optional ctypes.c_int32 flag."""
+    """scan_gpu_with_runner (src/gpu.rs:920-926).  `stop` is an optional ctypes.c_int32 flag.
+    `runner` may be a list of GpuRunners (one per GPU): the batches are then striped over them
+    (vgen_scan_multi)."""
+    runners = list(runner) if isinstance(runner, (list, tuple)) else [runner]
+    runner = runners[0]
     c = _ScanConfig()
     c.struct_size = ctypes.sizeof(_ScanConfig)
     c.format = int(config.format)
@@ -300,8 +307,12 @@ def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner: GpuRunner,
     c.seed, c.shard, c.n_shards, c.max_batches = config.seed, config.shard, config.n_shards, config.max_batches
     res = _ScanResult()
     cb = _PROGRESS(lambda ops, _u: progress_cb(ops)) if progress_cb else ctypes.cast(None, _PROGRESS)
-    rc = _L.vgen_scan(runner._h, pattern.encode(), ctypes.byref(c), cb, None,
-                      ctypes.byref(stop) if stop is not None else None, ctypes.byref(res))
+    stop_p = ctypes.byref(stop) if stop is not None else None
+    if len(runners) == 1:
+        rc = _L.vgen_scan(runner._h, pattern.encode(), ctypes.byref(c), cb, None, stop_p, ctypes.byref(res))
+    else:
+        arr = (ctypes.c_void_p * len(runners))(*[r._h for r in runners])
+        rc = _L.vgen_scan_multi(arr, len(runners), pattern.encode(), ctypes.byref(c), cb, None, stop_p, ctypes.byref(res))
     _check(rc, runner._h)
     out = ScanResult(operations=res.operations, elapsed_secs=res.elapsed_secs)
     for i in range(res.n_matches):

@@ -1,0 +1,378 @@
+// vgen_hip_cli.cpp — `vgen-hip`: a thin command line over the C ABI of libvgen_hip.so, reproducing the
+// flag set, defaults and result writers of the reference's `generate` / `range` / `list-gpus` /
+// `verify` commands (src/lib.rs:44-211 flags, :642-663 range parsing, :524 count 0 = unbounded,
+// :825-865 --repeat, :879-974 writers, :1038-1086 formatting helpers).  SURVEY.md §8(f) item 1.
+//
+// Deliberately absent: the TUI, the boha provider, `estimate`, and any CPU scan path (`--no-gpu` is an
+// error here: this build has no CPU backend).  Added: --seed (the reference seeds from OS entropy
+// only), --devices (batch-striped multi-GPU scan), --frames.
+#include <signal.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../../include/vgen_hip.h"
+
+namespace {
+
+volatile int32_t g_stop = 0;
+
+void on_sigint(int) {
+    if (g_stop) _exit(130);   // second Ctrl-C exits (lib.rs:1088-1097)
+    g_stop = 1;
+}
+
+struct Opts {
+    std::string cmd, pattern, format = "p2pkh", output = "text", file, range, key, address, devices = "0";
+    bool has_pattern = false, ignore_case = false, quiet = false, json = false, no_gpu = false;
+    uint64_t count = 1, repeat = 1, seed = 0;
+    uint32_t batch = 1u << 20, frames = 6;
+    int puzzle = 0;
+};
+
+[[noreturn]] void die(const std::string &msg) {
+    fprintf(stderr, "Error: %s\n", msg.c_str());
+    exit(1);
+}
+
+int format_id(const std::string &f) {
+    if (f == "p2pkh") return VGEN_FMT_P2PKH;
+    if (f == "p2wpkh") return VGEN_FMT_P2WPKH;
+    if (f == "p2sh-p2wpkh" || f == "p2sh-p2-wpkh" || f == "p2shp2wpkh") return VGEN_FMT_P2SH_P2WPKH;
+    if (f == "p2tr") return VGEN_FMT_P2TR;
+    if (f == "ethereum") return VGEN_FMT_ETHEREUM;
+    if (f == "p2pkh-uncompressed") return VGEN_FMT_P2PKH_UNCOMPRESSED;
+    die("invalid value '" + f + "' for '--format' (p2pkh, p2wpkh, p2sh-p2wpkh, p2tr, ethereum)");
+}
+
+const char *format_display(int id) {   // Display for AddressFormat, src/address.rs:48-58
+    switch (id) {
+    case VGEN_FMT_P2PKH: return "P2PKH";
+    case VGEN_FMT_P2PKH_UNCOMPRESSED: return "P2PKH (Uncompressed)";
+    case VGEN_FMT_P2WPKH: return "P2WPKH";
+    case VGEN_FMT_P2SH_P2WPKH: return "P2SH-P2WPKH";
+    case VGEN_FMT_P2TR: return "P2TR";
+    default: return "Ethereum";
+    }
+}
+
+std::string format_duration(double secs) {   // lib.rs:1038-1052
+    char b[64];
+    if (secs < 1.0) snprintf(b, sizeof b, "%.0fms", secs * 1000.0);
+    else if (secs < 60.0) snprintf(b, sizeof b, "%.1fs", secs);
+    else if (secs < 3600.0) snprintf(b, sizeof b, "%.1fm", secs / 60.0);
+    else if (secs < 86400.0) snprintf(b, sizeof b, "%.1fh", secs / 3600.0);
+    else if (secs < 31536000.0) snprintf(b, sizeof b, "%.1fd", secs / 86400.0);
+    else snprintf(b, sizeof b, "%.1fy", secs / 31536000.0);
+    return b;
+}
+
+std::string with_commas(uint64_t n) {   // lib.rs:1075-1086
+    std::string s = std::to_string(n), out;
+    for (size_t i = 0; i < s.size(); i++) {
+        if (i != 0 && (s.size() - i) % 3 == 0) out.push_back(',');
+        out.push_back(s[i]);
+    }
+    return out;
+}
+
+std::string csv_escape(const std::string &f) {   // lib.rs:1058-1073
+    if (f.find_first_of(",\"\n\r") == std::string::npos) return f;
+    std::string out = "\"";
+    for (char c : f) {
+        if (c == '"') out.push_back('"');
+        out.push_back(c);
+    }
+    return out + "\"";
+}
+
+std::string json_str(const std::string &s) {
+    std::string o = "\"";
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') {
+            o.push_back('\\');
+            o.push_back((char)c);
+        } else if (c < 0x20) {
+            char b[8];
+            snprintf(b, sizeof b, "\\u%04x", c);
+            o += b;
+        } else {
+            o.push_back((char)c);
+        }
+    }
+    return o + "\"";
+}
+
+std::string json_f64(double v) {
+    char b[64];
+    snprintf(b, sizeof b, "%.17g", v);
+    double back = strtod(b, nullptr);
+    for (int prec = 1; prec < 17; prec++) {   // shortest representation that round-trips
+        char t[64];
+        snprintf(t, sizeof t, "%.*g", prec, v);
+        if (strtod(t, nullptr) == back) {
+            snprintf(b, sizeof b, "%s", t);
+            break;
+        }
+    }
+    std::string s = b;
+    if (s.find_first_of(".eE") == std::string::npos) s += ".0";
+    return s;
+}
+
+bool parse_hex_key(const std::string &hex, uint8_t out[32]) {
+    if (hex.empty() || hex.size() > 64) return false;
+    memset(out, 0, 32);
+    std::string h(64 - hex.size(), '0');
+    h += hex;
+    for (int i = 0; i < 32; i++) {
+        unsigned v;
+        if (sscanf(h.c_str() + 2 * i, "%2x", &v) != 1) return false;
+        for (int j = 0; j < 2; j++) {
+            char c = h[2 * i + j];
+            if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F'))) return false;
+        }
+        out[i] = (uint8_t)v;
+    }
+    return true;
+}
+
+void usage() {
+    fprintf(stderr,
+            "vgen-hip — MI355X scan engine for the vgen hot path\n\n"
+            "  vgen-hip generate -p PATTERN [-f FORMAT] [-i] [-c COUNT] [-o text|json|jsonl|csv|minimal] [--file PATH]\n"
+            "                    [--gpu-batch-size N] [--repeat N] [-q] [--seed S] [--devices 0,1,..|all] [--frames F]\n"
+            "  vgen-hip range (--range START:END | --puzzle P) [-p PATTERN] [-f FORMAT] [-c COUNT (0 = whole range)] ...\n"
+            "  vgen-hip verify -k HEXKEY [-a ADDRESS]\n"
+            "  vgen-hip list-gpus [--json]\n");
+}
+
+Opts parse(int argc, char **argv) {
+    Opts o;
+    if (argc < 2) {
+        usage();
+        exit(2);
+    }
+    o.cmd = argv[1];
+    if (o.cmd == "range") o.count = 1;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) die("a value is required for '" + a + "'");
+            return argv[++i];
+        };
+        if (a == "-p" || a == "--pattern") { o.pattern = val(); o.has_pattern = true; }
+        else if (a == "-f" || a == "--format") o.format = val();
+        else if (a == "-i" || a == "--ignore-case") o.ignore_case = true;
+        else if (a == "-c" || a == "--count") o.count = strtoull(val().c_str(), nullptr, 10);
+        else if (a == "-o" || a == "--output") o.output = val();
+        else if (a == "--file") o.file = val();
+        else if (a == "--gpu-batch-size") o.batch = (uint32_t)strtoul(val().c_str(), nullptr, 10);
+        else if (a == "--repeat") o.repeat = strtoull(val().c_str(), nullptr, 10);
+        else if (a == "-q" || a == "--quiet") o.quiet = true;
+        else if (a == "--seed") o.seed = strtoull(val().c_str(), nullptr, 10);
+        else if (a == "--devices") o.devices = val();
+        else if (a == "--frames") o.frames = (uint32_t)strtoul(val().c_str(), nullptr, 10);
+        else if (a == "-r" || a == "--range") o.range = val();
+        else if (a == "--puzzle") o.puzzle = atoi(val().c_str());
+        else if (a == "-k" || a == "--key") o.key = val();
+        else if (a == "-a" || a == "--address") o.address = val();
+        else if (a == "--json") o.json = true;
+        else if (a == "--no-gpu") o.no_gpu = true;
+        else if (a == "--no-tui" || a == "--tui") {}                                   // no TUI in this build
+        else if (a == "-t" || a == "--threads" || a == "--backend" || a == "--cpu-batch-size" || a == "-l" ||
+                 a == "--prefix-length") (void)val();                                  // accepted, not applicable
+        else if (a == "-h" || a == "--help") { usage(); exit(0); }
+        else die("unexpected argument '" + a + "'");
+    }
+    return o;
+}
+
+std::vector<int> parse_devices(const std::string &s) {
+    int n = 0;
+    if (vgen_device_count(&n) != VGEN_OK || n <= 0) die("no HIP device available (this build has no CPU backend)");
+    std::vector<int> out;
+    if (s == "all") {
+        for (int i = 0; i < n; i++) out.push_back(i);
+        return out;
+    }
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        size_t c = s.find(',', pos);
+        std::string t = s.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+        if (t.empty()) die("bad --devices list");
+        int d = atoi(t.c_str());
+        if (d < 0 || d >= n) die("device " + t + " out of range (" + std::to_string(n) + " device(s))");
+        out.push_back(d);
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
+    return out;
+}
+
+int run_search(const Opts &o, const std::string &pattern, bool has_range, const uint8_t start[32], const uint8_t end[32]) {
+    if (o.no_gpu) die("--no-gpu: this build has no CPU scan path (the MI355X engine is the only backend)");
+    const int fmt = format_id(o.format);
+    // surface pattern errors before touching the device (Pattern::new, pattern.rs:21-33)
+    vgen_filter *probe = nullptr;
+    if (vgen_filter_compile(pattern.c_str(), o.ignore_case, (uint32_t)fmt, &probe) != VGEN_OK) die(vgen_last_error(nullptr));
+    vgen_filter_free(probe);
+
+    std::vector<int> devs = parse_devices(o.devices);
+    std::vector<vgen_ctx *> ctxs;
+    for (int d : devs) {
+        vgen_params p;
+        memset(&p, 0, sizeof p);
+        p.struct_size = sizeof p;
+        p.device = d;
+        p.batch_size = o.batch;
+        p.format = (uint32_t)fmt;
+        p.frames = o.frames;
+        vgen_ctx *c = nullptr;
+        if (vgen_create(&p, &c) != VGEN_OK) die(std::string("GPU initialization failed: ") + vgen_last_error(nullptr));
+        ctxs.push_back(c);
+    }
+
+    vgen_scan_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.format = (uint32_t)fmt;
+    cfg.count = o.count == 0 ? UINT64_MAX : o.count;   // lib.rs:524
+    cfg.case_insensitive = o.ignore_case;
+    cfg.seed = o.seed;
+    if (has_range) {
+        cfg.has_start = cfg.has_end = 1;
+        memcpy(cfg.start, start, 32);
+        memcpy(cfg.end, end, 32);
+    }
+
+    std::vector<vgen_generated> all;
+    uint64_t total_ops = 0;
+    double total_secs = 0;
+    for (uint64_t rep = 0; rep < (o.repeat ? o.repeat : 1) && !g_stop; rep++) {   // lib.rs:825-865
+        vgen_scan_result res;
+        int rc = ctxs.size() == 1 ? vgen_scan(ctxs[0], pattern.c_str(), &cfg, nullptr, nullptr, &g_stop, &res)
+                                  : vgen_scan_multi(ctxs.data(), (uint32_t)ctxs.size(), pattern.c_str(), &cfg, nullptr,
+                                                    nullptr, &g_stop, &res);
+        if (rc != VGEN_OK) die(vgen_last_error(ctxs[0]));
+        for (uint64_t i = 0; i < res.n_matches; i++) all.push_back(res.matches[i]);
+        total_ops += res.operations;
+        total_secs += res.elapsed_secs;
+        vgen_scan_result_free(&res);
+    }
+    for (auto *c : ctxs) vgen_destroy(c);
+
+    FILE *w = stdout;
+    if (!o.file.empty() && !(w = fopen(o.file.c_str(), "w"))) die("Failed to create output file");
+    const double rate = total_secs > 0 ? (double)total_ops / total_secs : 0.0;
+    const std::string fmt_name = format_display(fmt);
+    if (o.output == "csv" && !all.empty())
+        fprintf(w, "address,wif,private_key_hex,format,pattern,operations,elapsed_secs,rate\n");
+    for (size_t idx = 0; idx < all.size(); idx++) {
+        const vgen_generated &g = all[idx];
+        if (o.output == "text") {
+            fprintf(w, "=== Match %zu of %zu ===\n", idx + 1, all.size());
+            fprintf(w, "Pattern : %s\nFormat  : %s\nAddress : %s\nWIF     : %s\nHex     : %s\n", pattern.c_str(),
+                    fmt_name.c_str(), g.address, g.wif, g.hex);
+            if (!o.quiet) {
+                fprintf(w, "Ops     : %s (%.0f/sec)\n", with_commas(total_ops).c_str(), rate);
+                fprintf(w, "Time    : %s\n", format_duration(total_secs).c_str());
+            }
+            fprintf(w, "\n");
+        } else if (o.output == "json" || o.output == "jsonl") {
+            const bool pretty = o.output == "json";
+            const char *nl = pretty ? "\n  " : "", *sp = pretty ? " " : "";
+            fprintf(w, "{%s\"address\":%s%s,%s\"wif\":%s%s,%s\"private_key_hex\":%s%s,%s\"format\":%s%s,%s\"pattern\":%s%s,%s"
+                       "\"operations\":%s%llu,%s\"elapsed_secs\":%s%s,%s\"rate\":%s%s%s}\n",
+                    nl, sp, json_str(g.address).c_str(), nl, sp, json_str(g.wif).c_str(), nl, sp, json_str(g.hex).c_str(), nl,
+                    sp, json_str(fmt_name).c_str(), nl, sp, json_str(pattern).c_str(), nl, sp,
+                    (unsigned long long)total_ops, nl, sp, json_f64(total_secs).c_str(), nl, sp, json_f64(rate).c_str(),
+                    pretty ? "\n" : "");
+        } else if (o.output == "csv") {
+            fprintf(w, "%s,%s,%s,%s,%s,%llu,%s,%s\n", csv_escape(g.address).c_str(), csv_escape(g.wif).c_str(),
+                    csv_escape(g.hex).c_str(), csv_escape(fmt_name).c_str(), csv_escape(pattern).c_str(),
+                    (unsigned long long)total_ops, json_f64(total_secs).c_str(), json_f64(rate).c_str());
+        } else if (o.output == "minimal") {
+            fprintf(w, "%s\n", g.wif);
+        } else {
+            die("invalid value '" + o.output + "' for '--output'");
+        }
+    }
+    if (w != stdout) {
+        fclose(w);
+        if (!all.empty() && !o.quiet) fprintf(stderr, "Wrote %zu result(s) to %s\n", all.size(), o.file.c_str());
+    }
+    if (all.empty() && !o.quiet)
+        fprintf(stderr, "No match found after %s operations (%s)\n", with_commas(total_ops).c_str(),
+                format_duration(total_secs).c_str());
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // one hardware queue per frame stream; before HIP initialises
+    Opts o = parse(argc, argv);
+    signal(SIGINT, on_sigint);
+    if (o.cmd == "generate") {
+        if (!o.has_pattern) die("the following required arguments were not provided: --pattern <PATTERN>");
+        uint8_t z[32] = {0};
+        return run_search(o, o.pattern, false, z, z);
+    }
+    if (o.cmd == "range") {
+        uint8_t start[32], end[32];
+        if (o.puzzle) {   // lib.rs:643-649
+            if (o.puzzle < 1 || o.puzzle > 160) die("Puzzle number must be between 1 and 160");
+            memset(start, 0, 32);
+            memset(end, 0, 32);
+            const int sb = o.puzzle - 1;   // start = 2^(p-1), end = 2^p - 1
+            start[31 - sb / 8] = (uint8_t)(1u << (sb % 8));
+            for (int b = 0; b < o.puzzle; b++) end[31 - b / 8] |= (uint8_t)(1u << (b % 8));
+        } else if (!o.range.empty()) {   // lib.rs:650-657
+            size_t c = o.range.find(':');
+            if (c == std::string::npos || o.range.find(':', c + 1) != std::string::npos) die("Range must be in format START:END");
+            if (!parse_hex_key(o.range.substr(0, c), start)) die("Invalid start hex");
+            if (!parse_hex_key(o.range.substr(c + 1), end)) die("Invalid end hex");
+        } else {
+            die("Either --range, --puzzle, or a provider pattern with key range must be specified");
+        }
+        bool start_zero = true;
+        for (int i = 0; i < 32; i++) start_zero = start_zero && start[i] == 0;
+        if (start_zero) start[31] = 1;   // key 0 is not a key: the CPU path skips it (scanner.rs:294-295)
+        return run_search(o, o.has_pattern ? o.pattern : ".", true, start, end);   // default pattern, lib.rs:519
+    }
+    if (o.cmd == "list-gpus") {
+        int n = 0;
+        vgen_device_count(&n);
+        if (o.json) printf("[");
+        for (int i = 0; i < n; i++) {
+            char name[256];
+            vgen_device_name(i, name, sizeof name);
+            if (o.json) printf("%s{\"index\":%d,\"name\":%s,\"backend\":\"hip\"}", i ? "," : "", i, json_str(name).c_str());
+            else printf("[%d] %s (HIP)\n", i, name);
+        }
+        if (o.json) printf("]\n");
+        if (!n && !o.json) printf("No GPU adapters found\n");
+        return 0;
+    }
+    if (o.cmd == "verify") {
+        uint8_t k[32];
+        if (!parse_hex_key(o.key, k)) die("verify: --key must be a hex private key in this build");
+        const int fmts[] = {VGEN_FMT_P2PKH, VGEN_FMT_P2WPKH, VGEN_FMT_P2SH_P2WPKH, VGEN_FMT_P2PKH_UNCOMPRESSED, VGEN_FMT_ETHEREUM};
+        bool ok = o.address.empty();
+        for (int f : fmts) {
+            char addr[128], wif[128];
+            if (vgen_derive((uint32_t)f, k, addr, sizeof addr, wif, sizeof wif) != VGEN_OK) die("invalid private key");
+            printf("%-22s %s\n", format_display(f), addr);
+            if (o.address == addr) ok = true;
+        }
+        if (!o.address.empty()) printf("%s\n", ok ? "MATCH" : "MISMATCH");
+        return ok ? 0 : 1;
+    }
+    usage();
+    return 2;
+}

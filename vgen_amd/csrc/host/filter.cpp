@@ -339,6 +339,19 @@ void derive_symbols(const Dfa &d, const SymSpec &sp, DevFilter &dev, double &sel
     std::vector<std::string> best_suffixes;
     double suffix_sel = 1.0;
     const unsigned kmax = std::min<unsigned>(8, n_total);
+    // viable[r][s]: from DFA state s some string of exactly r more symbols ends in acceptance — prunes
+    // the suffix enumeration to branches that can still succeed
+    std::vector<std::vector<uint8_t>> viable(kmax + 1, std::vector<uint8_t>(d.n_states, 0));
+    for (uint32_t st = 0; st < d.n_states; st++) viable[0][st] = d.match_now[st] || d.match_at_end[st];
+    for (unsigned r = 1; r <= kmax; r++)
+        for (uint32_t st = 0; st < d.n_states; st++) {
+            if (d.match_now[st]) {
+                viable[r][st] = 1;
+                continue;
+            }
+            for (size_t a = 0; a < A && !viable[r][st]; a++)
+                viable[r][st] = viable[r - 1][step(d, st, (unsigned char)sp.alphabet[a])];
+        }
     for (unsigned k = 1; k <= kmax; k++) {
         // DFS over suffix strings with state sets
         struct Item {
@@ -368,9 +381,10 @@ void derive_symbols(const Dfa &d, const SymSpec &sp, DevFilter &dev, double &sel
             }
             for (size_t a = 0; a < A; a++) {
                 std::vector<uint32_t> nxt;
+                const unsigned remaining = k - (unsigned)it.s.size() - 1;
                 for (uint32_t st : it.states) {
                     uint32_t n = d.match_now[st] ? st : step(d, st, (unsigned char)sp.alphabet[a]);
-                    if (!d.dead[n]) nxt.push_back(n);
+                    if (!d.dead[n] && viable[remaining][n]) nxt.push_back(n);
                 }
                 if (nxt.empty()) continue;
                 std::sort(nxt.begin(), nxt.end());

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <deque>
+#include <mutex>
 #include <random>
 #include <thread>
 #include <vector>
@@ -96,17 +97,14 @@ bool make_match(const vgen_filter &flt, uint32_t format, const Scalar &batch_sta
 
 using namespace vg;
 
-extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
-                         void *user, volatile int32_t *stop, vgen_scan_result *out) {
-    if (!ctx || !pattern || !cfg || !out || cfg->struct_size != sizeof(vgen_scan_config)) return VGEN_E_INVALID;
-    memset(out, 0, sizeof *out);
-    if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
-    const auto t0 = std::chrono::steady_clock::now();
+namespace {
 
-    vgen_filter flt;
-    std::string err;
-    if (!filter_compile(pattern, cfg->case_insensitive != 0, cfg->format, flt, err))
-        return ctx->fail(VGEN_E_PATTERN, err);
+// One shard of a scan on one context.  `shared_found` (optional) is the match counter shared by the
+// shards of a multi-device scan; without it the shard counts its own matches.
+int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cfg, vgen_progress_cb cb, void *user,
+               volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
+               std::vector<vgen_generated> &matches, uint64_t &total_ops) {
+    if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
 
     const uint32_t N = ctx->batch;
     const uint32_t shards = cfg->n_shards > 1 ? cfg->n_shards : 1;
@@ -140,8 +138,13 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     if (shard) exhausted = scalar_add_u64(current, current, (uint64_t)shard * N) || !scalar_is_valid(current);
     const uint64_t stride = (uint64_t)shards * N;
 
-    std::vector<vgen_generated> matches;
-    uint64_t total_ops = 0, dispatched = 0;
+    uint64_t dispatched = 0;
+    total_ops = 0;
+    auto found = [&]() -> uint64_t { return shared_found ? shared_found->load(std::memory_order_relaxed) : matches.size(); };
+    auto push = [&](const vgen_generated &g) {
+        matches.push_back(g);
+        if (shared_found) shared_found->fetch_add(1, std::memory_order_relaxed);
+    };
     const uint64_t count = cfg->count;
     const uint32_t nf = ctx->frames;
     std::vector<Pending> pend(nf);
@@ -168,7 +171,7 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     };
 
     for (uint32_t i = 0; i < nf; i++) {
-        if (!can_dispatch() || stopped() || matches.size() >= count) break;
+        if (!can_dispatch() || stopped() || found() >= count) break;
         if ((status = dispatch(i)) != VGEN_OK) break;
         in_flight++;
     }
@@ -188,7 +191,7 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
         }
 
         bool dispatched_next = false;
-        if (!stopped() && matches.size() < count && can_dispatch()) {
+        if (!stopped() && found() < count && can_dispatch()) {
             if ((status = dispatch(frame)) != VGEN_OK) break;
             in_flight++;
             dispatched_next = true;
@@ -211,36 +214,112 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
             for (auto &x : th) x.join();
             for (auto &p : part)
                 for (auto &g : p)
-                    if (matches.size() < count) matches.push_back(g);
+                    if (found() < count) push(g);
         } else {
             if (n_found > recs.size()) {
                 status = ctx->fail(VGEN_E_STATE, "device match ring overflowed; raise match_cap or use a more selective pattern");
                 break;
             }
             vgen_generated g;
-            for (uint32_t i = 0; i < n_found && matches.size() < count; i++)
-                if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) matches.push_back(g);
+            for (uint32_t i = 0; i < n_found && found() < count; i++)
+                if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) push(g);
         }
 
         total_ops += N;                              // gpu.rs:1106
-        if (cb) cb(total_ops, user);
-        if (matches.size() >= count && !dispatched_next) break;   // gpu.rs:1111
+        if (cb) cb(shared_ops ? shared_ops->fetch_add(N) + N : total_ops, user);
+        if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
         frame = (frame + 1) % nf;
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
     for (uint32_t f = 0; f < nf; f++)
         if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
-    if (status != VGEN_OK) return status;
+    return status;
+}
 
+int finish_result(vgen_ctx *ctx, std::vector<vgen_generated> &matches, uint64_t ops, double secs, vgen_scan_result *out) {
     out->n_matches = matches.size();
-    out->operations = total_ops;
+    out->operations = ops;
+    out->elapsed_secs = secs;
     if (!matches.empty()) {
         out->matches = (vgen_generated *)malloc(matches.size() * sizeof(vgen_generated));
         if (!out->matches) return ctx->fail(VGEN_E_NOMEM, "out of memory");
         memcpy(out->matches, matches.data(), matches.size() * sizeof(vgen_generated));
     }
-    out->elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return VGEN_OK;
+}
+
+}  // namespace
+
+extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
+                         void *user, volatile int32_t *stop, vgen_scan_result *out) {
+    if (!ctx || !pattern || !cfg || !out || cfg->struct_size != sizeof(vgen_scan_config)) return VGEN_E_INVALID;
+    memset(out, 0, sizeof *out);
+    const auto t0 = std::chrono::steady_clock::now();
+    vgen_filter flt;
+    std::string err;
+    if (!filter_compile(pattern, cfg->case_insensitive != 0, cfg->format, flt, err))
+        return ctx->fail(VGEN_E_PATTERN, err);
+    std::vector<vgen_generated> matches;
+    uint64_t ops = 0;
+    int rc = scan_shard(ctx, flt, cfg, cb, user, stop, nullptr, nullptr, matches, ops);
+    if (rc != VGEN_OK) return rc;
+    return finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+}
+
+// Multi-device scan: one host thread per context, batches striped over the contexts (context i takes
+// global batches b = i mod n), a shared match counter and stop flag, results merged in ascending key
+// order and truncated to `count` (no collective, host-side aggregation only).
+extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *pattern, const vgen_scan_config *cfg,
+                               vgen_progress_cb cb, void *user, volatile int32_t *stop, vgen_scan_result *out) {
+    if (!ctxs || n_ctx == 0 || !pattern || !cfg || !out || cfg->struct_size != sizeof(vgen_scan_config)) return VGEN_E_INVALID;
+    for (uint32_t i = 0; i < n_ctx; i++)
+        if (!ctxs[i] || ctxs[i]->batch != ctxs[0]->batch) return VGEN_E_INVALID;
+    memset(out, 0, sizeof *out);
+    const auto t0 = std::chrono::steady_clock::now();
+    vgen_filter flt;
+    std::string err;
+    if (!filter_compile(pattern, cfg->case_insensitive != 0, cfg->format, flt, err))
+        return ctxs[0]->fail(VGEN_E_PATTERN, err);
+    vgen_scan_config base = *cfg;
+    if (!base.has_start) {   // all shards must walk the same base key
+        Scalar k;
+        if (base.seed) seed_key(base.seed, 0, k);
+        else random_valid_key(k);
+        scalar_to_be(k, base.start);
+        base.has_start = 1;
+    }
+    std::atomic<uint64_t> found{0}, ops_shared{0};
+    std::vector<std::vector<vgen_generated>> part(n_ctx);
+    std::vector<uint64_t> ops(n_ctx, 0);
+    std::vector<int> rcs(n_ctx, VGEN_OK);
+    std::vector<std::thread> th;
+    std::mutex cb_mu;
+    struct CbCtx { vgen_progress_cb cb; void *user; std::mutex *mu; } cbc{cb, user, &cb_mu};
+    auto locked_cb = [](uint64_t o, void *u) {
+        CbCtx *c = (CbCtx *)u;
+        std::lock_guard<std::mutex> g(*c->mu);
+        c->cb(o, c->user);
+    };
+    for (uint32_t i = 0; i < n_ctx; i++)
+        th.emplace_back([&, i]() {
+            vgen_scan_config c = base;
+            c.shard = i;
+            c.n_shards = n_ctx;
+            rcs[i] = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
+                                part[i], ops[i]);
+        });
+    for (auto &x : th) x.join();
+    for (uint32_t i = 0; i < n_ctx; i++)
+        if (rcs[i] != VGEN_OK) return rcs[i];
+    std::vector<vgen_generated> all;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_ctx; i++) {
+        all.insert(all.end(), part[i].begin(), part[i].end());
+        total += ops[i];
+    }
+    std::sort(all.begin(), all.end(), [](const vgen_generated &a, const vgen_generated &b) { return memcmp(a.key, b.key, 32) < 0; });
+    if (all.size() > cfg->count) all.resize((size_t)cfg->count);
+    return finish_result(ctxs[0], all, total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
 }
 
 extern "C" void vgen_scan_result_free(vgen_scan_result *r) {
