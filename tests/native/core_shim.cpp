@@ -195,3 +195,18 @@ int core_mul_windows_nz(const unsigned char *key_be, unsigned char *xy) {
     return 1;
 }
 }
+
+extern "C" {
+void core_fe_mul_add(const u32 *a, const u32 *b, const u32 *c, u32 *r, int square) {
+    fe x, y, z, w;
+    for (int i = 0; i < 9; i++) { x.n[i] = a[i]; y.n[i] = b[i]; z.n[i] = c[i]; }
+    if (square) fe_sqr_add(w, x, z); else fe_mul_add(w, x, y, z);
+    for (int i = 0; i < 9; i++) r[i] = w.n[i];
+}
+void core_fe_canonicalize(const u32 *a, u32 *r) {
+    fe x;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    fe_canonicalize(x);
+    for (int i = 0; i < 9; i++) r[i] = x.n[i];
+}
+}

@@ -127,3 +127,38 @@ def test_word_conversion_roundtrip(core):
         core.core_fe_words(A9(*limbs_of(v)), w, back)
         assert sum(int(x) << (32 * i) for i, x in enumerate(w)) == v
         assert list(back) == limbs_of(v)
+
+
+@pytest.mark.parametrize("ma,mb,mc", [(1, 1, 3), (1, 3, 2), (3, 1, 3), (2, 3, 3), (1, 1, 0)])
+def test_mul_add_and_sqr_add(core, ma, mb, mc):
+    rng = random.Random(ma * 100 + mb * 10 + mc)
+    styles = ["max", "min", "mixed", "rand"]
+    for sa in styles:
+        for sb in styles:
+            for sc in styles:
+                for _ in range(10 if "rand" in (sa, sb, sc) or "mixed" in (sa, sb, sc) else 1):
+                    a, b = rand_limbs(rng, ma, sa), rand_limbs(rng, mb, sb)
+                    c = rand_limbs(rng, mc, sc) if mc else [0] * 9
+                    r = A9()
+                    core.core_fe_mul_add(A9(*a), A9(*b), A9(*c), r, 0)
+                    check_mag1(list(r))
+                    assert val(r) % P == (val(a) * val(b) + val(c)) % P
+                    if ma == 1:
+                        core.core_fe_mul_add(A9(*a), A9(*a), A9(*c), r, 1)
+                        check_mag1(list(r))
+                        assert val(r) % P == (val(a) ** 2 + val(c)) % P
+
+
+def test_canonicalize_weakly_normalised_inputs(core):
+    rng = random.Random(321)
+    specials = [limbs_of(P), limbs_of(P - 1), limbs_of(P + 1), limbs_of(2**256 - 1), limbs_of(0), limbs_of(1),
+                limbs_of(2**256 - 2**32 - 978), [M29] * 8 + [1 << 24], [0] * 8 + [1 << 24], [M29] * 8 + [(1 << 24) - 1],
+                limbs_of(P)[:8] + [1 << 24], [5] + [0] * 7 + [(1 << 24) + 1], limbs_of(P + 2**32 + 976),
+                limbs_of(2**256 - 1)[:8] + [(1 << 24) + 1]]
+    cases = specials + [[rng.choice([0, 1, M29, M29 - 1, rng.randrange(M29 + 1)]) for _ in range(8)] +
+                        [rng.choice([0, 1 << 24, (1 << 24) - 1, (1 << 24) + 1, rng.randrange((1 << 24) + 2)])]
+                        for _ in range(3000)]
+    for a in cases:
+        r = A9()
+        core.core_fe_canonicalize(A9(*a), r)
+        assert list(r) == limbs_of(val(a) % P), a

@@ -142,6 +142,83 @@ VG_HD void fe_sqr(fe &r, const fe &a) {
     fe_fold_(r, e);
 }
 
+// r = a * b + c, c of magnitude <= 3: c's limbs join the low product digits before the fold, so the
+// sum costs nine 32-bit adds and no extra carry pass.  Result magnitude 1 (as fe_mul).
+VG_HD void fe_mul_add(fe &r, const fe &a, const fe &b, const fe &c3) {
+    u32 e[18];
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 9) c += (u64)a.n[i] * b.n[j];
+        }
+        e[k] = (u32)c & FE_M29;
+        c >>= 29;
+    }
+    e[17] = (u32)c;
+#pragma unroll
+    for (int k = 0; k < 9; k++) e[k] += c3.n[k];   // < 2^29 + 3*2^29 = 2^31: still a u32, fold takes 64-bit sums
+    fe_fold_(r, e);
+}
+
+// r = a^2 + c, c of magnitude <= 3 (see fe_mul_add); a of magnitude 1.
+VG_HD void fe_sqr_add(fe &r, const fe &a, const fe &c3) {
+    u32 e[18];
+    u32 d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 9 && i < j) c += (u64)d[i] * a.n[j];
+            if (j == i) c += (u64)a.n[i] * a.n[i];
+        }
+        e[k] = (u32)c & FE_M29;
+        c >>= 29;
+    }
+    e[17] = (u32)c;
+#pragma unroll
+    for (int k = 0; k < 9; k++) e[k] += c3.n[k];
+    fe_fold_(r, e);
+}
+
+// Canonical representative of a WEAKLY NORMALISED value (output of fe_mul / fe_sqr / fe_*_add /
+// fe_normalize_weak: limbs < 2^29, n[8] <= 2^24 + 1).  One carry pass computing both v = value with the
+// bits above 2^256 folded back and u = v + C (C = 2^32 + 977 = 2^256 - p); u reaching 2^256 means
+// v >= p and the answer is u - 2^256, otherwise it is v.
+VG_HD void fe_canonicalize(fe &r) {
+    const u32 ov = r.n[8] >> 24;                      // 0 or 1 (times 2^256)
+    u32 v[9], u[9];
+    u32 cv = r.n[0] + ov * 977u;                      // v = r - ov*2^256 + ov*C
+    u32 cu = cv + 977u;
+    v[0] = cv & FE_M29; cv >>= 29;
+    u[0] = cu & FE_M29; cu >>= 29;
+    cv += r.n[1] + ov * 8u;
+    cu += r.n[1] + ov * 8u + 8u;
+    v[1] = cv & FE_M29; cv >>= 29;
+    u[1] = cu & FE_M29; cu >>= 29;
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        cv += r.n[k];
+        cu += r.n[k];
+        v[k] = cv & FE_M29; cv >>= 29;
+        u[k] = cu & FE_M29; cu >>= 29;
+    }
+    const u32 top = r.n[8] & FE_M24;
+    cv += top;                                        // < 2^24 + 1: if the fold made v reach 2^256 ...
+    cu += top;                                        // ... then u did as well and u - 2^256 is the answer
+    v[8] = cv & FE_M24;
+    u[8] = cu & FE_M24;
+    const bool ge = (cu >> 24) != 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.n[k] = ge ? u[k] : v[k];
+}
+
 // Weak normalisation: any magnitude <= 7 in, magnitude 1 out (value unchanged mod p, < 2^256 + 2^233).
 VG_HD void fe_normalize_weak(fe &r) {
     u32 c = r.n[0];

@@ -21,6 +21,25 @@ VG_HD u32 bswap32(u32 x) {
     return (x >> 24) | ((x >> 8) & 0x0000FF00u) | ((x << 8) & 0x00FF0000u) | (x << 24);
 }
 
+// Three-input boolean functions.  On the device they are spelled as v_bitop3_b32 (one full-rate
+// instruction for ANY 3-input truth table on gfx950); hipcc finds the and/or/not forms by itself but
+// leaves x^y^z of rotates as two v_xor, so the xor3 of the sigma functions is made explicit.  The truth
+// table index is (a << 2 | b << 1 | c).  On the host the same functions are plain C.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VG_BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+#else
+VG_HD u32 vg_bitop3_host(u32 a, u32 b, u32 c, u32 tt) {
+    u32 r = 0;
+    for (int i = 0; i < 8; i++)
+        if ((tt >> i) & 1) r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);
+    return r;
+}
+#define VG_BITOP3(a, b, c, tt) vg_bitop3_host((a), (b), (c), (tt))
+#endif
+#define VG_XOR3(a, b, c) VG_BITOP3(a, b, c, 0x96)
+#define VG_CH(e, f, g) VG_BITOP3(e, f, g, 0xCA)     // (e & f) ^ (~e & g)
+#define VG_MAJ(a, b, c) VG_BITOP3(a, b, c, 0xE8)    // majority
+
 // ---- SHA-256 ---------------------------------------------------------------------------------
 
 constexpr u32 SHA256_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
@@ -28,13 +47,13 @@ constexpr u32 SHA256_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
 
 #define VG_SHA_ROUND(a, b, c, d, e, f, g, h, k, w)                                    \
     {                                                                                 \
-        u32 t1_ = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + (k) + (w); \
-        u32 t2_ = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));        \
+        u32 t1_ = h + VG_XOR3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + VG_CH(e, f, g) + (k) + (w); \
+        u32 t2_ = VG_XOR3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + VG_MAJ(a, b, c);                 \
         d += t1_;                                                                     \
         h = t1_ + t2_;                                                                \
     }
-#define VG_SHA_S0(x) (rotr32(x, 7) ^ rotr32(x, 18) ^ ((x) >> 3))
-#define VG_SHA_S1(x) (rotr32(x, 17) ^ rotr32(x, 19) ^ ((x) >> 10))
+#define VG_SHA_S0(x) VG_XOR3(rotr32(x, 7), rotr32(x, 18), ((x) >> 3))
+#define VG_SHA_S1(x) VG_XOR3(rotr32(x, 17), rotr32(x, 19), ((x) >> 10))
 #define VG_SHA_SCHED(i) (w[(i) & 15] += VG_SHA_S1(w[((i) - 2) & 15]) + w[((i) - 7) & 15] + VG_SHA_S0(w[((i) - 15) & 15]))
 
 #define VG_SHA_8ROUNDS(base, W)                                            \
@@ -134,11 +153,11 @@ VG_HD void sha256_script22(const u32 h[5], u32 out[8]) {
 
 // ---- RIPEMD-160 --------------------------------------------------------------------------------
 
-#define VG_RMD_F1(x, y, z) ((x) ^ (y) ^ (z))
-#define VG_RMD_F2(x, y, z) (((x) & (y)) | (~(x) & (z)))
-#define VG_RMD_F3(x, y, z) (((x) | ~(y)) ^ (z))
-#define VG_RMD_F4(x, y, z) (((x) & (z)) | ((y) & ~(z)))
-#define VG_RMD_F5(x, y, z) ((x) ^ ((y) | ~(z)))
+#define VG_RMD_F1(x, y, z) VG_XOR3(x, y, z)
+#define VG_RMD_F2(x, y, z) VG_BITOP3(x, y, z, 0xCA)   // (x & y) | (~x & z)
+#define VG_RMD_F3(x, y, z) VG_BITOP3(x, y, z, 0x59)   // (x | ~y) ^ z
+#define VG_RMD_F4(x, y, z) VG_BITOP3(x, y, z, 0xE4)   // (x & z) | (y & ~z)
+#define VG_RMD_F5(x, y, z) VG_BITOP3(x, y, z, 0x2D)   // x ^ (y | ~z)
 #define VG_RMD_STEP(F, a, b, c, d, e, x, k, s)  \
     {                                           \
         a += F(b, c, d) + (x) + (k);            \

@@ -224,6 +224,12 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
         } else {
             idx = inv;
         }
+        fe nsum, nqy;   // -(R.x + Q.x) (magnitude 3) and -Q.y, shared by the +R and -R results
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            nsum.n[i] = nrx.n[i] + q.nqx[i];
+            nqy.n[i] = q.nqy[i];
+        }
 #pragma unroll 1
         for (int sgn = 0; sgn < 2; sgn++) {
             // +R: dy = R.y - Q.y ; -R: dy = -R.y - Q.y
@@ -231,17 +237,13 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
 #pragma unroll
             for (int i = 0; i < 9; i++) dy.n[i] = (sgn ? nry.n[i] : ry.n[i]) + q.nqy[i];   // magnitude <= 3
             fe_mul(lam, dy, idx);
-            fe_sqr(x3, lam);
-#pragma unroll
-            for (int i = 0; i < 9; i++) x3.n[i] += nrx.n[i] + q.nqx[i];                    // magnitude 4
-            fe_normalize(x3);
+            fe_sqr_add(x3, lam, nsum);            // lam^2 - R.x - Q.x, weakly normalised
+            fe_canonicalize(x3);
             fe_neg(t, x3, 1);
 #pragma unroll
             for (int i = 0; i < 9; i++) t.n[i] += q.qx[i];                                  // magnitude 3
-            fe_mul(y3, lam, t);
-#pragma unroll
-            for (int i = 0; i < 9; i++) y3.n[i] += q.nqy[i];                                // magnitude 2
-            fe_normalize(y3);
+            fe_mul_add(y3, lam, t, nqy);          // lam*(Q.x - x3) - Q.y
+            fe_canonicalize(y3);
 
             u32 xw[8], pl[5];
             fe_to_words(x3, xw);
@@ -362,8 +364,8 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
     fe_mul(zi3, zi2, zi);
     fe_mul(x, acc.x, zi2);
     fe_mul(y, acc.y, zi3);
-    fe_normalize(x);
-    fe_normalize(y);
+    fe_canonicalize(x);
+    fe_canonicalize(y);
 
     u32 xw[8], pl[5];
     fe_to_words(x, xw);
