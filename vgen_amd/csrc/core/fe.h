@@ -102,9 +102,20 @@ VG_HD void fe_fold_(fe &r, const u32 *e) {
     r.n[8] = n8 + cc;                 // <= 2^24
 }
 
-// r = a * b.  Requires m_a * m_b <= 6.  Result magnitude 1.
-VG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
-    u32 e[18];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VG_FE_NO_ASM)
+#include "fe_gfx950_asm.inc"
+#define VG_FE_ASM 1
+#endif
+
+// e[0..16]: 29-bit digits of a*b (column sums chained through their carries), e[17]: the rest.
+VG_HD void fe_product_digits_(u32 *e, const fe &a, const fe &b) {
+#ifdef VG_FE_ASM
+    u64 t[17];
+    fe_mul_cols_asm(a.n, b.n, t);
+#pragma unroll
+    for (int k = 0; k < 17; k++) e[k] = (u32)t[k] & FE_M29;
+    e[17] = (u32)(t[16] >> 29);
+#else
     u64 c = 0;
 #pragma unroll
     for (int k = 0; k < 17; k++) {
@@ -117,15 +128,21 @@ VG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
         c >>= 29;
     }
     e[17] = (u32)c;
-    fe_fold_(r, e);
+#endif
 }
 
-// r = a^2.  Requires m_a <= 1 (the doubled cross terms use 2*a_i).  Result magnitude 1.
-VG_HD void fe_sqr(fe &r, const fe &a) {
-    u32 e[18];
+// the same for a^2 (a of magnitude 1): cross terms once, with doubled limbs
+VG_HD void fe_square_digits_(u32 *e, const fe &a) {
     u32 d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
+#ifdef VG_FE_ASM
+    u64 t[17];
+    fe_sqr_cols_asm(a.n, d, t);
+#pragma unroll
+    for (int k = 0; k < 17; k++) e[k] = (u32)t[k] & FE_M29;
+    e[17] = (u32)(t[16] >> 29);
+#else
     u64 c = 0;
 #pragma unroll
     for (int k = 0; k < 17; k++) {
@@ -139,6 +156,20 @@ VG_HD void fe_sqr(fe &r, const fe &a) {
         c >>= 29;
     }
     e[17] = (u32)c;
+#endif
+}
+
+// r = a * b.  Requires m_a * m_b <= 6.  Result magnitude 1.
+VG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
+    u32 e[18];
+    fe_product_digits_(e, a, b);
+    fe_fold_(r, e);
+}
+
+// r = a^2.  Requires m_a <= 1 (the doubled cross terms use 2*a_i).  Result magnitude 1.
+VG_HD void fe_sqr(fe &r, const fe &a) {
+    u32 e[18];
+    fe_square_digits_(e, a);
     fe_fold_(r, e);
 }
 
@@ -146,42 +177,16 @@ VG_HD void fe_sqr(fe &r, const fe &a) {
 // sum costs nine 32-bit adds and no extra carry pass.  Result magnitude 1 (as fe_mul).
 VG_HD void fe_mul_add(fe &r, const fe &a, const fe &b, const fe &c3) {
     u32 e[18];
-    u64 c = 0;
+    fe_product_digits_(e, a, b);
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const int j = k - i;
-            if (j >= 0 && j < 9) c += (u64)a.n[i] * b.n[j];
-        }
-        e[k] = (u32)c & FE_M29;
-        c >>= 29;
-    }
-    e[17] = (u32)c;
-#pragma unroll
-    for (int k = 0; k < 9; k++) e[k] += c3.n[k];   // < 2^29 + 3*2^29 = 2^31: still a u32, fold takes 64-bit sums
+    for (int k = 0; k < 9; k++) e[k] += c3.n[k];   // < 2^29 + 3*2^29 = 2^31: still a u32, the fold takes 64-bit sums
     fe_fold_(r, e);
 }
 
 // r = a^2 + c, c of magnitude <= 3 (see fe_mul_add); a of magnitude 1.
 VG_HD void fe_sqr_add(fe &r, const fe &a, const fe &c3) {
     u32 e[18];
-    u32 d[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
-    u64 c = 0;
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const int j = k - i;
-            if (j >= 0 && j < 9 && i < j) c += (u64)d[i] * a.n[j];
-            if (j == i) c += (u64)a.n[i] * a.n[i];
-        }
-        e[k] = (u32)c & FE_M29;
-        c >>= 29;
-    }
-    e[17] = (u32)c;
+    fe_square_digits_(e, a);
 #pragma unroll
     for (int k = 0; k < 9; k++) e[k] += c3.n[k];
     fe_fold_(r, e);
