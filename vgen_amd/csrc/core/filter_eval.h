@@ -90,7 +90,20 @@ VG_HD bool filter_eval(const DevFilter *f, const u32 payload[5]) {
     }
     if (!need_chk) return any_data;
     if (!any_data) return false;         // the (expensive) checksum only for data-part survivors
-    chk = bech32_checksum_bc20(H, f->witver);
+    if (f->chk_lut) {
+        // the checksum is affine in the payload: 20 table lookups instead of 44 polymod steps
+        const u32 *lut = f->chk_lut;
+        chk = f->chk_base;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            chk ^= lut[(4 * i + 0) * 256 + (H[i] >> 24)];
+            chk ^= lut[(4 * i + 1) * 256 + ((H[i] >> 16) & 255u)];
+            chk ^= lut[(4 * i + 2) * 256 + ((H[i] >> 8) & 255u)];
+            chk ^= lut[(4 * i + 3) * 256 + (H[i] & 255u)];
+        }
+    } else {
+        chk = bech32_checksum_bc20(H, f->witver);
+    }
     for (u32 t = 0; t < n; t++) {
         const DevFilterTest &T = f->tests[t];
         u32 diff = (chk & T.chk_mask) ^ T.chk_value;

@@ -262,6 +262,14 @@ VG_HD void ripemd160_of_sha(const u32 sha[8], u32 out[5]) {
 
 VG_HD u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
 
+// 3-input boolean on 64-bit lanes = the 32-bit v_bitop3 on each half
+template <u32 TT>
+VG_HD u64 bitop3_64(u64 a, u64 b, u64 c) {
+    const u32 lo = VG_BITOP3((u32)a, (u32)b, (u32)c, TT);
+    const u32 hi = VG_BITOP3((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), TT);
+    return ((u64)hi << 32) | lo;
+}
+
 VG_HD void keccak_f1600(u64 a[25]) {
     constexpr u64 RC[24] = {
         0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
@@ -272,26 +280,39 @@ VG_HD void keccak_f1600(u64 a[25]) {
         0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 #pragma unroll 1
     for (int round = 0; round < 24; round++) {
-        u64 c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
-        u64 c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
-        u64 c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
-        u64 c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
-        u64 c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
-        u64 d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1);
-        u64 d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+        // theta: column parities as two xor3 each; the "a ^ d" of every lane is one more xor3
+        // (d_x = c_{x-1} ^ rotl(c_{x+1}, 1) is never materialised)
+        const u64 c0 = bitop3_64<0x96>(bitop3_64<0x96>(a[0], a[5], a[10]), a[15], a[20]);
+        const u64 c1 = bitop3_64<0x96>(bitop3_64<0x96>(a[1], a[6], a[11]), a[16], a[21]);
+        const u64 c2 = bitop3_64<0x96>(bitop3_64<0x96>(a[2], a[7], a[12]), a[17], a[22]);
+        const u64 c3 = bitop3_64<0x96>(bitop3_64<0x96>(a[3], a[8], a[13]), a[18], a[23]);
+        const u64 c4 = bitop3_64<0x96>(bitop3_64<0x96>(a[4], a[9], a[14]), a[19], a[24]);
+        const u64 r0 = rotl64(c0, 1), r1 = rotl64(c1, 1), r2 = rotl64(c2, 1), r3 = rotl64(c3, 1), r4 = rotl64(c4, 1);
+#define VG_TH0(x) bitop3_64<0x96>(x, c4, r1)
+#define VG_TH1(x) bitop3_64<0x96>(x, c0, r2)
+#define VG_TH2(x) bitop3_64<0x96>(x, c1, r3)
+#define VG_TH3(x) bitop3_64<0x96>(x, c2, r4)
+#define VG_TH4(x) bitop3_64<0x96>(x, c3, r0)
         // theta + rho + pi into b
-        u64 b0 = a[0] ^ d0;
-        u64 b10 = rotl64(a[1] ^ d1, 1), b20 = rotl64(a[2] ^ d2, 62), b5 = rotl64(a[3] ^ d3, 28), b15 = rotl64(a[4] ^ d4, 27);
-        u64 b16 = rotl64(a[5] ^ d0, 36), b1 = rotl64(a[6] ^ d1, 44), b11 = rotl64(a[7] ^ d2, 6), b21 = rotl64(a[8] ^ d3, 55), b6 = rotl64(a[9] ^ d4, 20);
-        u64 b7 = rotl64(a[10] ^ d0, 3), b17 = rotl64(a[11] ^ d1, 10), b2 = rotl64(a[12] ^ d2, 43), b12 = rotl64(a[13] ^ d3, 25), b22 = rotl64(a[14] ^ d4, 39);
-        u64 b23 = rotl64(a[15] ^ d0, 41), b8 = rotl64(a[16] ^ d1, 45), b18 = rotl64(a[17] ^ d2, 15), b3 = rotl64(a[18] ^ d3, 21), b13 = rotl64(a[19] ^ d4, 8);
-        u64 b14 = rotl64(a[20] ^ d0, 18), b24 = rotl64(a[21] ^ d1, 2), b9 = rotl64(a[22] ^ d2, 61), b19 = rotl64(a[23] ^ d3, 56), b4 = rotl64(a[24] ^ d4, 14);
-        // chi
-        a[0] = b0 ^ (~b1 & b2) ^ RC[round]; a[1] = b1 ^ (~b2 & b3); a[2] = b2 ^ (~b3 & b4); a[3] = b3 ^ (~b4 & b0); a[4] = b4 ^ (~b0 & b1);
-        a[5] = b5 ^ (~b6 & b7); a[6] = b6 ^ (~b7 & b8); a[7] = b7 ^ (~b8 & b9); a[8] = b8 ^ (~b9 & b5); a[9] = b9 ^ (~b5 & b6);
-        a[10] = b10 ^ (~b11 & b12); a[11] = b11 ^ (~b12 & b13); a[12] = b12 ^ (~b13 & b14); a[13] = b13 ^ (~b14 & b10); a[14] = b14 ^ (~b10 & b11);
-        a[15] = b15 ^ (~b16 & b17); a[16] = b16 ^ (~b17 & b18); a[17] = b17 ^ (~b18 & b19); a[18] = b18 ^ (~b19 & b15); a[19] = b19 ^ (~b15 & b16);
-        a[20] = b20 ^ (~b21 & b22); a[21] = b21 ^ (~b22 & b23); a[22] = b22 ^ (~b23 & b24); a[23] = b23 ^ (~b24 & b20); a[24] = b24 ^ (~b20 & b21);
+        u64 b0 = VG_TH0(a[0]);
+        u64 b10 = rotl64(VG_TH1(a[1]), 1), b20 = rotl64(VG_TH2(a[2]), 62), b5 = rotl64(VG_TH3(a[3]), 28), b15 = rotl64(VG_TH4(a[4]), 27);
+        u64 b16 = rotl64(VG_TH0(a[5]), 36), b1 = rotl64(VG_TH1(a[6]), 44), b11 = rotl64(VG_TH2(a[7]), 6), b21 = rotl64(VG_TH3(a[8]), 55), b6 = rotl64(VG_TH4(a[9]), 20);
+        u64 b7 = rotl64(VG_TH0(a[10]), 3), b17 = rotl64(VG_TH1(a[11]), 10), b2 = rotl64(VG_TH2(a[12]), 43), b12 = rotl64(VG_TH3(a[13]), 25), b22 = rotl64(VG_TH4(a[14]), 39);
+        u64 b23 = rotl64(VG_TH0(a[15]), 41), b8 = rotl64(VG_TH1(a[16]), 45), b18 = rotl64(VG_TH2(a[17]), 15), b3 = rotl64(VG_TH3(a[18]), 21), b13 = rotl64(VG_TH4(a[19]), 8);
+        u64 b14 = rotl64(VG_TH0(a[20]), 18), b24 = rotl64(VG_TH1(a[21]), 2), b9 = rotl64(VG_TH2(a[22]), 61), b19 = rotl64(VG_TH3(a[23]), 56), b4 = rotl64(VG_TH4(a[24]), 14);
+#undef VG_TH0
+#undef VG_TH1
+#undef VG_TH2
+#undef VG_TH3
+#undef VG_TH4
+        // chi: x ^ (~y & z) is the 3-input truth table 0xD2
+#define VG_CHI(x, y, z) bitop3_64<0xD2>(x, y, z)
+        a[0] = VG_CHI(b0, b1, b2) ^ RC[round]; a[1] = VG_CHI(b1, b2, b3); a[2] = VG_CHI(b2, b3, b4); a[3] = VG_CHI(b3, b4, b0); a[4] = VG_CHI(b4, b0, b1);
+        a[5] = VG_CHI(b5, b6, b7); a[6] = VG_CHI(b6, b7, b8); a[7] = VG_CHI(b7, b8, b9); a[8] = VG_CHI(b8, b9, b5); a[9] = VG_CHI(b9, b5, b6);
+        a[10] = VG_CHI(b10, b11, b12); a[11] = VG_CHI(b11, b12, b13); a[12] = VG_CHI(b12, b13, b14); a[13] = VG_CHI(b13, b14, b10); a[14] = VG_CHI(b14, b10, b11);
+        a[15] = VG_CHI(b15, b16, b17); a[16] = VG_CHI(b16, b17, b18); a[17] = VG_CHI(b17, b18, b19); a[18] = VG_CHI(b18, b19, b15); a[19] = VG_CHI(b19, b15, b16);
+        a[20] = VG_CHI(b20, b21, b22); a[21] = VG_CHI(b21, b22, b23); a[22] = VG_CHI(b22, b23, b24); a[23] = VG_CHI(b23, b24, b20); a[24] = VG_CHI(b24, b20, b21);
+#undef VG_CHI
     }
 }
 

@@ -39,6 +39,12 @@ struct DevFilter {
     uint32_t count;
     uint32_t flags;
     uint32_t witver;     // bech32: witness version symbol (0 for P2WPKH)
+    // Bech32 checksum as an affine map of the payload bytes: chk = chk_base ^ XOR_i chk_lut[i*256 + byte_i]
+    // (20 x 256 words).  Device pointer in the device copy, host pointer in the host copy; nullptr = use
+    // the step-by-step polymod.
+    const uint32_t *chk_lut;
+    uint32_t chk_base;
+    uint32_t pad;
     DevFilterTest tests[DEVF_MAX_TESTS];
 };
 

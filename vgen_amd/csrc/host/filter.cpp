@@ -1,6 +1,8 @@
 // filter.cpp — see filter.h.
 #include "filter.h"
 
+#include "../core/filter_eval.h"
+
 #include <string.h>
 
 #include <algorithm>
@@ -454,6 +456,20 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
         const SymSpec sp = {"bc1q", BECH32, 5, 32, 6};
         derive_symbols(out.dfa, sp, out.dev, out.selectivity);
         out.dev.witver = 0;
+        if (out.dev.flags & DEVF_FLAG_BECH32_CHK) {
+            // chk(H) = chk(0) ^ XOR_i (chk(only byte i set to b) ^ chk(0)): the polymod is linear over GF(2)
+            const u32 zero[5] = {0, 0, 0, 0, 0};
+            const u32 base = bech32_checksum_bc20(zero, 0);
+            out.chk_lut.assign(20 * 256, 0);
+            for (int i = 0; i < 20; i++)
+                for (u32 b = 0; b < 256; b++) {
+                    u32 H[5] = {0, 0, 0, 0, 0};
+                    H[i / 4] = b << (24 - 8 * (i % 4));
+                    out.chk_lut[(size_t)i * 256 + b] = bech32_checksum_bc20(H, 0) ^ base;
+                }
+            out.dev.chk_base = base;
+            out.dev.chk_lut = out.chk_lut.data();   // host pointer; the runtime swaps in the device copy
+        }
         break;
     }
     case VGF_ETHEREUM: {

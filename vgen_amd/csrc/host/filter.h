@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../device/device_types.h"
 #include "regex_dfa.h"
@@ -24,6 +25,7 @@ struct vgen_filter {
     vg::Dfa dfa;            // decides Pattern::matches exactly
     vg::DevFilter dev{};    // device prefilter (superset)
     double selectivity = 1.0;   // estimated fraction of keys the device reports
+    std::vector<uint32_t> chk_lut;   // Bech32 checksum tables (20 x 256) when the prefilter tests the checksum
 };
 
 namespace vg {

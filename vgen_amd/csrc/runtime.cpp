@@ -139,6 +139,7 @@ void rt_destroy(vgen_ctx *c) {
     }
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
+    if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
     if (c->d_filter) (void)hipFree(c->d_filter);
     delete c;
 }
@@ -153,6 +154,11 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
     }
     if (f->format != c->format) return c->fail(VGEN_E_INVALID, "filter was compiled for another address format");
     c->h_filter = f->dev;
+    if (f->dev.chk_lut) {   // Bech32 checksum tables: upload and point the device copy at them
+        if (!c->d_chk_lut) HIP_TRY(c, hipMalloc((void **)&c->d_chk_lut, 20 * 256 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_chk_lut, f->chk_lut.data(), 20 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->h_filter.chk_lut = c->d_chk_lut;
+    }
     HIP_TRY(c, hipMemcpy(c->d_filter, &c->h_filter, sizeof(DevFilter), hipMemcpyHostToDevice));
     c->have_filter = true;
     return VGEN_OK;
