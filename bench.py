@@ -188,6 +188,23 @@ def main():
                              "launches of different frames overlap on the device (each then runs longer), so chip_* "
                              "gives the same ratio from whole-run wall time over all kernels"},
     }
+    if rank == 0 and world == 1:
+        # time-to-first-match (the second half of BASELINE.json's metric): a `generate -c 1` style scan
+        # through the scanner (vgen_scan), warm = existing context, cold = including context creation
+        # (offset-table build + allocations; the HIP runtime itself is already initialised here)
+        t1 = time.perf_counter()
+        res = vg.scan_gpu_with_runner(args.pattern, vg.ScanConfig(format=fmt, count=1, seed=43,
+                                                                  case_insensitive=args.ci), runner)
+        warm = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        r2 = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=args.frames)
+        res2 = vg.scan_gpu_with_runner(args.pattern, vg.ScanConfig(format=fmt, count=1, seed=44,
+                                                                   case_insensitive=args.ci), r2)
+        cold = time.perf_counter() - t1
+        r2.close()
+        out["time_to_first_match"] = {"warm_s": round(warm, 5), "cold_s": round(cold, 5),
+                                      "keys_scanned_warm": res.operations, "keys_scanned_cold": res2.operations,
+                                      "found": bool(res.matches) and bool(res2.matches)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.format, args.pattern, args.ci)
     runner.close()

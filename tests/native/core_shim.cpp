@@ -210,3 +210,30 @@ void core_fe_canonicalize(const u32 *a, u32 *r) {
     for (int i = 0; i < 9; i++) r[i] = x.n[i];
 }
 }
+
+#include "../../vgen_amd/csrc/core/dfa_eval.h"
+
+extern "C" {
+// Runs the DEVICE full-match algorithm (dfa_match_payload, the code the kernel runs) and the exact DFA on
+// the host-encoded address for every payload.  out_flags: bit0 device-dfa result, bit1 exact result.
+// returns the device kind the filter compiler chose, or -1 on pattern error.
+int core_dfa_check(const char *pattern, int ci, unsigned format, const unsigned char *payloads, int n,
+                   unsigned char *out_flags) {
+    vgen_filter f;
+    std::string err;
+    if (!filter_compile(pattern, ci != 0, format, f, err)) return -1;
+    if (f.dev.kind != DEVF_DFA) return (int)f.dev.kind;
+    for (int i = 0; i < n; i++) {
+        u32 pl[5];
+        for (int w = 0; w < 5; w++) {
+            const unsigned char *p = payloads + 20 * i + 4 * w;
+            pl[w] = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+        }
+        int dev = dfa_match_payload(f.dfa_blob.data(), (int)format, pl) ? 1 : 0;
+        std::string addr = address_from_payload(format, payloads + 20 * i);
+        int exact = f.dfa.is_match(addr) ? 1 : 0;
+        out_flags[i] = (unsigned char)(dev | (exact << 1));
+    }
+    return (int)DEVF_DFA;
+}
+}

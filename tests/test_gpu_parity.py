@@ -288,3 +288,54 @@ def test_cli_generate_and_range(vg, vo, tmp_path):
     assert out.stdout.strip() == vo.wif(target)
     out = subprocess.run([exe, "generate", "-p", "^1Cat", "--no-gpu"], capture_output=True, text=True)
     assert out.returncode != 0 and "no CPU" in out.stderr
+
+
+DFA_CASES = [
+    (0, "Cat", False), (0, "1[Oo]ri", False), (0, "abc$", False), (0, "(?i)dead", False), (0, "[0-9]{5}$", False),
+    (2, "Cat", False), (2, "xyz$", False), (4, "AAA", False),
+    (1, "dead", False), (1, "q{4}", False), (5, "dead", False), (5, "[0-9]{7}", True), (5, "Ab.*Cd", False),
+]
+
+
+@pytest.mark.parametrize("fmt,pattern,ci", DFA_CASES, ids=lambda x: str(x))
+def test_full_device_match_equals_dfa_over_dump(vg, vo, fmt, pattern, ci):
+    """Patterns without a cheap prefilter are matched in full on the device (address encoded and walked
+    through the DFA, core/dfa_eval.h).  Same contract as the prefilter: never misses, exact for
+    Base58/Bech32, case-folded superset for Ethereum; the confirmed set equals the oracle's."""
+    batch = 1 << 17
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), match_cap=65536)
+    start = vo.seed_key(4242, fmt)
+    blob = dump(r, start)
+    oracle_re = vo.Regex(pattern, ci)
+    addrs = [vo.address_from_hash160(fmt, blob[20 * i:20 * i + 20]) for i in range(batch)]
+    expect = [i for i in range(batch) if oracle_re.matches(addrs[i])]
+    p = vg.Pattern(pattern, ci, vg.AddressFormat(fmt))
+    assert p.device_kind == 4
+    r.set_filter(p)
+    r.dispatch(start, 0)
+    recs, n_found, _ = r.await_result(0)
+    assert n_found <= r.match_cap
+    confirmed = [i for i, payload in recs if p.matches(vg.address_from_payload(fmt, payload))]
+    assert confirmed == expect
+    if fmt != 5:
+        assert [i for i, _ in recs] == expect        # exact on the device for Base58 / Bech32
+    r.close()
+
+
+def test_scan_with_unanchored_pattern_and_ring_overflow_fallback(vg, vo):
+    # the reference's own example pattern "1[Oo]ri" (pattern.rs:304) is unanchored
+    r = vg.GpuRunner(batch_size=1 << 18, fmt=vg.AddressFormat.P2pkh)
+    res = vg.scan_gpu_with_runner("1[Oo]ri", vg.ScanConfig(count=3, seed=7), r)
+    assert len(res.matches) == 3
+    for m in res.matches:
+        assert re.search("1[Oo]ri", m.address) and vo.generate(0, int(m.hex, 16))["address"] == m.address
+    # a permissive full-match pattern overflows the candidate ring: the scan falls back to host filtering
+    # of full dumps without losing or duplicating matches
+    r2 = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, match_cap=256, frames=3)
+    cfg = vg.ScanConfig(count=10**9, start=0x5000, end=0x5000 + 6 * 8192 - 1)
+    res = vg.scan_gpu_with_runner("[A-Z]{2}", cfg, r2)
+    ref = vo.scan_range(0, "[A-Z]{2}", 0x5000, 0x5000 + 6 * 8192 - 1, count=10**9)
+    assert [m.hex for m in res.matches] == [x["hex"] for x in ref["matches"]]
+    assert res.operations == 6 * 8192
+    r.close()
+    r2.close()

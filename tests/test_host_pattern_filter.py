@@ -122,11 +122,11 @@ def test_prefilter_is_a_tight_superset_for_prefixes_and_suffixes(core, fmt):
         assert sum(dev) <= 3 * sum(exact) + 12, (pat, sum(dev), sum(exact))
 
 
-def test_unanchored_and_base58_suffix_patterns_fall_back_to_host_filtering(core):
+def test_unanchored_and_base58_suffix_patterns_use_the_device_dfa(core):
     payloads = [bytes(20)]
     for pat, fmt in [("Cat", 0), ("abc$", 0), ("dead", 1), ("[0-9]{6}", 5)]:
         kind, sel, dev, exact = check(core, pat, False, fmt, payloads)
-        assert kind == 0 or all(dev), (pat, kind)     # never a device filter that could drop matches
+        assert kind == 4 and all(dev), (pat, kind)    # full on-device match; the prefilter stage passes everything
     for pat, fmt in [(".", 0), ("^1", 0), ("^bc1q", 1), ("^0x", 5), ("^3", 2)]:
         kind, sel, dev, exact = check(core, pat, False, fmt, payloads)
         assert kind == 3 and all(dev) and all(exact)
@@ -146,3 +146,47 @@ def test_suffix_prefilter_uses_the_whole_literal(core):
     assert kind == 2 and abs(sel - 32.0 ** -4) < 1e-9
     kind, sel, _, _ = check(core, "(aa|zz)$", False, 1, payloads)
     assert kind == 2 and abs(sel - 2 * 32.0 ** -2) < 1e-9
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2, 4, 5])
+def test_device_full_match_algorithm_equals_exact_dfa(core, fmt):
+    """DEVF_DFA: the on-device encode + DFA walk (core/dfa_eval.h, run here on the host) decides exactly what
+    the DFA decides on the encoded address — Base58Check incl. checksum digits and leading '1's, Bech32 incl.
+    checksum symbols; for Ethereum it is the case-folded language (a superset of the exact one)."""
+    core.core_dfa_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_char_p, ctypes.c_int,
+                                    ctypes.c_char_p]
+    rng = random.Random(500 + fmt)
+    payloads = [bytes(rng.randrange(256) for _ in range(20)) for _ in range(1500)]
+    payloads += [bytes(k) + bytes(rng.randrange(256) for _ in range(20 - k)) for k in (1, 2, 3, 7, 19) for _ in range(20)]
+    payloads += [bytes(20), bytes([255] * 20), bytes(19) + b"\x01"]
+    addrs = [address(core, fmt, p) for p in payloads]
+    pats = {0: ["Cat", "1[Oo]ri", "abc$", "[0-9]{4}$", "AA.*zz", "^1.*7$", "(?i)dead", "11"],
+            4: ["Cat", "xyz$", "1111"],
+            2: ["Cat", "abc$", "^3.*9$", "(?i)beef"],
+            1: ["dead", "[0-9]{5}", "q{3}", "xyz.*acd", "de.*ad"],
+            5: ["dead", "[0-9]{6}", "00.*ff", "(?i)BEEF.*f$", "Aa"]}[fmt]
+    # patterns built from real addresses so that matches exist
+    for a in rng.sample(addrs, 6):
+        mid = len(a) // 2
+        pats.append(re.escape(a[mid:mid + 3]))
+        pats.append(re.escape(a[-3:]) + "$")
+    blob = b"".join(payloads)
+    n_dfa = 0
+    for pat in pats:
+        flags = ctypes.create_string_buffer(len(payloads))
+        kind = core.core_dfa_check(pat.encode(), 0, fmt, blob, len(payloads), flags)
+        if kind != 4:      # the pattern has a cheap prefilter (suffix masks on Bech32 / hex): covered elsewhere
+            assert kind in (1, 2, 3), (pat, kind)
+            continue
+        n_dfa += 1
+        dev = [b & 1 for b in flags.raw]
+        exact = [(b >> 1) & 1 for b in flags.raw]
+        oracle = vo.Regex(pat, False)
+        assert exact == [int(oracle.matches(a)) for a in addrs], pat
+        if fmt == 5:
+            folded = re.compile(pat, re.I)
+            assert dev == [int(folded.search(a) is not None) for a in addrs], pat
+            assert all(d or not e for d, e in zip(dev, exact))
+        else:
+            assert dev == exact, (pat, [a for a, d, e in zip(addrs, dev, exact) if d != e][:3])
+    assert n_dfa >= 5

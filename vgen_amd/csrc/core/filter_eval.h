@@ -64,7 +64,7 @@ VG_HD u32 bech32_checksum_bc20(const u32 H[5], u32 witver) {
 // payload: five words in memory order (little-endian words of the 20-byte string).
 VG_HD bool filter_eval(const DevFilter *f, const u32 payload[5]) {
     const u32 kind = f->kind;
-    if (kind == DEVF_ALL || kind == DEVF_HOST_ALL) return true;
+    if (kind == DEVF_ALL || kind == DEVF_HOST_ALL || kind == DEVF_DFA) return true;   // DFA: see dfa_eval.h
     u32 H[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) H[i] = bswap32(payload[i]);

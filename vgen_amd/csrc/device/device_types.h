@@ -21,7 +21,8 @@ enum : uint32_t {
     DEVF_HOST_ALL = 0,   // no usable prefilter: every key is a candidate (dump + host filter)
     DEVF_RANGES = 1,     // any r:  lo_r <= H <= hi_r           (Base58 prefixes)
     DEVF_MASKED = 2,     // any t:  (H & mask_t) == value_t     (Bech32 / hex prefixes & suffixes)
-    DEVF_ALL = 3         // pattern accepts every address
+    DEVF_ALL = 3,        // pattern accepts every address
+    DEVF_DFA = 4         // full match on the device: encode the address, walk the DFA (core/dfa_eval.h)
 };
 
 constexpr uint32_t DEVF_MAX_TESTS = 64;
@@ -44,7 +45,9 @@ struct DevFilter {
     // the step-by-step polymod.
     const uint32_t *chk_lut;
     uint32_t chk_base;
-    uint32_t pad;
+    uint32_t dfa_bytes;  // DEVF_DFA: size of the DFA blob (<= 48 KiB, staged in LDS by the kernel)
+    // DEVF_DFA: the blob (layout in core/dfa_eval.h); device pointer in the device copy
+    const uint32_t *dfa_blob;
     DevFilterTest tests[DEVF_MAX_TESTS];
 };
 
@@ -85,6 +88,9 @@ struct SeqArgs {
     uint32_t s;                // S
     uint32_t match_base;       // value of mhdr->count when this dispatch was enqueued
     uint32_t match_cap;
+    const uint32_t *dfa_blob;  // DEVF_DFA: the automaton (device memory), staged into LDS by the kernel
+    uint32_t dfa_bytes;        // 0 = prefilter mode
+    uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 

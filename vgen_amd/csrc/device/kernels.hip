@@ -26,6 +26,7 @@
 //     only candidate records through a wave-aggregated atomic slot counter.
 #include <hip/hip_runtime.h>
 
+#include "../core/dfa_eval.h"
 #include "../core/ec.h"
 #include "../core/filter_eval.h"
 #include "../core/hash.h"
@@ -157,10 +158,18 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 
 // ---- stage 3: walk the tree down, finish the additions, hash, filter ---------------------------------------
 
-template <int FMT>
+// FULL: the filter is the pattern's whole DFA (DEVF_DFA): its tables are staged into dynamic LDS and every
+// key's address is encoded and matched on the device (core/dfa_eval.h).  A separate instantiation so
+// that the extra registers of the Base58Check path do not touch the prefilter kernels' occupancy.
+template <int FMT, bool FULL>
 __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
+    extern __shared__ u32 dfa_lds[];
     const int tid = threadIdx.x;
+    if (FULL) {
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
+        // (visibility: the barriers of the tree phase below come before the first DFA read)
+    }
     const u32 S = args.s;
     const u32 lanes = args.lanes;
     const u32 u = blockIdx.x * WG + tid;
@@ -254,7 +263,7 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
                 u32 *o = args.dump + (size_t)index * 5;
 #pragma unroll
                 for (int i = 0; i < 5; i++) o[i] = pl[i];
-            } else if (filter_eval(args.filter, pl)) {
+            } else if (FULL ? dfa_match_payload(dfa_lds, (int)args.fmt, pl) : filter_eval(args.filter, pl)) {
                 // monotonic counter: no per-dispatch reset; this dispatch's slots start at match_base
                 const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
                 if (slot < args.match_cap) {
@@ -420,7 +429,12 @@ hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream) {
 
 template <int FMT>
 static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(seq_bwd_kernel<FMT>, dim3(a.groups), dim3(WG), 0, stream, a);
+    if (a.dfa_bytes && !a.dump) {
+        if (a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+    } else {
+        hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // filter.cpp — see filter.h.
 #include "filter.h"
 
+#include "../core/dfa_eval.h"
 #include "../core/filter_eval.h"
 
 #include <string.h>
@@ -247,6 +248,15 @@ void derive_base58(const Dfa &d, uint8_t version, DevFilter &dev, double &sel) {
             dev.kind = exact ? DEVF_ALL : DEVF_HOST_ALL;
             return;
         }
+        if (sel > 0.2) {   // ranges that cover most of the space are no prefilter
+            bool exact = true;
+            for (auto &p : prefixes) exact = exact && p.absorbing;
+            if (!exact) {
+                dev.kind = DEVF_HOST_ALL;
+                sel = 1.0;
+                return;
+            }
+        }
         dev.kind = DEVF_RANGES;
         dev.count = (uint32_t)ranges.size();
         for (size_t i = 0; i < ranges.size(); i++) {
@@ -420,6 +430,10 @@ void derive_symbols(const Dfa &d, const SymSpec &sp, DevFilter &dev, double &sel
         use_s = best_suffixes;
         sel = suffix_sel;
     }
+    if (sel > 0.2) {   // not a useful necessary condition: leave it to the full match (DEVF_DFA) / host
+        sel = 1.0;
+        return;
+    }
     dev.kind = DEVF_MASKED;
     dev.count = 0;
     for (auto &p : use_p)
@@ -435,6 +449,33 @@ void derive_symbols(const Dfa &d, const SymSpec &sp, DevFilter &dev, double &sel
     // count == 0 means nothing can match: the kernel then reports no candidates
 }
 
+// Packs `d` into the device layout of core/dfa_eval.h.  `head` is the literal every address of the format
+// starts with and that the device does not re-walk; `alphabet` maps symbol index -> character.
+// Returns false when the automaton does not fit the LDS budget (or 16-bit state numbers).
+bool build_dfa_blob(const Dfa &d, const char *head, const char *alphabet, std::vector<uint32_t> &blob) {
+    if (d.n_states > 65535) return false;
+    uint32_t s = 0;
+    for (const char *h = head; *h; h++) s = d.match_now[s] ? s : step(d, s, (unsigned char)*h);
+    const size_t flags_off = DFA_HDR_WORDS * 4;
+    const size_t trans_off = (flags_off + d.n_states + 3) & ~(size_t)3;
+    const size_t total = (trans_off + (size_t)d.n_states * d.n_cls * 2 + 3) & ~(size_t)3;
+    if (total > DFA_MAX_BYTES) return false;
+    blob.assign(total / 4, 0);
+    blob[0] = d.n_states;
+    blob[1] = d.n_cls;
+    blob[2] = s;
+    blob[3] = (uint32_t)flags_off;
+    blob[4] = (uint32_t)trans_off;
+    blob[5] = (uint32_t)total;
+    uint8_t *b = reinterpret_cast<uint8_t *>(blob.data());
+    for (size_t i = 0; alphabet[i]; i++) b[8 * 4 + i] = d.cls[(unsigned char)alphabet[i]];
+    for (uint32_t st = 0; st < d.n_states; st++)
+        b[flags_off + st] = (uint8_t)((d.match_now[st] ? 1 : 0) | (d.match_at_end[st] ? 2 : 0) | (d.dead[st] ? 4 : 0));
+    uint16_t *t = reinterpret_cast<uint16_t *>(b + trans_off);
+    for (size_t i = 0; i < (size_t)d.n_states * d.n_cls; i++) t[i] = (uint16_t)d.trans[i];
+    return true;
+}
+
 }  // namespace
 
 bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t format, vgen_filter &out,
@@ -448,9 +489,11 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
     case VGF_P2PKH:
     case VGF_P2PKH_UNCOMPRESSED:
         derive_base58(out.dfa, 0x00, out.dev, out.selectivity);
+        if (out.dev.kind == DEVF_HOST_ALL && build_dfa_blob(out.dfa, "", B58, out.dfa_blob)) out.dev.kind = DEVF_DFA;
         break;
     case VGF_P2SH_P2WPKH:
         derive_base58(out.dfa, 0x05, out.dev, out.selectivity);
+        if (out.dev.kind == DEVF_HOST_ALL && build_dfa_blob(out.dfa, "", B58, out.dfa_blob)) out.dev.kind = DEVF_DFA;
         break;
     case VGF_P2WPKH: {
         const SymSpec sp = {"bc1q", BECH32, 5, 32, 6};
@@ -470,6 +513,7 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
             out.dev.chk_base = base;
             out.dev.chk_lut = out.chk_lut.data();   // host pointer; the runtime swaps in the device copy
         }
+        if (out.dev.kind == DEVF_HOST_ALL && build_dfa_blob(out.dfa, "bc1q", BECH32, out.dfa_blob)) out.dev.kind = DEVF_DFA;
         break;
     }
     case VGF_ETHEREUM: {
@@ -483,12 +527,18 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
         }
         const SymSpec sp = {"0x", HEXL, 4, 40, 0};
         derive_symbols(folded, sp, out.dev, out.selectivity);
+        if (out.dev.kind == DEVF_HOST_ALL && build_dfa_blob(folded, "0x", HEXL, out.dfa_blob)) out.dev.kind = DEVF_DFA;
         break;
     }
     default:
         out.dev.kind = DEVF_HOST_ALL;   // P2TR: host filtering (the reference does the same, gpu.rs:1287-1293)
         out.selectivity = 1.0;
         break;
+    }
+    if (out.dev.kind == DEVF_DFA) {
+        out.dev.dfa_blob = out.dfa_blob.data();   // host pointer; the runtime swaps in the device copy
+        out.dev.dfa_bytes = (uint32_t)(out.dfa_blob.size() * 4);
+        out.selectivity = -1.0;                   // unknown: the scanner adapts (ring overflow -> host filtering)
     }
     return true;
 }

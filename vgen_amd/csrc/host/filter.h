@@ -26,6 +26,7 @@ struct vgen_filter {
     vg::DevFilter dev{};    // device prefilter (superset)
     double selectivity = 1.0;   // estimated fraction of keys the device reports
     std::vector<uint32_t> chk_lut;   // Bech32 checksum tables (20 x 256) when the prefilter tests the checksum
+    std::vector<uint32_t> dfa_blob;  // DEVF_DFA: the DFA in device layout (core/dfa_eval.h)
 };
 
 namespace vg {

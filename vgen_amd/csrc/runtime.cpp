@@ -140,6 +140,7 @@ void rt_destroy(vgen_ctx *c) {
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
+    if (c->d_dfa) (void)hipFree(c->d_dfa);
     if (c->d_filter) (void)hipFree(c->d_filter);
     delete c;
 }
@@ -158,6 +159,11 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
         if (!c->d_chk_lut) HIP_TRY(c, hipMalloc((void **)&c->d_chk_lut, 20 * 256 * sizeof(uint32_t)));
         HIP_TRY(c, hipMemcpy(c->d_chk_lut, f->chk_lut.data(), 20 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->h_filter.chk_lut = c->d_chk_lut;
+    }
+    if (f->dev.kind == DEVF_DFA) {   // the pattern's automaton: upload, point the device copy at it
+        if (!c->d_dfa) HIP_TRY(c, hipMalloc((void **)&c->d_dfa, 48 * 1024));
+        HIP_TRY(c, hipMemcpy(c->d_dfa, f->dfa_blob.data(), f->dfa_blob.size() * 4, hipMemcpyHostToDevice));
+        c->h_filter.dfa_blob = c->d_dfa;
     }
     HIP_TRY(c, hipMemcpy(c->d_filter, &c->h_filter, sizeof(DevFilter), hipMemcpyHostToDevice));
     c->have_filter = true;
@@ -182,7 +188,8 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
         for (int i = 0; i < 8; i++) a.base[i] = base->w[i];
     a.filter = c->d_filter;
     a.n = n;
-    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
+    // (the arbitrary-scalar kernel has no on-device DFA variant: full-match patterns are filtered on the host)
+    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL || c->h_filter.kind == DEVF_DFA;
     if (dump) {
         if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
         if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.stream));
@@ -261,7 +268,12 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         a.mrec = reinterpret_cast<DevMatch *>(f.d_match + sizeof(DevMatchHeader));
         a.match_base = f.match_base;   // the counter is monotonic: no reset, no upload
         a.match_cap = c->match_cap;
+        if (c->h_filter.kind == DEVF_DFA) {
+            a.dfa_blob = c->h_filter.dfa_blob;
+            a.dfa_bytes = c->h_filter.dfa_bytes;
+        }
     }
+    a.fmt = c->format;
     HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
     HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream, f.ev_mid));
     HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));

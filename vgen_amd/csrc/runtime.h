@@ -25,6 +25,7 @@ struct vgen_ctx {
     uint32_t *d_rtab = nullptr;          // [18][lanes]
     uint32_t *d_gtab = nullptr;          // 4-bit fixed-window generator table (keys kernel), built on first use
     vg::DevFilter *d_filter = nullptr;   // current device filter program
+    uint32_t *d_dfa = nullptr;           // DEVF_DFA automaton of the current filter
     uint32_t *d_chk_lut = nullptr;       // Bech32 checksum tables of the current filter (when it tests the checksum)
     bool have_filter = false;            // false = dump mode
     vg::DevFilter h_filter{};

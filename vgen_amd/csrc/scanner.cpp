@@ -113,6 +113,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
 
     // device prefilter or host filtering of full dumps: too permissive a prefilter would overflow the
     // match ring, so it is only used when a batch is expected to produce few candidates
+    // (a DEVF_DFA filter has no selectivity estimate: it starts on the device and falls back on overflow)
     bool host_all = flt.dev.kind == DEVF_HOST_ALL ||
                     (flt.dev.kind != DEVF_HOST_ALL && flt.selectivity * (double)N > (double)ctx->match_cap / 8);
     int rc = vgen_set_filter(ctx, host_all ? nullptr : &flt);
@@ -217,8 +218,23 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                     if (found() < count) push(g);
         } else {
             if (n_found > recs.size()) {
-                status = ctx->fail(VGEN_E_STATE, "device match ring overflowed; raise match_cap or use a more selective pattern");
-                break;
+                // More candidates than the ring holds (a permissive pattern): nothing may be dropped, so
+                // drain what is in flight, switch to host filtering of full dumps (the reference's mode)
+                // and redo from this batch.
+                for (uint32_t f = 0; f < nf; f++)
+                    if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
+                if ((status = vgen_set_filter(ctx, nullptr)) != VGEN_OK) break;
+                dispatched -= 1 + in_flight;
+                in_flight = 0;
+                current = batch_start;
+                exhausted = false;
+                for (uint32_t i = 0; i < nf; i++) {
+                    if (!can_dispatch() || stopped() || found() >= count) break;
+                    if ((status = dispatch(i)) != VGEN_OK) break;
+                    in_flight++;
+                }
+                frame = 0;
+                continue;
             }
             vgen_generated g;
             for (uint32_t i = 0; i < n_found && found() < count; i++)
