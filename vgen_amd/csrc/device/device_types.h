@@ -110,6 +110,9 @@ struct KeysArgs {
     uint32_t n;
     uint32_t match_base;
     uint32_t match_cap;
+    uint32_t fmt;              // VGF_* of the context
+    const uint32_t *dfa_blob;  // DEVF_DFA (see SeqArgs)
+    uint32_t dfa_bytes;
     uint32_t pad;
 };
 

@@ -293,11 +293,14 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
 constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                             0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
-template <int FMT>
+template <int FMT, bool FULL>
 __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args) {
-    extern __shared__ u32 tab[];   // KEYS_TABLE_WORDS
+    extern __shared__ u32 tab[];   // KEYS_TABLE_WORDS, then (FULL) the DFA blob
     const int tid = threadIdx.x;
     for (u32 i = tid; i < KEYS_TABLE_WORDS; i += KEYS_WG) tab[i] = args.gtab[i];
+    const u32 *dfa_lds = tab + KEYS_TABLE_WORDS;
+    if (FULL)
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += KEYS_WG) tab[KEYS_TABLE_WORDS + i] = args.dfa_blob[i];
     __syncthreads();
 
     const u32 idx = blockIdx.x * KEYS_WG + tid;
@@ -385,7 +388,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
         u32 *o = args.dump + (size_t)idx * 5;
 #pragma unroll
         for (int i = 0; i < 5; i++) o[i] = valid ? pl[i] : 0u;
-    } else if (valid && filter_eval(args.filter, pl)) {
+    } else if (valid && (FULL ? dfa_match_payload(dfa_lds, (int)args.fmt, pl) : filter_eval(args.filter, pl))) {
         const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
         if (slot < args.match_cap) {
             DevMatch *m = args.mrec + slot;
@@ -400,11 +403,22 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
 
 template <int FMT>
 static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream) {
-    const size_t lds_bytes = KEYS_TABLE_WORDS * sizeof(u32);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&keys_scan_kernel<FMT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(keys_scan_kernel<FMT>, dim3((a.n + KEYS_WG - 1) / KEYS_WG), dim3(KEYS_WG), lds_bytes, stream, a);
+    const bool full = a.dfa_bytes && !a.dump;
+    if (full && a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
+    const size_t lds_bytes = KEYS_TABLE_WORDS * sizeof(u32) + (full ? a.dfa_bytes : 0);
+    const dim3 grid((a.n + KEYS_WG - 1) / KEYS_WG);
+    hipError_t e;
+    if (full) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&keys_scan_kernel<FMT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((keys_scan_kernel<FMT, true>), grid, dim3(KEYS_WG), lds_bytes, stream, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&keys_scan_kernel<FMT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((keys_scan_kernel<FMT, false>), grid, dim3(KEYS_WG), lds_bytes, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -188,8 +188,8 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
         for (int i = 0; i < 8; i++) a.base[i] = base->w[i];
     a.filter = c->d_filter;
     a.n = n;
-    // (the arbitrary-scalar kernel has no on-device DFA variant: full-match patterns are filtered on the host)
-    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL || c->h_filter.kind == DEVF_DFA;
+    a.fmt = c->format;
+    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
     if (dump) {
         if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
         if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.stream));
@@ -199,6 +199,10 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
         a.mrec = reinterpret_cast<DevMatch *>(f.d_match + sizeof(DevMatchHeader));
         a.match_base = f.match_base;
         a.match_cap = c->match_cap;
+        if (c->h_filter.kind == DEVF_DFA) {
+            a.dfa_blob = c->h_filter.dfa_blob;
+            a.dfa_bytes = c->h_filter.dfa_bytes;
+        }
     }
     HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
     HIP_TRY(c, hipEventRecord(f.ev_mid, f.stream));
