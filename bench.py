@@ -30,15 +30,18 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_ORDER = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
-FORMATS = {"p2pkh": 0, "p2wpkh": 1, "p2sh-p2wpkh": 2, "p2pkh-uncompressed": 4, "ethereum": 5}
+FORMATS = {"p2pkh": 0, "p2wpkh": 1, "p2sh-p2wpkh": 2, "p2tr": 3, "p2pkh-uncompressed": 4, "ethereum": 5}
 
 # Algorithmic work per key (lane-op equivalents), SURVEY.md §8(d) / BASELINE.md §5, with the 32x32
 # multiply weight re-based from the estimate r_mul = 4 to the measured issue ratio r_mul = 2
 # (v_mad_u64_u32 / v_mul_*_u32 issue at half the v_add_u32 rate on gfx950, profiles/r01_ubench_valu.jsonl).
-W_IMUL = {"p2pkh": 518, "p2wpkh": 518, "p2sh-p2wpkh": 518, "p2pkh-uncompressed": 518, "ethereum": 518}
+# P2TR adds, per key, the BIP-341 tweak: one fixed-base multiplication (64 mixed additions of 8M+3S), one
+# more field inversion (255S+15M) and one SHA-256 compression: ~990 field multiplications of 57 imul + ~60 iop.
+W_IMUL = {"p2pkh": 518, "p2wpkh": 518, "p2sh-p2wpkh": 518, "p2pkh-uncompressed": 518, "ethereum": 518,
+          "p2tr": 518 + 990 * 57}
 W_IOP = {"p2pkh": 550 + 1450 + 1130 + 20, "p2wpkh": 550 + 1450 + 1130 + 20 + 500,
          "p2sh-p2wpkh": 550 + 2 * (1450 + 1130) + 20, "p2pkh-uncompressed": 550 + 2 * 1450 + 1130 + 20,
-         "ethereum": 550 + 6400 + 20}
+         "ethereum": 550 + 6400 + 20, "p2tr": 550 + 1450 + 20 + 500 + 990 * 60}
 R_MUL = 2
 # peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz full-rate integer lane-ops (MI355X_MICROARCH.md: SIMD-32,
 # 2400 MHz; equals the 157.3 TFLOP/s fp32 vector peak / 2).  Measured sustained: 64.7 T/s.

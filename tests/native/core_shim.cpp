@@ -132,13 +132,14 @@ int core_filter_check(const char *pattern, int ci, unsigned format, const unsign
     *kind_out = (int)f.dev.kind;
     *sel_out = f.selectivity;
     for (int i = 0; i < n; i++) {
-        u32 pl[5];
-        for (int w = 0; w < 5; w++) {
-            const unsigned char *p = payloads + 20 * i + 4 * w;
+        const int pb = format == 3 ? 32 : 20;     // P2TR carries the 32-byte x-only output key
+        u32 pl[8];
+        for (int w = 0; w < pb / 4; w++) {
+            const unsigned char *p = payloads + pb * i + 4 * w;
             pl[w] = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
         }
-        int dev = filter_eval(&f.dev, pl) ? 1 : 0;
-        std::string addr = address_from_payload(format, payloads + 20 * i);
+        int dev = (format == 3 ? filter_eval_n<8>(&f.dev, pl) : filter_eval(&f.dev, pl)) ? 1 : 0;
+        std::string addr = address_from_payload(format, payloads + pb * i);
         int exact = f.dfa.is_match(addr) ? 1 : 0;
         out_flags[i] = (unsigned char)(dev | (exact << 1));
     }
@@ -224,16 +225,40 @@ int core_dfa_check(const char *pattern, int ci, unsigned format, const unsigned 
     if (!filter_compile(pattern, ci != 0, format, f, err)) return -1;
     if (f.dev.kind != DEVF_DFA) return (int)f.dev.kind;
     for (int i = 0; i < n; i++) {
-        u32 pl[5];
-        for (int w = 0; w < 5; w++) {
-            const unsigned char *p = payloads + 20 * i + 4 * w;
+        const int pb = format == 3 ? 32 : 20;
+        u32 pl[8];
+        for (int w = 0; w < pb / 4; w++) {
+            const unsigned char *p = payloads + pb * i + 4 * w;
             pl[w] = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
         }
-        int dev = dfa_match_payload(f.dfa_blob.data(), (int)format, pl) ? 1 : 0;
-        std::string addr = address_from_payload(format, payloads + 20 * i);
+        int dev = (format == 3 ? dfa_match_payload_n<8>(f.dfa_blob.data(), 3, pl)
+                               : dfa_match_payload(f.dfa_blob.data(), (int)format, pl)) ? 1 : 0;
+        std::string addr = address_from_payload(format, payloads + pb * i);
         int exact = f.dfa.is_match(addr) ? 1 : 0;
         out_flags[i] = (unsigned char)(dev | (exact << 1));
     }
     return (int)DEVF_DFA;
+}
+}
+
+#include "../../vgen_amd/csrc/core/taproot.h"
+
+extern "C" {
+// Device algorithm for the P2TR output key, on the host: key -> k*G via ec_mul_gen_windows (the same
+// table layout), then taproot_output_x.  out: 32 bytes big-endian x(Q).  0 if invalid.
+int core_taproot_from_key(const unsigned char *key_be, unsigned char *out32) {
+    static std::vector<uint32_t> tab;
+    if (tab.empty()) host_gen_table_limbs(tab);
+    Scalar k;
+    scalar_from_be(k, key_be);
+    if (!scalar_is_valid(k)) return 0;
+    gej pj;
+    ec_mul_gen_windows(pj, k.w, tab.data());
+    ge p;
+    if (!ge_from_gej(p, pj)) return 0;
+    u32 xw[8];
+    if (!taproot_output_x(p.x, p.y, tab.data(), xw)) return 0;
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) out32[4 * (7 - i) + j] = (unsigned char)(xw[i] >> (24 - 8 * j));
+    return 1;
 }
 }

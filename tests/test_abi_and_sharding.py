@@ -37,7 +37,7 @@ def test_host_side_helpers_match_oracle():
     import vgen_amd as vg
     from oracle import pyoracle as vo
     for k in (1, 2, 0xC0FFEE, 2**200 + 17):
-        for fmt in (0, 1, 2, 4, 5):
+        for fmt in (0, 1, 2, 3, 4, 5):
             g = vg.derive(fmt, k)
             o = vo.generate(fmt, k)
             assert (g.address, g.wif, g.hex) == (o["address"], o["wif"], o["hex"])

@@ -339,3 +339,63 @@ def test_scan_with_unanchored_pattern_and_ring_overflow_fallback(vg, vo):
     assert res.operations == 6 * 8192
     r.close()
     r2.close()
+
+
+# ---- P2TR: 32-byte payload (x-only output key), BIP-341 tweak done on the device -------------------------------
+
+
+def test_p2tr_dump_matches_oracle(vg, vo):
+    batch = 8192
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2tr)
+    for start in (vo.seed_key(42, 3), 1, 2**65, N - 2 * batch - 7, N - 100):
+        r.set_filter(None)
+        r.dispatch(start, 0)
+        blob, _, _ = r.await_result(0)
+        assert len(blob) == 32 * batch
+        assert blob == vo.payload_seq(vo.FMT_P2TR, start, batch), hex(start)
+    r.close()
+
+
+def test_p2tr_keys_mode_and_filters(vg, vo):
+    import random
+    rng = random.Random(341)
+    batch = 8192
+    keys = [1, 2, N - 1, 0, N, 0x0C28FCA386C7A227600B2FE50B7CAE11EC86D3BF1FBE471BE89827E19D72AA1D] + \
+           [rng.randrange(1, N) for _ in range(4000)]
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2tr, match_cap=8192)
+    r.set_filter(None)
+    r.dispatch_keys(keys, 0)
+    blob, _, _ = r.await_result(0)
+    addrs = []
+    for i, k in enumerate(keys):
+        want = vo.payload(vo.FMT_P2TR, k) if vo.key_valid(k) else bytes(32)
+        assert blob[32 * i:32 * i + 32] == want, hex(k)
+        addrs.append(vo.generate(vo.FMT_P2TR, k)["address"] if vo.key_valid(k) else None)
+    assert addrs[0] == "bc1pmfr3p9j00pfxjh0zmgp99y8zftmd3s5pmedqhyptwy6lm87hf5sspknck9"
+    for pat, kind in [("^bc1pq", 2), ("^bc1p[qp]z", 2), ("aa$", 2), ("^bc1pq.*q$", 2), ("qqq", 4), ("[0-9]{6}", 4)]:
+        p = vg.Pattern(pat, False, vg.AddressFormat.P2tr)
+        assert p.device_kind == kind, (pat, p.device_kind)
+        oracle_re = vo.Regex(pat, False)
+        r.set_filter(p)
+        r.dispatch_keys(keys, 1)
+        recs, n_found, _ = r.await_result(1)
+        got = [i for i, pl in recs if p.matches(vg.address_from_payload(3, pl))]
+        want = [i for i, a in enumerate(addrs) if a and oracle_re.matches(a)]
+        assert got == want, pat
+        for i, pl in recs:
+            assert pl == blob[32 * i:32 * i + 32]
+        if kind == 4:
+            assert [i for i, _ in recs] == want
+    r.close()
+
+
+def test_p2tr_scan(vg, vo):
+    r = vg.GpuRunner(batch_size=65536, fmt=vg.AddressFormat.P2tr)
+    res = vg.scan_gpu_with_runner("^bc1pqq", vg.ScanConfig(format=vg.AddressFormat.P2tr, count=2, seed=11), r)
+    assert len(res.matches) == 2
+    for m in res.matches:
+        g = vo.generate(vo.FMT_P2TR, int(m.hex, 16))
+        assert m.address.startswith("bc1pqq") and (g["address"], g["wif"]) == (m.address, m.wif)
+    d = vg.derive(3, 1)
+    assert d.address == "bc1pmfr3p9j00pfxjh0zmgp99y8zftmd3s5pmedqhyptwy6lm87hf5sspknck9"
+    r.close()

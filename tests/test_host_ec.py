@@ -65,3 +65,15 @@ def test_branch_free_window_accumulation_used_by_keys_kernel(core):
         out = ctypes.create_string_buffer(64)
         assert core.core_mul_windows_nz(k.to_bytes(32, "big"), out) == 1
         assert out.raw == vo.pubkey(k)[1:], hex(k)
+
+
+def test_taproot_output_key_device_algorithm(core):
+    """core/taproot.h (the code the P2TR kernels run) against the oracle's BIP-341 restatement."""
+    rng = random.Random(99)
+    keys = [1, 2, 3, N - 1, 0x0C28FCA386C7A227600B2FE50B7CAE11EC86D3BF1FBE471BE89827E19D72AA1D] + \
+           [rng.randrange(1, N) for _ in range(25)]
+    for k in keys:
+        out = ctypes.create_string_buffer(32)
+        assert core.core_taproot_from_key(k.to_bytes(32, "big"), out) == 1
+        assert out.raw == vo.payload(vo.FMT_P2TR, k), hex(k)
+    assert vo.segwit_addr("bc", 1, vo.payload(vo.FMT_P2TR, 1)) == "bc1pmfr3p9j00pfxjh0zmgp99y8zftmd3s5pmedqhyptwy6lm87hf5sspknck9"

@@ -233,6 +233,7 @@ class GpuRunner:
         b, f, m = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
         _L.vgen_get_info(h, ctypes.byref(b), ctypes.byref(f), ctypes.byref(m))
         self.batch_size, self.frames, self.match_cap, self.format = b.value, f.value, m.value, AddressFormat(int(fmt))
+        self.payload_bytes = 32 if self.format == AddressFormat.P2tr else 20
         self._pattern = None
 
     def close(self):
@@ -261,11 +262,11 @@ class GpuRunner:
         n, tested = ctypes.c_uint32(), ctypes.c_uint64()
         _check(_L.vgen_wait(self._h, frame, recs, self.match_cap, ctypes.byref(n), ctypes.byref(tested)), self._h)
         if self._pattern is None:
-            buf = ctypes.create_string_buffer(self.batch_size * 20)
+            buf = ctypes.create_string_buffer(self.batch_size * self.payload_bytes)
             _check(_L.vgen_read_dump(self._h, frame, buf, len(buf)), self._h)
             return buf.raw, 0, tested.value
         k = min(n.value, self.match_cap)
-        return [(recs[i].index, bytes(recs[i].payload)[:20]) for i in range(k)], n.value, tested.value
+        return [(recs[i].index, bytes(recs[i].payload)[:self.payload_bytes]) for i in range(k)], n.value, tested.value
 
     def wait(self, frame: int):
         """vgen_wait without fetching anything (benchmark loop)."""

@@ -362,7 +362,8 @@ int main(int argc, char **argv) {
     if (o.cmd == "verify") {
         uint8_t k[32];
         if (!parse_hex_key(o.key, k)) die("verify: --key must be a hex private key in this build");
-        const int fmts[] = {VGEN_FMT_P2PKH, VGEN_FMT_P2WPKH, VGEN_FMT_P2SH_P2WPKH, VGEN_FMT_P2PKH_UNCOMPRESSED, VGEN_FMT_ETHEREUM};
+        const int fmts[] = {VGEN_FMT_P2PKH, VGEN_FMT_P2WPKH, VGEN_FMT_P2SH_P2WPKH, VGEN_FMT_P2TR,
+                            VGEN_FMT_P2PKH_UNCOMPRESSED, VGEN_FMT_ETHEREUM};
         bool ok = o.address.empty();
         for (int f : fmts) {
             char addr[128], wif[128];

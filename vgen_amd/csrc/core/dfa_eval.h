@@ -163,19 +163,16 @@ VG_HD bool dfa_match_base58(const u32 *blob, u32 version, const u32 H[5]) {
 
 // ---- fixed-length symbol strings ------------------------------------------------------------------------------
 
-// Bech32 P2WPKH: 32 data symbols + 6 checksum symbols after the literal "bc1q" (already consumed: blob[2]).
-VG_HD bool dfa_match_bech32_v0(const u32 *blob, const u32 H[5]) {
+// Bech32(m) witness programs: NW = 5 -> "bc1q" + 32 data symbols, NW = 8 -> "bc1p" + 52 data symbols (P2TR),
+// then 6 checksum symbols.  The literal head is already consumed (blob[2]).
+template <int NW>
+VG_HD bool dfa_match_bech32(const u32 *blob, const u32 *H, u32 witver) {
+    constexpr int NSYM = (NW * 32 + 4) / 5;
     const DfaView v = dfa_view(blob);
     u32 s = blob[2];
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const int bit = 5 * k, w = bit >> 5, o = bit & 31;
-        u32 sym;
-        if (o <= 27) sym = (H[w] >> (27 - o)) & 31u;
-        else sym = ((H[w] << (o - 27)) | (H[w + 1] >> (59 - o))) & 31u;
-        s = dfa_step(v, s, sym);
-    }
-    const u32 chk = bech32_checksum_bc20(H, 0);
+    for (int k = 0; k < NSYM; k++) s = dfa_step(v, s, bits5<NW>(H, k));
+    const u32 chk = bech32_checksum_bc<NW>(H, witver);
 #pragma unroll
     for (int k = 0; k < 6; k++) s = dfa_step(v, s, (chk >> (25 - 5 * k)) & 31u);
     return dfa_accept(v, s);
@@ -190,14 +187,20 @@ VG_HD bool dfa_match_hex40(const u32 *blob, const u32 H[5]) {
     return dfa_accept(v, s);
 }
 
-// payload: five words in memory order.  fmt: VGF_* (P2TR not supported here).
-VG_HD bool dfa_match_payload(const u32 *blob, int fmt, const u32 payload[5]) {
-    u32 H[5];
+// payload: NW words in memory order (5, or 8 for P2TR).  fmt: VGF_*.
+template <int NW>
+VG_HD bool dfa_match_payload_n(const u32 *blob, int fmt, const u32 *payload) {
+    u32 H[NW];
 #pragma unroll
-    for (int i = 0; i < 5; i++) H[i] = bswap32(payload[i]);
-    if (fmt == VGF_P2WPKH) return dfa_match_bech32_v0(blob, H);
+    for (int i = 0; i < NW; i++) H[i] = bswap32(payload[i]);
+    if (NW == 8) return dfa_match_bech32<NW>(blob, H, 1);
+    if (fmt == VGF_P2WPKH) return dfa_match_bech32<NW>(blob, H, 0);
     if (fmt == VGF_ETHEREUM) return dfa_match_hex40(blob, H);
     return dfa_match_base58(blob, fmt == VGF_P2SH_P2WPKH ? 5u : 0u, H);
+}
+
+VG_HD bool dfa_match_payload(const u32 *blob, int fmt, const u32 payload[5]) {
+    return dfa_match_payload_n<5>(blob, fmt, payload);
 }
 
 }  // namespace vg

@@ -205,3 +205,44 @@ VG_HD void gej_add_ge_nz(gej &r, const gej &a, const ge &b) {
 }
 
 }  // namespace vg
+
+namespace vg {
+
+// acc = k * G by 4-bit fixed windows, least significant window first, with the table layout of
+// host_gen_table_limbs ([64][15][18] limbs: x then y of d * 16^w * G).  k: eight little-endian words,
+// 0 < k < n.  Unsigned digits accumulated low to high keep the running sum below the next addend's
+// scalar, so the branch-free mixed addition never meets P = +/-Q; "still at infinity" is a select.
+// Works on any memory the table lives in (LDS on the device, heap on the host).
+VG_HD void ec_mul_gen_windows(gej &acc, const u32 k[8], const u32 *tab) {
+    gej_set_infinity(acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int w = 0; w < 64; w++) {
+        const u32 d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+        const u32 e = (d ? d : 1u) - 1u;
+        const u32 *ent = tab + ((u32)w * 15u + e) * 18u;
+        ge t;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            t.x.n[i] = ent[i];
+            t.y.n[i] = ent[9 + i];
+        }
+        gej sum;
+        gej_add_ge_nz(sum, acc, t);      // garbage while acc is at infinity; replaced below
+        const bool take_table = acc.inf != 0;
+        const bool skip = d == 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const u32 nx = take_table ? t.x.n[i] : sum.x.n[i];
+            const u32 ny = take_table ? t.y.n[i] : sum.y.n[i];
+            const u32 nzl = take_table ? (i == 0 ? 1u : 0u) : sum.z.n[i];
+            acc.x.n[i] = skip ? acc.x.n[i] : nx;
+            acc.y.n[i] = skip ? acc.y.n[i] : ny;
+            acc.z.n[i] = skip ? acc.z.n[i] : nzl;
+        }
+        acc.inf = skip ? acc.inf : 0u;
+    }
+}
+
+}  // namespace vg

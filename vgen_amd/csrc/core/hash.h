@@ -151,6 +151,26 @@ VG_HD void sha256_script22(const u32 h[5], u32 out[8]) {
     sha256_compress(out, w);
 }
 
+// BIP-341 TapTweak for a key-path-only output: t = SHA-256(SHA-256("TapTweak") || SHA-256("TapTweak") || x).
+// The first 64-byte block is constant; its chaining value is the midstate the reference also carries
+// (src/shaders/sha256.wgsl:180-183, cross-checked in tests/test_oracle_golden.py).  xw: x as eight words,
+// xw[0] least significant; out: t as eight BIG-endian words (out[0] most significant).
+constexpr u32 TAPTWEAK_MIDSTATE[8] = {0xd129a2f3u, 0x701c655du, 0x6583b6c3u, 0xb9419727u,
+                                      0x95f4e232u, 0x94fd54f4u, 0xa2ae8d85u, 0x47ca590bu};
+
+VG_HD void sha256_taptweak(const u32 xw[8], u32 out[8]) {
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = xw[7 - i];
+    w[8] = 0x80000000u;
+#pragma unroll
+    for (int i = 9; i < 15; i++) w[i] = 0;
+    w[15] = 96 * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = TAPTWEAK_MIDSTATE[i];
+    sha256_compress(out, w);
+}
+
 // ---- RIPEMD-160 --------------------------------------------------------------------------------
 
 #define VG_RMD_F1(x, y, z) VG_XOR3(x, y, z)

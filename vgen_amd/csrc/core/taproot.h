@@ -1,0 +1,65 @@
+// taproot.h — BIP-341 key-path output key on top of ec.h / hash.h; single source (device + host).
+//
+// What the reference does on the HOST for every key of a P2TR batch (XOnlyPublicKey::from_slice +
+// Address::p2tr(secp, internal_key, None, ..), src/gpu.rs:1287-1291, "CPU bound by design"
+// src/shaders/search_p2tr.wgsl:112): P = lift_x(x) (even Y), t = TapTweak(x), Q = P + t*G, output x(Q).
+// Here it runs per lane on the device: the tweak multiplication uses the same LDS-staged fixed-window
+// table as the arbitrary-scalar kernel.
+#pragma once
+#include "ec.h"
+#include "hash.h"
+
+namespace vg {
+
+constexpr u32 TAP_ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
+                                0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+
+// x, y: canonical affine internal key.  out_xw: x(Q) as eight words, out_xw[0] least significant.
+// Returns false when the tweak is not a valid scalar (t == 0 or t >= n: probability ~2^-128) or Q is the
+// point at infinity; such keys yield no address (Address::p2tr would panic / fail there).
+VG_HD bool taproot_output_x(const fe &x, const fe &y, const u32 *gtab, u32 out_xw[8]) {
+    u32 xw[8], tb[8], k[8];
+    fe_to_words(x, xw);
+    sha256_taptweak(xw, tb);
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = tb[7 - i];   // little-endian words
+    u32 nz = 0;
+    int cmp = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        nz |= k[i];
+        const int d = (k[i] > TAP_ORDER_N[i]) - (k[i] < TAP_ORDER_N[i]);
+        cmp = cmp == 0 ? d : cmp;
+    }
+    const bool ok = nz != 0 && cmp < 0;
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = 0;
+        k[0] = 1;
+    }
+    gej tg;
+    ec_mul_gen_windows(tg, k, gtab);
+    // P with even Y
+    ge p;
+    p.x = x;
+    fe ny;
+    fe_neg(ny, y, 1);
+    fe_normalize(ny);
+    const bool odd = (y.n[0] & 1u) != 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) p.y.n[i] = odd ? ny.n[i] : y.n[i];
+    gej q;
+    gej_add_ge_nz(q, tg, p);              // t*G == +/-P would need t = +/-d: negligible, and caught below
+    fe zi, zi2, qx;
+    fe_inv(zi, q.z);
+    fe_sqr(zi2, zi);
+    fe_mul(qx, q.x, zi2);
+    fe_canonicalize(qx);
+    fe zc = q.z;
+    fe_canonicalize(zc);
+    const bool inf = fe_is_zero_canonical(zc);
+    fe_to_words(qx, out_xw);
+    return ok && !inf;
+}
+
+}  // namespace vg

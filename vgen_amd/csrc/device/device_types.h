@@ -28,9 +28,11 @@ enum : uint32_t {
 constexpr uint32_t DEVF_MAX_TESTS = 64;
 constexpr uint32_t DEVF_FLAG_BECH32_CHK = 1u;   // masked tests also constrain the bech32 checksum
 
+constexpr int DEVF_WORDS = 8;   // payload words a test covers: 5 used for 20-byte payloads, 8 for P2TR
+
 struct DevFilterTest {
-    uint32_t a[5];       // ranges: lo      masked: mask
-    uint32_t b[5];       // ranges: hi      masked: value
+    uint32_t a[DEVF_WORDS];   // ranges: lo      masked: mask
+    uint32_t b[DEVF_WORDS];   // ranges: hi      masked: value
     uint32_t chk_mask;   // bech32 checksum (30 bits, first symbol in bits 29..25)
     uint32_t chk_value;
 };
@@ -41,7 +43,7 @@ struct DevFilter {
     uint32_t flags;
     uint32_t witver;     // bech32: witness version symbol (0 for P2WPKH)
     // Bech32 checksum as an affine map of the payload bytes: chk = chk_base ^ XOR_i chk_lut[i*256 + byte_i]
-    // (20 x 256 words).  Device pointer in the device copy, host pointer in the host copy; nullptr = use
+    // (20 x 256 words; 32 x 256 for the 32-byte P2TR payload).  Device pointer in the device copy, host pointer in the host copy; nullptr = use
     // the step-by-step polymod.
     const uint32_t *chk_lut;
     uint32_t chk_base;
@@ -89,6 +91,7 @@ struct SeqArgs {
     uint32_t match_base;       // value of mhdr->count when this dispatch was enqueued
     uint32_t match_cap;
     const uint32_t *dfa_blob;  // DEVF_DFA: the automaton (device memory), staged into LDS by the kernel
+    const uint32_t *gtab;      // P2TR: fixed-window generator table (KEYS_TABLE_WORDS) for the tweak multiplication
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)

@@ -30,6 +30,7 @@
 #include "../core/ec.h"
 #include "../core/filter_eval.h"
 #include "../core/hash.h"
+#include "../core/taproot.h"
 #include "device_types.h"
 #include "launch.h"
 
@@ -40,7 +41,23 @@ constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 // ---- payload per format -----------------------------------------------------------------------------
 
 template <int FMT>
-__device__ __forceinline__ void payload_from_point(const u32 xw[8], const fe &y_canon, u32 out[5]) {
+struct PayloadWords {
+    static constexpr int value = (FMT == VGF_P2TR) ? 8 : 5;
+};
+
+// x, y: canonical affine public key.  out: the payload words in memory order (PayloadWords<FMT>).
+// gtab: the fixed-window generator table in LDS (P2TR only).  Returns false when the key yields no
+// address (P2TR tweak not a valid scalar — probability ~2^-128).
+template <int FMT>
+__device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, const u32 *gtab, u32 *out) {
+    u32 xw[8];
+    if (FMT == VGF_P2TR) {
+        const bool ok = taproot_output_x(x, y_canon, gtab, xw);
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
+        return ok;
+    }
+    fe_to_words(x, xw);
     if (FMT == VGF_P2PKH || FMT == VGF_P2WPKH) {
         u32 sha[8];
         sha256_pub33(2u | (y_canon.n[0] & 1u), xw, sha);
@@ -61,6 +78,7 @@ __device__ __forceinline__ void payload_from_point(const u32 xw[8], const fe &y_
         fe_to_words(y_canon, yw);
         keccak256_pub64_addr(xw, yw, out);
     }
+    return true;
 }
 
 // ---- LDS / lane helpers ---------------------------------------------------------------------------------
@@ -164,11 +182,16 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 template <int FMT, bool FULL>
 __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
-    extern __shared__ u32 dfa_lds[];
+    extern __shared__ u32 dyn_lds[];   // [P2TR: fixed-window generator table][FULL: DFA blob]
+    constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
+    const u32 *gtab = dyn_lds;
+    u32 *dfa_lds = dyn_lds + (FMT == VGF_P2TR ? KEYS_TABLE_WORDS : 0);
+    if (FMT == VGF_P2TR)
+        for (u32 i = tid; i < KEYS_TABLE_WORDS; i += WG) dyn_lds[i] = args.gtab[i];
     if (FULL) {
         for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
-        // (visibility: the barriers of the tree phase below come before the first DFA read)
+        // (visibility: the barriers of the tree phase below come before the first read of either table)
     }
     const u32 S = args.s;
     const u32 lanes = args.lanes;
@@ -254,16 +277,15 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
             fe_mul_add(y3, lam, t, nqy);          // lam*(Q.x - x3) - Q.y
             fe_canonicalize(y3);
 
-            u32 xw[8], pl[5];
-            fe_to_words(x3, xw);
-            payload_from_point<FMT>(xw, y3, pl);
+            u32 pl[NW];
+            const bool ok = payload_from_point<FMT>(x3, y3, gtab, pl);
 
             const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (dump) {
-                u32 *o = args.dump + (size_t)index * 5;
+                u32 *o = args.dump + (size_t)index * NW;
 #pragma unroll
-                for (int i = 0; i < 5; i++) o[i] = pl[i];
-            } else if (FULL ? dfa_match_payload(dfa_lds, (int)args.fmt, pl) : filter_eval(args.filter, pl)) {
+                for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
+            } else if (ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl))) {
                 // monotonic counter: no per-dispatch reset; this dispatch's slots start at match_base
                 const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
                 if (slot < args.match_cap) {
@@ -271,8 +293,7 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
                     m->index = index;
                     m->reserved = 0;
 #pragma unroll
-                    for (int i = 0; i < 5; i++) m->payload[i] = pl[i];
-                    m->payload[5] = m->payload[6] = m->payload[7] = 0;
+                    for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? pl[i] : 0u;
                 }
             }
         }
@@ -296,6 +317,7 @@ constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
 template <int FMT, bool FULL>
 __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args) {
     extern __shared__ u32 tab[];   // KEYS_TABLE_WORDS, then (FULL) the DFA blob
+    constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
     for (u32 i = tid; i < KEYS_TABLE_WORDS; i += KEYS_WG) tab[i] = args.gtab[i];
     const u32 *dfa_lds = tab + KEYS_TABLE_WORDS;
@@ -341,33 +363,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
     }
 
     gej acc;
-    gej_set_infinity(acc);
-#pragma unroll 1
-    for (int w = 0; w < 64; w++) {
-        const u32 d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
-        const u32 e = (d ? d : 1u) - 1u;
-        const u32 *ent = tab + ((u32)w * 15u + e) * 18u;
-        ge t;
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            t.x.n[i] = ent[i];
-            t.y.n[i] = ent[9 + i];
-        }
-        gej sum;
-        gej_add_ge_nz(sum, acc, t);      // garbage while acc is at infinity; replaced below
-        const bool take_table = acc.inf != 0;
-        const bool skip = d == 0;
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const u32 nx = take_table ? t.x.n[i] : sum.x.n[i];
-            const u32 ny = take_table ? t.y.n[i] : sum.y.n[i];
-            const u32 nzl = take_table ? (i == 0 ? 1u : 0u) : sum.z.n[i];
-            acc.x.n[i] = skip ? acc.x.n[i] : nx;
-            acc.y.n[i] = skip ? acc.y.n[i] : ny;
-            acc.z.n[i] = skip ? acc.z.n[i] : nzl;
-        }
-        acc.inf = skip ? acc.inf : 0u;
-    }
+    ec_mul_gen_windows(acc, k, tab);
 
     // to affine (per-lane Fermat inverse), canonical coordinates
     fe zi, zi2, zi3, x, y;
@@ -379,24 +375,22 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
     fe_canonicalize(x);
     fe_canonicalize(y);
 
-    u32 xw[8], pl[5];
-    fe_to_words(x, xw);
-    payload_from_point<FMT>(xw, y, pl);
+    u32 pl[NW];
+    const bool ok = payload_from_point<FMT>(x, y, tab, pl) && valid;
 
     if (!in_range) return;
     if (args.dump) {
-        u32 *o = args.dump + (size_t)idx * 5;
+        u32 *o = args.dump + (size_t)idx * NW;
 #pragma unroll
-        for (int i = 0; i < 5; i++) o[i] = valid ? pl[i] : 0u;
-    } else if (valid && (FULL ? dfa_match_payload(dfa_lds, (int)args.fmt, pl) : filter_eval(args.filter, pl))) {
+        for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
+    } else if (ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl))) {
         const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
         if (slot < args.match_cap) {
             DevMatch *m = args.mrec + slot;
             m->index = idx;
             m->reserved = 0;
 #pragma unroll
-            for (int i = 0; i < 5; i++) m->payload[i] = pl[i];
-            m->payload[5] = m->payload[6] = m->payload[7] = 0;
+            for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? pl[i] : 0u;
         }
     }
 }
@@ -434,6 +428,8 @@ hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream) {
         return launch_keys_fmt<VGF_P2PKH_UNCOMPRESSED>(a, stream);
     case VGF_ETHEREUM:
         return launch_keys_fmt<VGF_ETHEREUM>(a, stream);
+    case VGF_P2TR:
+        return launch_keys_fmt<VGF_P2TR>(a, stream);
     default:
         return hipErrorInvalidValue;
     }
@@ -443,11 +439,23 @@ hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream) {
 
 template <int FMT>
 static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
+    const size_t tab_bytes = FMT == VGF_P2TR ? KEYS_TABLE_WORDS * sizeof(u32) : 0;
+    if (FMT == VGF_P2TR && !a.gtab) return hipErrorInvalidValue;
+    hipError_t e;
     if (a.dfa_bytes && !a.dump) {
         if (a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+        const size_t lds = tab_bytes + a.dfa_bytes;
+        if (lds > 48 * 1024 &&
+            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seq_bwd_kernel<FMT, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
+        if (tab_bytes > 48 * 1024 &&
+            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seq_bwd_kernel<FMT, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes)) != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), tab_bytes, stream, a);
     }
     return hipGetLastError();
 }
@@ -471,6 +479,8 @@ hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream, hipEve
         return launch_bwd<VGF_P2PKH_UNCOMPRESSED>(a, stream);
     case VGF_ETHEREUM:
         return launch_bwd<VGF_ETHEREUM>(a, stream);
+    case VGF_P2TR:
+        return launch_bwd<VGF_P2TR>(a, stream);
     default:
         return hipErrorInvalidValue;
     }

@@ -3,9 +3,11 @@
 
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../core/hash.h"
+#include "../core/taproot.h"
 #include "../device/device_types.h"
 #include "host_ec.h"
 
@@ -255,8 +257,23 @@ int payload_from_key(uint32_t format, const uint8_t key_be[32], uint8_t out[32])
         host_keccak256(pub65 + 1, 64, kk);
         memcpy(out, kk + 12, 20);
         return 20;
+    case VGF_P2TR: {
+        // BIP-341 key path, no script tree (address.rs:136-140): the single-source device algorithm
+        static std::vector<uint32_t> tab;
+        static std::once_flag once;
+        std::call_once(once, [] { host_gen_table_limbs(tab); });
+        u32 xw[8];
+        if (!taproot_output_x(p.x, p.y, tab.data(), xw)) return 0;
+        for (int i = 0; i < 8; i++) {
+            out[4 * (7 - i)] = (uint8_t)(xw[i] >> 24);
+            out[4 * (7 - i) + 1] = (uint8_t)(xw[i] >> 16);
+            out[4 * (7 - i) + 2] = (uint8_t)(xw[i] >> 8);
+            out[4 * (7 - i) + 3] = (uint8_t)xw[i];
+        }
+        return 32;
+    }
     default:
-        return 0;   // P2TR: next
+        return 0;
     }
 }
 

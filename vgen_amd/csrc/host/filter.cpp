@@ -275,6 +275,7 @@ struct SymSpec {
     unsigned bits;          // bits per symbol
     unsigned n_data;        // symbols that come from the payload
     unsigned n_chk;         // trailing checksum symbols (Bech32)
+    unsigned payload_bits;  // 160, or 256 for P2TR (the last data symbol is then zero-padded)
 };
 
 int sym_index(const SymSpec &sp, char c) {
@@ -282,14 +283,20 @@ int sym_index(const SymSpec &sp, char c) {
     return p && c ? (int)(p - sp.alphabet) : -1;
 }
 
-// Writes symbol `v` at position `pos` (0 = first data symbol) into a test's mask/value.
-void set_symbol(const SymSpec &sp, DevFilterTest &t, unsigned pos, unsigned v) {
+// Writes symbol `v` at position `pos` (0 = first data symbol) into a test's mask/value.  Returns false
+// when the symbol cannot occur there (a set bit in the zero padding of the last data symbol).
+bool set_symbol(const SymSpec &sp, DevFilterTest &t, unsigned pos, unsigned v) {
     if (pos < sp.n_data) {
-        const unsigned bit = pos * sp.bits;   // from the most significant bit of the 160-bit payload
+        const unsigned bit = pos * sp.bits;   // from the most significant bit of the payload
         for (unsigned k = 0; k < sp.bits; k++) {
             const unsigned b = bit + k, w = b >> 5, o = 31 - (b & 31);
+            const bool one = (v >> (sp.bits - 1 - k)) & 1;
+            if (b >= sp.payload_bits) {
+                if (one) return false;
+                continue;
+            }
             t.a[w] |= 1u << o;
-            if ((v >> (sp.bits - 1 - k)) & 1) t.b[w] |= 1u << o;
+            if (one) t.b[w] |= 1u << o;
         }
     } else {
         const unsigned c = pos - sp.n_data;   // checksum symbol c in bits (29 - 5c) .. (25 - 5c)
@@ -297,6 +304,7 @@ void set_symbol(const SymSpec &sp, DevFilterTest &t, unsigned pos, unsigned v) {
         t.chk_mask |= 31u << sh;
         t.chk_value |= (v & 31u) << sh;
     }
+    return true;
 }
 
 void derive_symbols(const Dfa &d, const SymSpec &sp, DevFilter &dev, double &sel) {
@@ -440,9 +448,12 @@ void derive_symbols(const Dfa &d, const SymSpec &sp, DevFilter &dev, double &sel
         for (auto &sx : use_s) {
             DevFilterTest t;
             memset(&t, 0, sizeof t);
-            for (size_t i = 0; i < p.s.size(); i++) set_symbol(sp, t, (unsigned)i, (unsigned)sym_index(sp, p.s[i]));
+            bool possible = true;
+            for (size_t i = 0; i < p.s.size(); i++)
+                possible = set_symbol(sp, t, (unsigned)i, (unsigned)sym_index(sp, p.s[i])) && possible;
             for (size_t i = 0; i < sx.size(); i++)
-                set_symbol(sp, t, n_total - (unsigned)sx.size() + (unsigned)i, (unsigned)sym_index(sp, sx[i]));
+                possible = set_symbol(sp, t, n_total - (unsigned)sx.size() + (unsigned)i, (unsigned)sym_index(sp, sx[i])) && possible;
+            if (!possible) continue;
             if (t.chk_mask) dev.flags |= DEVF_FLAG_BECH32_CHK;
             dev.tests[dev.count++] = t;
         }
@@ -496,7 +507,7 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
         if (out.dev.kind == DEVF_HOST_ALL && build_dfa_blob(out.dfa, "", B58, out.dfa_blob)) out.dev.kind = DEVF_DFA;
         break;
     case VGF_P2WPKH: {
-        const SymSpec sp = {"bc1q", BECH32, 5, 32, 6};
+        const SymSpec sp = {"bc1q", BECH32, 5, 32, 6, 160};
         derive_symbols(out.dfa, sp, out.dev, out.selectivity);
         out.dev.witver = 0;
         if (out.dev.flags & DEVF_FLAG_BECH32_CHK) {
@@ -525,13 +536,34 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
             err = e2;
             return false;
         }
-        const SymSpec sp = {"0x", HEXL, 4, 40, 0};
+        const SymSpec sp = {"0x", HEXL, 4, 40, 0, 160};
         derive_symbols(folded, sp, out.dev, out.selectivity);
         if (out.dev.kind == DEVF_HOST_ALL && build_dfa_blob(folded, "0x", HEXL, out.dfa_blob)) out.dev.kind = DEVF_DFA;
         break;
     }
+    case VGF_P2TR: {
+        // bc1p + 52 data symbols (256 bits + 4 pad bits) + 6 Bech32m checksum symbols
+        const SymSpec sp = {"bc1p", BECH32, 5, 52, 6, 256};
+        derive_symbols(out.dfa, sp, out.dev, out.selectivity);
+        out.dev.witver = 1;
+        if (out.dev.flags & DEVF_FLAG_BECH32_CHK) {
+            const u32 zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const u32 base = bech32_checksum_bc<8>(zero, 1);
+            out.chk_lut.assign(32 * 256, 0);
+            for (int i = 0; i < 32; i++)
+                for (u32 b = 0; b < 256; b++) {
+                    u32 H[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    H[i / 4] = b << (24 - 8 * (i % 4));
+                    out.chk_lut[(size_t)i * 256 + b] = bech32_checksum_bc<8>(H, 1) ^ base;
+                }
+            out.dev.chk_base = base;
+            out.dev.chk_lut = out.chk_lut.data();
+        }
+        if (out.dev.kind == DEVF_HOST_ALL && build_dfa_blob(out.dfa, "bc1p", BECH32, out.dfa_blob)) out.dev.kind = DEVF_DFA;
+        break;
+    }
     default:
-        out.dev.kind = DEVF_HOST_ALL;   // P2TR: host filtering (the reference does the same, gpu.rs:1287-1293)
+        out.dev.kind = DEVF_HOST_ALL;
         out.selectivity = 1.0;
         break;
     }

@@ -62,16 +62,13 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         err = "unknown address format";
         return VGEN_E_INVALID;
     }
-    if (p->format == VGF_P2TR) {
-        err = "P2TR is not implemented on the device yet";
-        return VGEN_E_UNSUPPORTED;
-    }
     vgen_ctx *c = new vgen_ctx();
     c->device = p->device;
     c->batch = p->batch_size ? p->batch_size : (1u << 20);
     c->frames = p->frames ? p->frames : 2;
     c->match_cap = p->match_cap ? p->match_cap : 4096;
     c->format = p->format;
+    c->payload_words = p->format == VGF_P2TR ? 8 : 5;
     c->S = env_u32("VGEN_SEQ_S", 8);
     auto bail = [&](int st, const std::string &m) {
         err = m;
@@ -156,8 +153,8 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
     if (f->format != c->format) return c->fail(VGEN_E_INVALID, "filter was compiled for another address format");
     c->h_filter = f->dev;
     if (f->dev.chk_lut) {   // Bech32 checksum tables: upload and point the device copy at them
-        if (!c->d_chk_lut) HIP_TRY(c, hipMalloc((void **)&c->d_chk_lut, 20 * 256 * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemcpy(c->d_chk_lut, f->chk_lut.data(), 20 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!c->d_chk_lut) HIP_TRY(c, hipMalloc((void **)&c->d_chk_lut, 32 * 256 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_chk_lut, f->chk_lut.data(), f->chk_lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->h_filter.chk_lut = c->d_chk_lut;
     }
     if (f->dev.kind == DEVF_DFA) {   // the pattern's automaton: upload, point the device copy at it
@@ -173,13 +170,18 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
 namespace {
 
 // Enqueues the arbitrary-scalar kernel on frame f: explicit keys (keys_dev != nullptr) or base + i.
-int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
+int ensure_gtab(vgen_ctx *c) {
     if (!c->d_gtab) {
         std::vector<uint32_t> tab;
         host_gen_table_limbs(tab);
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
         HIP_TRY(c, hipMemcpy(c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    return VGEN_OK;
+}
+
+int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
+    if (int rc = ensure_gtab(c)) return rc;
     KeysArgs a;
     memset(&a, 0, sizeof a);
     a.gtab = c->d_gtab;
@@ -278,6 +280,10 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         }
     }
     a.fmt = c->format;
+    if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table
+        if (int rc = ensure_gtab(c)) return rc;
+        a.gtab = c->d_gtab;
+    }
     HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
     HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream, f.ev_mid));
     HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));

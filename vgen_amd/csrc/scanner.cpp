@@ -107,6 +107,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
 
     const uint32_t N = ctx->batch;
+    const size_t pbytes = (size_t)ctx->payload_words * 4;
     const uint32_t shards = cfg->n_shards > 1 ? cfg->n_shards : 1;
     const uint32_t shard = cfg->n_shards > 1 ? cfg->shard : 0;
     if (shard >= shards) return ctx->fail(VGEN_E_INVALID, "shard >= n_shards");
@@ -187,7 +188,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         pend[frame].valid = false;
         const bool dumped = ctx->fr[frame].dumped;
         if (dumped) {
-            dumpbuf.resize((size_t)N * 20);
+            dumpbuf.resize((size_t)N * pbytes);
             if ((status = vgen_read_dump(ctx, frame, dumpbuf.data(), dumpbuf.size())) != VGEN_OK) break;
         }
 
@@ -209,7 +210,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                     uint32_t lo = (uint32_t)((uint64_t)N * t / nt), hi = (uint32_t)((uint64_t)N * (t + 1) / nt);
                     vgen_generated g;
                     for (uint32_t i = lo; i < hi; i++)
-                        if (make_match(flt, cfg->format, batch_start, i, &dumpbuf[(size_t)i * 20], end, g))
+                        if (make_match(flt, cfg->format, batch_start, i, &dumpbuf[(size_t)i * pbytes], end, g))
                             part[t].push_back(g);
                 });
             for (auto &x : th) x.join();
