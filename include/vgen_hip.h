@@ -109,6 +109,18 @@ int vgen_filter_matches(const vgen_filter *f, const char *address);
  * prefilter; reference-equivalent host filtering), 1 = hash160 range test (Base58 prefixes),
  * 2 = masked-bits test (Bech32 / hex prefixes and suffixes), 3 = match-all. */
 int vgen_filter_device_kind(const vgen_filter *f);
+/* Pattern::validate_charset(format) (src/pattern.rs:49-177): the characters of `pattern` that can never
+ * occur in an address of `format` (literals outside classes; members of non-negated classes with no
+ * valid member), in order of first appearance.  Writes up to cap-1 characters + NUL into `out` and the
+ * full count into *n.  The caller warns "pattern will NEVER match" when *n > 0 (src/lib.rs:684-706). */
+int vgen_pattern_invalid_chars(const char *pattern, int case_insensitive, uint32_t format, char *out, size_t cap,
+                               size_t *n);
+/* Pattern::estimate_difficulty(format) (src/pattern.rs:183-253): "1 in N" heuristic = alphabet size
+ * (58 | 34 case-insensitive | 32 | 16) to the number of fixed alphanumeric pattern characters, less the
+ * characters of the format's constant prefix when the pattern is anchored on it; saturates at 2^64-1. */
+int vgen_pattern_difficulty(const char *pattern, int case_insensitive, uint32_t format, uint64_t *out);
+/* AddressFormat::charset_name (src/address.rs:39-45): "Base58" | "Bech32" | "Hex"; NULL for an unknown format. */
+const char *vgen_format_charset_name(uint32_t format);
 /* Selects the filter for subsequent dispatches; NULL = dump mode (every payload is written,
  * index order — the reference kernel's behaviour, src/shaders/search.wgsl:2-31). */
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
@@ -151,6 +163,21 @@ int vgen_key_add(const uint8_t key_be[32], uint64_t amount, uint8_t out_be[32]);
  * use and tests). address cap >= 96, wif cap >= 72. VGEN_E_RANGE for an invalid key. */
 int vgen_derive(uint32_t format, const uint8_t key_be[32], char *address, size_t acap, char *wif, size_t wcap);
 
+/* ---- provider patterns (src/provider.rs) -------------------------------------------------------------- */
+
+/* provider::resolve (src/provider.rs:12-52): "boha:b1000:66" / "boha:b1000/66" -> the puzzle's target
+ * address, its address format and (when known) its key range.  The reference reads puzzles from the
+ * un-vendored `boha` crate; this build has a static table — every b1000 puzzle's range (2^(N-1)..2^N-1)
+ * and the addresses the reference itself pins (puzzles 1 and 66) — extended by the optional CSV file
+ * `table_path` (rows "collection/id,address,kind[,start_hex,end_hex]", kind p2pkh|p2wpkh|p2tr|p2sh).
+ * Returns 1 = resolved, 0 = not a provider pattern (treat it as a regex), VGEN_E_INVALID = unknown
+ * puzzle / bad table (message in vgen_last_error(NULL)). */
+int vgen_provider_resolve(const char *pattern, const char *table_path, char *address, size_t acap, uint32_t *format,
+                          int32_t *has_range, uint8_t start_be[32], uint8_t end_be[32]);
+/* provider::build_pattern / build_exact_pattern (src/provider.rs:54-62): prefix_length 0 = the exact
+ * pattern "^address$", otherwise "^" + the first prefix_length characters (clamped); metacharacters escaped. */
+int vgen_provider_build_pattern(const char *address, uint32_t prefix_length, char *out, size_t cap);
+
 /* ---- scanner: scan_gpu_with_runner (src/gpu.rs:920-1125) ----------------------------------------------- */
 
 /* ScanConfig (src/scanner.rs:17-46) restricted to the fields the GPU path reads. */
@@ -169,6 +196,16 @@ typedef struct vgen_scan_config {
     uint32_t n_shards;       /* 0/1 = single device; >1: this context takes global batches b with
                                 b % n_shards == shard */
     uint64_t max_batches;    /* stop after this many dispatches per shard (0 = no limit) */
+    /* Build-side addition (the reference cannot resume): when non-NULL, the scan records the finished
+     * batches of every shard and the matches found in them in this file (rewritten atomically, at most
+     * every checkpoint_interval_ms and once when the scan returns) and, when the file already exists and
+     * describes the same scan (pattern, format, batch size, sharding, end, and the base key if start or
+     * seed pin it), resumes after the recorded batches, with the recorded matches counting towards
+     * `count`.  An unseeded random scan adopts the file's base key.  A file of a different scan is
+     * VGEN_E_INVALID. */
+    const char *checkpoint_path;
+    uint32_t checkpoint_interval_ms;   /* 0 = 10 s */
+    uint32_t reserved;
 } vgen_scan_config;
 
 /* GeneratedAddress (src/address.rs:63-72). */
@@ -184,8 +221,11 @@ typedef struct vgen_generated {
 typedef struct vgen_scan_result {
     vgen_generated *matches;  /* vgen_scan_result_free */
     uint64_t n_matches;
-    uint64_t operations;
+    uint64_t operations;      /* of this call */
     double elapsed_secs;
+    uint64_t resumed_operations;  /* operations recorded in the checkpoint this call resumed from (else 0) */
+    int32_t complete;         /* 1: the key range ran out (every shard reached `end` / the end of the key space) */
+    int32_t reserved;
 } vgen_scan_result;
 
 typedef void (*vgen_progress_cb)(uint64_t operations, void *user); /* ProgressCallback, scanner.rs:71 */

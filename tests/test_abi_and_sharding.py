@@ -92,3 +92,15 @@ def test_two_rank_batch_striping_equals_single_range_scan(tmp_path):
     ref = vo.scan_range(0, "^1[A-F]", k0, k0 + 6 * 2048 - 1, count=10**9, threads=2)
     assert got["ops"] == 6 * 2048 == ref["operations"]
     assert got["keys"] == [hex(m["key"]) for m in ref["matches"]]
+
+
+def test_cli_warns_about_impossible_patterns_before_touching_the_device():
+    """lib.rs:684-706.  Without a device the command then fails loudly (no CPU scan path in this build)."""
+    import subprocess
+    import vgen_amd as vg
+    exe = os.path.join(os.path.dirname(vg.library_path()), "vgen-hip")
+    out = subprocess.run([exe, "generate", "-p", "^bc1qB", "-f", "p2wpkh"], capture_output=True, text=True, timeout=60)
+    assert "Warning: Pattern contains characters not valid in Bech32 addresses: 'b1B'" in out.stderr
+    assert "Base58 excludes" not in out.stderr
+    out = subprocess.run([exe, "generate", "-p", "^1Cat"], capture_output=True, text=True, timeout=60)
+    assert "Warning" not in out.stderr

@@ -288,6 +288,28 @@ def test_cli_generate_and_range(vg, vo, tmp_path):
     assert out.stdout.strip() == vo.wif(target)
     out = subprocess.run([exe, "generate", "-p", "^1Cat", "--no-gpu"], capture_output=True, text=True)
     assert out.returncode != 0 and "no CPU" in out.stderr
+    # provider pattern: address + key range from the static table / a table file (provider.rs, lib.rs:599-631)
+    out = subprocess.run([exe, "range", "-p", "boha:b1000:1", "-o", "minimal", "--gpu-batch-size", "8192"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == vo.wif(1) and "exact match" in out.stderr
+    table = tmp_path / "puzzles.csv"
+    table.write_text("b1000/12,%s,p2pkh\n" % vo.generate(0, 2683)["address"])
+    out = subprocess.run([exe, "range", "-p", "boha:b1000:12", "-o", "minimal", "--gpu-batch-size", "8192",
+                          "--provider-table", str(table), "--checkpoint", str(tmp_path / "p12.ckpt")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == vo.wif(2683), out.stderr
+    assert "\nmatch=%064x\n" % 2683 in open(tmp_path / "p12.ckpt").read()
+    # estimate (lib.rs:345-375): difficulty heuristic over the measured device rate
+    out = subprocess.run([exe, "estimate", "-p", "^1Cat"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Estimated difficulty: 1 in %d\n" % 58 ** 3 in out.stdout and "Format: P2PKH\n" in out.stdout
+    rate = float([l for l in out.stdout.splitlines() if l.startswith("Benchmark rate:")][0].split()[2])
+    assert rate > 1e8                       # >= 100 Mkeys/s on one MI355X (BASELINE.json north_star)
+    # impossible pattern: the warning of lib.rs:684-706, then an (empty) bounded range scan
+    out = subprocess.run([exe, "range", "--range", "1:FFF", "-p", "^1O0", "-c", "0", "--gpu-batch-size", "8192"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "not valid in Base58 addresses: 'O0'" in out.stderr and "NEVER match" in out.stderr
+    assert "No match found after" in out.stderr and out.stdout == ""
 
 
 DFA_CASES = [
@@ -399,3 +421,76 @@ def test_p2tr_scan(vg, vo):
     d = vg.derive(3, 1)
     assert d.address == "bc1pmfr3p9j00pfxjh0zmgp99y8zftmd3s5pmedqhyptwy6lm87hf5sspknck9"
     r.close()
+
+
+# ---- resumable scans (vgen_scan_config.checkpoint_path) -----------------------------------
+
+
+def test_checkpointed_range_scan_resumes_where_it_stopped(vg, vo, tmp_path):
+    batch, lo, hi, pat = 8192, 1, 0x2FFFF, "^1[A-C]"
+    want = vo.scan_range(0, pat, lo, hi, count=10**9)["matches"]
+    assert len(want) > 50
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh)
+    ck = str(tmp_path / "scan.ckpt")
+    cfg = lambda **kw: vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=lo, end=hi, checkpoint_path=ck, **kw)
+    # interrupted after 5 batches
+    a = vg.scan_gpu_with_runner(pat, cfg(max_batches=5), r)
+    assert a.operations == 5 * batch and not a.complete and a.resumed_operations == 0
+    assert [m.hex for m in a.matches] == [x["hex"] for x in want if int(x["hex"], 16) < lo + 5 * batch]
+    text = open(ck).read()
+    assert text.startswith("vgen-hip checkpoint v1\n") and "\ndone=5\n" in text and "\ncomplete=0\n" in text
+    assert text.count("\nmatch=") == len(a.matches)
+    # a different scan must not pick the file up
+    with pytest.raises(vg.VgenError) as e:
+        vg.scan_gpu_with_runner("^1[A-D]", cfg(), r)
+    assert "does not belong to this scan (pattern)" in str(e.value)
+    with pytest.raises(vg.VgenError):
+        vg.scan_gpu_with_runner(pat, vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=lo + 1, end=hi,
+                                                   checkpoint_path=ck), r)
+    # resumed: 3 more batches, then to the end of the range
+    b = vg.scan_gpu_with_runner(pat, cfg(max_batches=3), r)
+    assert b.resumed_operations == 5 * batch and b.operations == 3 * batch and not b.complete
+    c = vg.scan_gpu_with_runner(pat, cfg(), r)
+    total_batches = (hi - lo + 1 + batch - 1) // batch
+    assert c.complete and c.resumed_operations == 8 * batch and c.operations == (total_batches - 8) * batch
+    assert [(m.address, m.wif, m.hex) for m in c.matches] == [(x["address"], x["wif"], x["hex"]) for x in want]
+    # a finished scan returns its result without touching the device again
+    d = vg.scan_gpu_with_runner(pat, cfg(), r)
+    assert d.complete and d.operations == 0 and [m.hex for m in d.matches] == [x["hex"] for x in want]
+    # count-limited: matches recorded earlier count towards `count`
+    ck2 = str(tmp_path / "count.ckpt")
+    cfg2 = lambda n, **kw: vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=n, start=lo, end=hi, checkpoint_path=ck2, **kw)
+    first = vg.scan_gpu_with_runner(pat, cfg2(3), r)
+    more = vg.scan_gpu_with_runner(pat, cfg2(3), r)
+    assert [m.hex for m in first.matches] == [x["hex"] for x in want[:3]] and more.operations == 0
+    assert [m.hex for m in more.matches] == [x["hex"] for x in want[:3]]
+    r.close()
+
+
+def test_checkpointed_striped_and_seeded_scans(vg, vo, tmp_path):
+    batch, lo, hi, pat = 8192, 1, 0x2FFFF, "^1[A-C]"
+    want = [x["hex"] for x in vo.scan_range(0, pat, lo, hi, count=10**9)["matches"]]
+    rs = [vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh) for _ in range(2)]
+    ck = str(tmp_path / "multi.ckpt")
+    cfg = lambda **kw: vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=lo, end=hi, checkpoint_path=ck,
+                                     checkpoint_interval_ms=1, **kw)
+    a = vg.scan_gpu_with_runner(pat, cfg(max_batches=4), rs)            # 4 batches per shard
+    assert a.operations == 8 * batch and not a.complete and "\ndone=4 4\n" in open(ck).read()
+    b = vg.scan_gpu_with_runner(pat, cfg(), rs)
+    assert b.complete and b.resumed_operations == 8 * batch and [m.hex for m in b.matches] == want
+    with pytest.raises(vg.VgenError):                                    # one context cannot resume a two-shard file
+        vg.scan_gpu_with_runner(pat, cfg(), rs[0])
+    # unseeded random scan: the resumed run adopts the base key of the file
+    ck3 = str(tmp_path / "random.ckpt")
+    rc = lambda **kw: vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, checkpoint_path=ck3, **kw)
+    vg.scan_gpu_with_runner("^1zzzzzzzz", rc(max_batches=2), rs[0])
+    base = [l for l in open(ck3).read().splitlines() if l.startswith("base=")][0]
+    x = vg.scan_gpu_with_runner("^1zzzzzzzz", rc(max_batches=2), rs[0])
+    assert x.resumed_operations == 2 * batch and base in open(ck3).read() and "\ndone=4\n" in open(ck3).read()
+    # seeded: pinned base; another seed is a different scan
+    ck4 = str(tmp_path / "seed.ckpt")
+    vg.scan_gpu_with_runner("^1zzzzzzzz", vg.ScanConfig(count=None, seed=5, max_batches=1, checkpoint_path=ck4), rs[0])
+    with pytest.raises(vg.VgenError):
+        vg.scan_gpu_with_runner("^1zzzzzzzz", vg.ScanConfig(count=None, seed=6, max_batches=1, checkpoint_path=ck4), rs[0])
+    for r in rs:
+        r.close()

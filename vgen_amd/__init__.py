@@ -12,8 +12,9 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .api import (AddressFormat, GeneratedAddress, GpuRunner, Pattern, ScanConfig, ScanResult, VgenError,
                   abi_version, address_from_payload, derive, device_count, device_name, key_add, key_to_wif,
-                  library_path, scan_gpu_with_runner)
+                  library_path, scan_gpu_with_runner, ProviderResult, provider_resolve, build_pattern, build_exact_pattern)
 
 __all__ = ["AddressFormat", "GeneratedAddress", "GpuRunner", "Pattern", "ScanConfig", "ScanResult", "VgenError",
            "abi_version", "address_from_payload", "derive", "device_count", "device_name", "key_add",
-           "key_to_wif", "library_path", "scan_gpu_with_runner"]
+           "key_to_wif", "library_path", "scan_gpu_with_runner", "ProviderResult", "provider_resolve", "build_pattern",
+           "build_exact_pattern"]

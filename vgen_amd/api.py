@@ -46,6 +46,10 @@ class AddressFormat(enum.IntEnum):
     P2pkhUncompressed = 4
     Ethereum = 5
 
+    def charset_name(self) -> str:
+        """AddressFormat::charset_name (src/address.rs:39-45)."""
+        return _L.vgen_format_charset_name(int(self)).decode()
+
 
 class _Params(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("batch_size", ctypes.c_uint32),
@@ -61,7 +65,9 @@ class _ScanConfig(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("format", ctypes.c_uint32), ("count", ctypes.c_uint64),
                 ("case_insensitive", ctypes.c_int32), ("has_start", ctypes.c_int32), ("start", ctypes.c_uint8 * 32),
                 ("has_end", ctypes.c_int32), ("end", ctypes.c_uint8 * 32), ("seed", ctypes.c_uint64),
-                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("max_batches", ctypes.c_uint64)]
+                ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("max_batches", ctypes.c_uint64),
+                ("checkpoint_path", ctypes.c_char_p), ("checkpoint_interval_ms", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
 
 
 class _Generated(ctypes.Structure):
@@ -71,7 +77,8 @@ class _Generated(ctypes.Structure):
 
 class _ScanResult(ctypes.Structure):
     _fields_ = [("matches", ctypes.POINTER(_Generated)), ("n_matches", ctypes.c_uint64),
-                ("operations", ctypes.c_uint64), ("elapsed_secs", ctypes.c_double)]
+                ("operations", ctypes.c_uint64), ("elapsed_secs", ctypes.c_double),
+                ("resumed_operations", ctypes.c_uint64), ("complete", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _PROGRESS = ctypes.CFUNCTYPE(None, ctypes.c_uint64, ctypes.c_void_p)
@@ -87,6 +94,15 @@ _L.vgen_filter_free.argtypes = [ctypes.c_void_p]
 _L.vgen_filter_free.restype = None
 _L.vgen_filter_matches.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
 _L.vgen_filter_device_kind.argtypes = [ctypes.c_void_p]
+_L.vgen_pattern_invalid_chars.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t,
+                                          ctypes.POINTER(ctypes.c_size_t)]
+_L.vgen_pattern_difficulty.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
+_L.vgen_format_charset_name.argtypes = [ctypes.c_uint32]
+_L.vgen_format_charset_name.restype = ctypes.c_char_p
+_L.vgen_provider_resolve.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                                     ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p,
+                                     ctypes.c_char_p]
+_L.vgen_provider_build_pattern.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_set_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 _L.vgen_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
 _L.vgen_dispatch_keys.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
@@ -190,10 +206,65 @@ class Pattern:
     def device_kind(self) -> int:
         return _L.vgen_filter_device_kind(self._h)
 
+    def validate_charset(self, fmt: Optional[AddressFormat] = None) -> List[str]:
+        """Pattern::validate_charset (src/pattern.rs:49-177): characters that can never occur in `fmt` addresses."""
+        fmt = self.format if fmt is None else fmt
+        buf, n = ctypes.create_string_buffer(260), ctypes.c_size_t()
+        _check(_L.vgen_pattern_invalid_chars(self.original.encode(), int(self.case_insensitive), int(fmt), buf, 260,
+                                             ctypes.byref(n)))
+        return list(buf.value.decode())
+
+    def estimate_difficulty(self, fmt: Optional[AddressFormat] = None) -> int:
+        """Pattern::estimate_difficulty (src/pattern.rs:183-253): 1 in N addresses is expected to match."""
+        fmt = self.format if fmt is None else fmt
+        d = ctypes.c_uint64()
+        _check(_L.vgen_pattern_difficulty(self.original.encode(), int(self.case_insensitive), int(fmt), ctypes.byref(d)))
+        return d.value
+
+    def is_case_insensitive(self) -> bool:
+        return self.case_insensitive
+
     def __del__(self):
         if getattr(self, "_h", None):
             _L.vgen_filter_free(self._h)
             self._h = None
+
+
+@dataclass
+class ProviderResult:
+    """ProviderResult (src/provider.rs:6-10)."""
+    address: str
+    format: AddressFormat
+    key_range: Optional[tuple] = None
+
+
+def provider_resolve(pattern: str, table_path: Optional[str] = None) -> Optional[ProviderResult]:
+    """provider::resolve (src/provider.rs:12-52): None when `pattern` is an ordinary regex."""
+    addr, fmt, has = ctypes.create_string_buffer(128), ctypes.c_uint32(), ctypes.c_int32()
+    lo, hi = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    rc = _L.vgen_provider_resolve(pattern.encode(), os.fsencode(table_path) if table_path else None, addr, 128,
+                                  ctypes.byref(fmt), ctypes.byref(has), lo, hi)
+    if rc == 0:
+        return None
+    _check(rc if rc < 0 else 0)
+    rng = (int.from_bytes(lo.raw, "big"), int.from_bytes(hi.raw, "big")) if has.value else None
+    return ProviderResult(addr.value.decode(), AddressFormat(fmt.value), rng)
+
+
+def build_pattern(result: ProviderResult, prefix_length: int) -> str:
+    """provider::build_pattern (src/provider.rs:54-58)."""
+    if prefix_length < 1:
+        raise ValueError("--prefix-length must be at least 1 for provider patterns")   # lib.rs:570-572
+    out = ctypes.create_string_buffer(300)
+    _check(_L.vgen_provider_build_pattern(result.address.encode(), prefix_length, out, 300))
+    return out.value.decode()
+
+
+def build_exact_pattern(result: ProviderResult) -> str:
+    """provider::build_exact_pattern (src/provider.rs:60-62)."""
+    out = ctypes.create_string_buffer(300)
+    _check(_L.vgen_provider_build_pattern(result.address.encode(), 0, out, 300))
+    return out.value.decode()
 
 
 @dataclass
@@ -209,6 +280,8 @@ class ScanConfig:
     shard: int = 0
     n_shards: int = 1
     max_batches: int = 0
+    checkpoint_path: Optional[str] = None      # resumable scans (vgen_scan_config.checkpoint_path)
+    checkpoint_interval_ms: int = 0
 
 
 @dataclass
@@ -216,6 +289,8 @@ class ScanResult:
     matches: List[GeneratedAddress] = field(default_factory=list)
     operations: int = 0
     elapsed_secs: float = 0.0
+    resumed_operations: int = 0     # operations recorded in the checkpoint this call resumed from
+    complete: bool = False          # the key range ran out
 
     def rate(self) -> float:   # src/scanner.rs:61-67
         return self.operations / self.elapsed_secs if self.elapsed_secs > 0 else 0.0
@@ -306,6 +381,9 @@ def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
         c.has_end = 1
         c.end = (ctypes.c_uint8 * 32)(*_key(config.end))
     c.seed, c.shard, c.n_shards, c.max_batches = config.seed, config.shard, config.n_shards, config.max_batches
+    if config.checkpoint_path:
+        c.checkpoint_path = os.fsencode(config.checkpoint_path)
+        c.checkpoint_interval_ms = config.checkpoint_interval_ms
     res = _ScanResult()
     cb = _PROGRESS(lambda ops, _u: progress_cb(ops)) if progress_cb else ctypes.cast(None, _PROGRESS)
     stop_p = ctypes.byref(stop) if stop is not None else None
@@ -315,7 +393,8 @@ def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
         arr = (ctypes.c_void_p * len(runners))(*[r._h for r in runners])
         rc = _L.vgen_scan_multi(arr, len(runners), pattern.encode(), ctypes.byref(c), cb, None, stop_p, ctypes.byref(res))
     _check(rc, runner._h)
-    out = ScanResult(operations=res.operations, elapsed_secs=res.elapsed_secs)
+    out = ScanResult(operations=res.operations, elapsed_secs=res.elapsed_secs,
+                     resumed_operations=res.resumed_operations, complete=bool(res.complete))
     for i in range(res.n_matches):
         g = res.matches[i]
         out.matches.append(GeneratedAddress(g.address.decode(), g.wif.decode(), g.hex.decode(), AddressFormat(g.format)))

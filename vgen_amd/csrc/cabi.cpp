@@ -7,6 +7,8 @@
 #include "../../include/vgen_hip.h"
 #include "host/encode.h"
 #include "host/filter.h"
+#include "host/pattern_info.h"
+#include "host/provider.h"
 #include "host/scalar.h"
 #include "runtime.h"
 
@@ -91,6 +93,55 @@ int vgen_filter_matches(const vgen_filter *f, const char *address) {
 }
 
 int vgen_filter_device_kind(const vgen_filter *f) { return f ? (int)f->dev.kind : VGEN_E_INVALID; }
+
+int vgen_pattern_invalid_chars(const char *pattern, int case_insensitive, uint32_t format, char *out, size_t cap,
+                               size_t *n) {
+    if (!pattern || !n || !vg::format_charset_name(format)) return VGEN_E_INVALID;
+    const std::string bad = vg::pattern_invalid_chars(pattern, case_insensitive != 0, format);
+    *n = bad.size();
+    if (out && cap) {
+        const size_t m = bad.size() < cap - 1 ? bad.size() : cap - 1;
+        memcpy(out, bad.data(), m);
+        out[m] = 0;
+    }
+    return VGEN_OK;
+}
+
+int vgen_pattern_difficulty(const char *pattern, int case_insensitive, uint32_t format, uint64_t *out) {
+    if (!pattern || !out || !vg::format_charset_name(format)) return VGEN_E_INVALID;
+    *out = vg::pattern_difficulty(pattern, case_insensitive != 0, format);
+    return VGEN_OK;
+}
+
+const char *vgen_format_charset_name(uint32_t format) { return vg::format_charset_name(format); }
+
+int vgen_provider_resolve(const char *pattern, const char *table_path, char *address, size_t acap, uint32_t *format,
+                          int32_t *has_range, uint8_t start_be[32], uint8_t end_be[32]) {
+    if (!pattern || !address || !format || !has_range || !start_be || !end_be) return VGEN_E_INVALID;
+    vg::ProviderResult r;
+    std::string err;
+    const int rc = vg::provider_resolve(pattern, table_path, r, err);
+    if (rc < 0) {
+        g_last_error = err;
+        return VGEN_E_INVALID;
+    }
+    if (rc == 0) return 0;
+    if (r.address.size() + 1 > acap) return VGEN_E_INVALID;
+    memcpy(address, r.address.c_str(), r.address.size() + 1);
+    *format = r.format;
+    *has_range = r.has_range ? 1 : 0;
+    memcpy(start_be, r.start, 32);
+    memcpy(end_be, r.end, 32);
+    return 1;
+}
+
+int vgen_provider_build_pattern(const char *address, uint32_t prefix_length, char *out, size_t cap) {
+    if (!address || !out) return VGEN_E_INVALID;
+    const std::string p = prefix_length ? vg::provider_build_pattern(address, prefix_length) : vg::provider_build_exact_pattern(address);
+    if (p.size() + 1 > cap) return VGEN_E_INVALID;
+    memcpy(out, p.c_str(), p.size() + 1);
+    return VGEN_OK;
+}
 
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f) {
     if (!ctx) return VGEN_E_INVALID;

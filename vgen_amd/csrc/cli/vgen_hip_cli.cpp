@@ -3,9 +3,9 @@
 // `verify` commands (src/lib.rs:44-211 flags, :642-663 range parsing, :524 count 0 = unbounded,
 // :825-865 --repeat, :879-974 writers, :1038-1086 formatting helpers).  SURVEY.md §8(f) item 1.
 //
-// Deliberately absent: the TUI, the boha provider, `estimate`, and any CPU scan path (`--no-gpu` is an
+// `estimate` (lib.rs:345-375) reports the device rate.  Provider patterns resolve against a static table (host/provider.cpp), not the boha crate.  Deliberately absent: the TUI and any CPU scan path (`--no-gpu` is an
 // error here: this build has no CPU backend).  Added: --seed (the reference seeds from OS entropy
-// only), --devices (batch-striped multi-GPU scan), --frames.
+// only), --devices (batch-striped multi-GPU scan), --frames, --checkpoint (resumable scans).
 #include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -27,11 +27,12 @@ void on_sigint(int) {
 }
 
 struct Opts {
-    std::string cmd, pattern, format = "p2pkh", output = "text", file, range, key, address, devices = "0";
+    std::string cmd, pattern, format = "p2pkh", output = "text", file, range, key, address, devices = "0", checkpoint, provider_table;
     bool has_pattern = false, ignore_case = false, quiet = false, json = false, no_gpu = false;
     uint64_t count = 1, repeat = 1, seed = 0;
     uint32_t batch = 1u << 20, frames = 6;
     int puzzle = 0;
+    long prefix_length = -1;   // -l / --prefix-length (provider patterns)
 };
 
 [[noreturn]] void die(const std::string &msg) {
@@ -146,7 +147,10 @@ void usage() {
             "vgen-hip — MI355X scan engine for the vgen hot path\n\n"
             "  vgen-hip generate -p PATTERN [-f FORMAT] [-i] [-c COUNT] [-o text|json|jsonl|csv|minimal] [--file PATH]\n"
             "                    [--gpu-batch-size N] [--repeat N] [-q] [--seed S] [--devices 0,1,..|all] [--frames F]\n"
+            "                    [--checkpoint FILE]   (resume an interrupted scan from FILE; written as the scan runs)\n"
+            "                    PATTERN may be a provider pattern boha:b1000:N [-l PREFIX_LENGTH] [--provider-table CSV]\n"
             "  vgen-hip range (--range START:END | --puzzle P) [-p PATTERN] [-f FORMAT] [-c COUNT (0 = whole range)] ...\n"
+            "  vgen-hip estimate -p PATTERN [-f FORMAT] [-i]\n"
             "  vgen-hip verify -k HEXKEY [-a ADDRESS]\n"
             "  vgen-hip list-gpus [--json]\n");
 }
@@ -177,6 +181,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "--seed") o.seed = strtoull(val().c_str(), nullptr, 10);
         else if (a == "--devices") o.devices = val();
         else if (a == "--frames") o.frames = (uint32_t)strtoul(val().c_str(), nullptr, 10);
+        else if (a == "--checkpoint") o.checkpoint = val();
         else if (a == "-r" || a == "--range") o.range = val();
         else if (a == "--puzzle") o.puzzle = atoi(val().c_str());
         else if (a == "-k" || a == "--key") o.key = val();
@@ -184,8 +189,9 @@ Opts parse(int argc, char **argv) {
         else if (a == "--json") o.json = true;
         else if (a == "--no-gpu") o.no_gpu = true;
         else if (a == "--no-tui" || a == "--tui") {}                                   // no TUI in this build
-        else if (a == "-t" || a == "--threads" || a == "--backend" || a == "--cpu-batch-size" || a == "-l" ||
-                 a == "--prefix-length") (void)val();                                  // accepted, not applicable
+        else if (a == "-l" || a == "--prefix-length") o.prefix_length = strtol(val().c_str(), nullptr, 10);
+        else if (a == "--provider-table") o.provider_table = val();
+        else if (a == "-t" || a == "--threads" || a == "--backend" || a == "--cpu-batch-size") (void)val();   // accepted, not applicable
         else if (a == "-h" || a == "--help") { usage(); exit(0); }
         else die("unexpected argument '" + a + "'");
     }
@@ -214,6 +220,100 @@ std::vector<int> parse_devices(const std::string &s) {
     return out;
 }
 
+// resolve_pattern_and_format / the provider half of resolve_range_params (src/lib.rs:563-590,599-631):
+// a "boha:..." pattern becomes the exact (or, with -l, prefix) pattern of the puzzle's address, selects the
+// address format and, for `range` without an explicit range, supplies the key range.
+struct Resolved {
+    std::string pattern;
+    bool from_provider = false, has_range = false;
+    uint8_t start[32], end[32];
+};
+
+Resolved resolve_provider(Opts &o, bool for_range) {
+    Resolved r;
+    r.pattern = o.pattern;
+    char addr[128];
+    uint32_t fmt = 0;
+    int32_t has_range = 0;
+    const char *table = !o.provider_table.empty() ? o.provider_table.c_str() : getenv("VGEN_PROVIDER_TABLE");
+    const int rc = vgen_provider_resolve(o.pattern.c_str(), table, addr, sizeof addr, &fmt, &has_range, r.start, r.end);
+    if (rc < 0) die(vgen_last_error(nullptr));
+    if (rc == 0) {
+        if (o.prefix_length >= 0 && !for_range) fprintf(stderr, "Warning: --prefix-length is ignored for regex patterns\n");
+        return r;
+    }
+    if (o.prefix_length == 0) die("--prefix-length must be at least 1 for provider patterns");
+    char pat[300];
+    vgen_provider_build_pattern(addr, o.prefix_length > 0 ? (uint32_t)o.prefix_length : 0, pat, sizeof pat);
+    if (o.prefix_length > 0 || !for_range) fprintf(stderr, "Provider: %s → %s → pattern '%s'\n", o.pattern.c_str(), addr, pat);
+    else fprintf(stderr, "Provider: %s → %s → exact match\n", o.pattern.c_str(), addr);
+    static const char *names[] = {"p2pkh", "p2wpkh", "p2sh-p2wpkh", "p2tr", "p2pkh-uncompressed", "ethereum"};
+    o.format = names[fmt];
+    r.pattern = pat;
+    r.from_provider = true;
+    r.has_range = has_range != 0;
+    return r;
+}
+
+// Warning for patterns that can never match (src/lib.rs:684-706).
+void warn_impossible_pattern(const std::string &pattern, bool ignore_case, int fmt) {
+    char bad[260];
+    size_t n = 0;
+    if (vgen_pattern_invalid_chars(pattern.c_str(), ignore_case, (uint32_t)fmt, bad, sizeof bad, &n) != VGEN_OK || n == 0) return;
+    const char *cs = vgen_format_charset_name((uint32_t)fmt);
+    fprintf(stderr, "Warning: Pattern contains characters not valid in %s addresses: '%s'\n", cs, bad);
+    fprintf(stderr, "  %s alphabet excludes these characters - pattern will NEVER match!\n", cs);
+    if (strcmp(cs, "Base58") == 0)
+        fprintf(stderr, "  Base58 excludes: 0 (zero), O (uppercase o), I (uppercase i), l (lowercase L)\n");
+    fprintf(stderr, "\n");
+}
+
+// `estimate` (src/lib.rs:345-375): difficulty heuristic over a measured rate.  The reference times its CPU
+// generator (scanner.rs:333-346); here the rate is that of this pattern's scan on the device, over a
+// bounded number of dispatches.
+int run_estimate(Opts &o) {
+    o.pattern = resolve_provider(o, false).pattern;
+    const int fmt = format_id(o.format);
+    vgen_filter *probe = nullptr;
+    if (vgen_filter_compile(o.pattern.c_str(), o.ignore_case, (uint32_t)fmt, &probe) != VGEN_OK) die(vgen_last_error(nullptr));
+    vgen_filter_free(probe);
+    uint64_t difficulty = 0;
+    vgen_pattern_difficulty(o.pattern.c_str(), o.ignore_case, (uint32_t)fmt, &difficulty);
+
+    std::vector<int> devs = parse_devices(o.devices);
+    vgen_params p;
+    memset(&p, 0, sizeof p);
+    p.struct_size = sizeof p;
+    p.device = devs[0];
+    p.batch_size = o.batch;
+    p.format = (uint32_t)fmt;
+    p.frames = o.frames;
+    vgen_ctx *c = nullptr;
+    if (vgen_create(&p, &c) != VGEN_OK) die(std::string("GPU initialization failed: ") + vgen_last_error(nullptr));
+    vgen_scan_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.format = (uint32_t)fmt;
+    cfg.count = UINT64_MAX;
+    cfg.case_insensitive = o.ignore_case;
+    cfg.seed = o.seed;
+    double rate = 0;
+    for (int pass = 0; pass < 2; pass++) {   // first pass warms the device up
+        cfg.max_batches = pass ? 96 : 12;
+        vgen_scan_result res;
+        if (vgen_scan(c, o.pattern.c_str(), &cfg, nullptr, nullptr, &g_stop, &res) != VGEN_OK) die(vgen_last_error(c));
+        rate = res.elapsed_secs > 0 ? (double)res.operations / res.elapsed_secs : 0.0;
+        vgen_scan_result_free(&res);
+    }
+    vgen_destroy(c);
+    printf("Pattern: %s\nFormat: %s\nCase insensitive: %s\n\n", o.pattern.c_str(), format_display(fmt),
+           o.ignore_case ? "true" : "false");
+    printf("Estimated difficulty: 1 in %llu\n", (unsigned long long)difficulty);
+    printf("Benchmark rate: %.0f addr/sec\n", rate);
+    printf("Expected time: %s\n", format_duration(rate > 0 ? (double)difficulty / rate : 0.0).c_str());
+    return 0;
+}
+
 int run_search(const Opts &o, const std::string &pattern, bool has_range, const uint8_t start[32], const uint8_t end[32]) {
     if (o.no_gpu) die("--no-gpu: this build has no CPU scan path (the MI355X engine is the only backend)");
     const int fmt = format_id(o.format);
@@ -221,6 +321,7 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
     vgen_filter *probe = nullptr;
     if (vgen_filter_compile(pattern.c_str(), o.ignore_case, (uint32_t)fmt, &probe) != VGEN_OK) die(vgen_last_error(nullptr));
     vgen_filter_free(probe);
+    warn_impossible_pattern(pattern, o.ignore_case, fmt);
 
     std::vector<int> devs = parse_devices(o.devices);
     std::vector<vgen_ctx *> ctxs;
@@ -249,6 +350,7 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         memcpy(cfg.start, start, 32);
         memcpy(cfg.end, end, 32);
     }
+    if (!o.checkpoint.empty()) cfg.checkpoint_path = o.checkpoint.c_str();   // resumable scan (not in the reference)
 
     std::vector<vgen_generated> all;
     uint64_t total_ops = 0;
@@ -314,6 +416,12 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
 
 }  // namespace
 
+const char *argv_pattern(int argc, char **argv) {
+    for (int i = 2; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "-p") || !strcmp(argv[i], "--pattern")) return argv[i + 1];
+    return "";
+}
+
 int main(int argc, char **argv) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);   // one hardware queue per frame stream; before HIP initialises
     Opts o = parse(argc, argv);
@@ -321,11 +429,25 @@ int main(int argc, char **argv) {
     if (o.cmd == "generate") {
         if (!o.has_pattern) die("the following required arguments were not provided: --pattern <PATTERN>");
         uint8_t z[32] = {0};
-        return run_search(o, o.pattern, false, z, z);
+        const Resolved r = resolve_provider(o, false);
+        return run_search(o, r.pattern, false, z, z);
+    }
+    if (o.cmd == "estimate") {
+        if (!o.has_pattern) die("the following required arguments were not provided: --pattern <PATTERN>");
+        return run_estimate(o);
     }
     if (o.cmd == "range") {
         uint8_t start[32], end[32];
-        if (o.puzzle) {   // lib.rs:643-649
+        Resolved pr;
+        if (o.has_pattern) {
+            pr = resolve_provider(o, true);
+            o.pattern = pr.pattern;
+        }
+        if (pr.from_provider && !o.puzzle && o.range.empty()) {   // the provider's own key range, lib.rs:623-631
+            if (!pr.has_range) die("Provider '" + std::string(argv_pattern(argc, argv)) + "' has no key range. Use --range or --puzzle to specify range.");
+            memcpy(start, pr.start, 32);
+            memcpy(end, pr.end, 32);
+        } else if (o.puzzle) {   // lib.rs:643-649
             if (o.puzzle < 1 || o.puzzle > 160) die("Puzzle number must be between 1 and 160");
             memset(start, 0, 32);
             memset(end, 0, 32);

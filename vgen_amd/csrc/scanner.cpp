@@ -92,6 +92,160 @@ bool make_match(const vgen_filter &flt, uint32_t format, const Scalar &batch_sta
     return true;
 }
 
+bool generated_from_key(uint32_t format, const uint8_t kb[32], vgen_generated &g) {
+    uint8_t payload[32];
+    if (!payload_from_key(format, kb, payload)) return false;
+    memset(&g, 0, sizeof g);
+    std::string addr = address_from_payload(format, payload), wif = key_to_wif(format, kb), hex = hex_lower(kb, 32);
+    strncpy(g.address, addr.c_str(), sizeof g.address - 1);
+    strncpy(g.wif, wif.c_str(), sizeof g.wif - 1);
+    strncpy(g.hex, hex.c_str(), sizeof g.hex - 1);
+    g.format = format;
+    memcpy(g.key, kb, 32);
+    return true;
+}
+
+// Checkpoint of one scan (the reference has none): which batches of every shard are
+// finished, and the matches found in them, so that an interrupted range / seeded scan resumes where it
+// stopped instead of from its first key.  A batch is committed — its matches appended and its shard's
+// counter advanced — under one lock, so every file written is a consistent prefix of the scan.  Shards
+// process their batches in dispatch order, so "batches done" is a single number per shard.
+//
+// File (text, rewritten atomically through <path>.tmp + rename):
+//   vgen-hip checkpoint v1 / pattern_hex= / case_insensitive= / format= / batch_size= / n_shards= /
+//   first_shard= / base= / end= / operations= / done=<per slot> / complete= / match=<key hex> ...
+struct Checkpoint {
+    std::string path;
+    std::string pattern;
+    int ci = 0;
+    uint32_t format = 0, batch = 0, n_shards = 1, first_shard = 0;
+    uint8_t base[32] = {0}, end[32] = {0};
+    bool has_end = false;
+    double interval_s = 10.0;
+
+    std::mutex mu;
+    std::vector<uint64_t> done;            // per slot (slot = shard - first_shard)
+    std::vector<vgen_generated> ledger;    // matches of committed batches, commit order
+    uint64_t operations = 0;               // over all runs
+    uint64_t resumed_operations = 0;       // as loaded
+    bool complete = false;
+    std::chrono::steady_clock::time_point last_write = std::chrono::steady_clock::now();
+    std::string error;
+
+    static std::string hex(const uint8_t *p, size_t n) { return hex_lower(p, n); }
+    static bool unhex(const std::string &s, std::vector<uint8_t> &out) {
+        if (s.size() % 2) return false;
+        out.clear();
+        for (size_t i = 0; i < s.size(); i += 2) {
+            unsigned v;
+            if (!isxdigit((unsigned char)s[i]) || !isxdigit((unsigned char)s[i + 1]) || sscanf(s.c_str() + i, "%2x", &v) != 1)
+                return false;
+            out.push_back((uint8_t)v);
+        }
+        return true;
+    }
+
+    // Loads `path` when it exists and checks that it describes this very scan.  `pin_base`: the caller
+    // fixed the base key (config.start or a seed); otherwise the file's base key is adopted.
+    // returns 1 = resumed, 0 = no file (fresh scan), -1 = error (see `error`).
+    int load(bool pin_base) {
+        FILE *f = fopen(path.c_str(), "r");
+        if (!f) return 0;
+        std::vector<std::pair<std::string, std::string>> kv;
+        char line[4096];
+        bool header = false;
+        while (fgets(line, sizeof line, f)) {
+            std::string s(line);
+            while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+            if (!header) {
+                if (s != "vgen-hip checkpoint v1") break;
+                header = true;
+                continue;
+            }
+            size_t eq = s.find('=');
+            if (eq != std::string::npos) kv.emplace_back(s.substr(0, eq), s.substr(eq + 1));
+        }
+        fclose(f);
+        if (!header) return bad("not a vgen-hip checkpoint file");
+        auto get = [&](const char *k) -> const std::string * {
+            for (auto &e : kv)
+                if (e.first == k) return &e.second;
+            return nullptr;
+        };
+        auto differs = [&](const char *k, const std::string &want) {
+            const std::string *v = get(k);
+            return !v || *v != want;
+        };
+        if (differs("pattern_hex", hex((const uint8_t *)pattern.data(), pattern.size()))) return bad("pattern");
+        if (differs("case_insensitive", std::to_string(ci))) return bad("case_insensitive");
+        if (differs("format", std::to_string(format))) return bad("format");
+        if (differs("batch_size", std::to_string(batch))) return bad("batch_size");
+        if (differs("n_shards", std::to_string(n_shards))) return bad("n_shards");
+        if (differs("first_shard", std::to_string(first_shard))) return bad("first_shard");
+        if (differs("end", has_end ? hex(end, 32) : "none")) return bad("end");
+        std::vector<uint8_t> b;
+        const std::string *bs = get("base");
+        if (!bs || !unhex(*bs, b) || b.size() != 32) return bad("base");
+        if (pin_base && memcmp(b.data(), base, 32) != 0) return bad("base");
+        memcpy(base, b.data(), 32);
+        const std::string *d = get("done"), *o = get("operations"), *c = get("complete");
+        if (!d || !o || !c) return bad("done/operations/complete");
+        std::vector<uint64_t> dn;
+        const char *p = d->c_str();
+        while (*p) {
+            char *e;
+            dn.push_back(strtoull(p, &e, 10));
+            if (e == p) return bad("done");
+            p = e;
+            while (*p == ' ') p++;
+        }
+        if (dn.size() != done.size()) return bad("done (slot count)");
+        done = dn;
+        operations = resumed_operations = strtoull(o->c_str(), nullptr, 10);
+        complete = *c == "1";
+        for (auto &e : kv) {
+            if (e.first != "match") continue;
+            vgen_generated g;
+            if (!unhex(e.second, b) || b.size() != 32 || !generated_from_key(format, b.data(), g)) return bad("match");
+            ledger.push_back(g);
+        }
+        return 1;
+    }
+    int bad(const char *field) {
+        error = "checkpoint file '" + path + "' does not belong to this scan (" + field + ")";
+        return -1;
+    }
+
+    // caller holds mu
+    bool write_locked() {
+        const std::string tmp = path + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "w");
+        if (!f) return false;
+        fprintf(f, "vgen-hip checkpoint v1\npattern_hex=%s\ncase_insensitive=%d\nformat=%u\nbatch_size=%u\nn_shards=%u\n"
+                   "first_shard=%u\nbase=%s\nend=%s\noperations=%llu\ndone=",
+                hex((const uint8_t *)pattern.data(), pattern.size()).c_str(), ci, format, batch, n_shards, first_shard,
+                hex(base, 32).c_str(), has_end ? hex(end, 32).c_str() : "none", (unsigned long long)operations);
+        for (size_t i = 0; i < done.size(); i++) fprintf(f, "%s%llu", i ? " " : "", (unsigned long long)done[i]);
+        fprintf(f, "\ncomplete=%d\n", complete ? 1 : 0);
+        for (auto &g : ledger) fprintf(f, "match=%s\n", hex(g.key, 32).c_str());
+        bool ok = fflush(f) == 0;
+        ok = (fclose(f) == 0) && ok;
+        ok = ok && rename(tmp.c_str(), path.c_str()) == 0;
+        last_write = std::chrono::steady_clock::now();
+        return ok;
+    }
+
+    // One finished batch of `slot`: its matches and the shard's counter move together.
+    void commit(uint32_t slot, const std::vector<vgen_generated> &batch_matches, uint64_t ops) {
+        std::lock_guard<std::mutex> g(mu);
+        ledger.insert(ledger.end(), batch_matches.begin(), batch_matches.end());
+        done[slot]++;
+        operations += ops;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - last_write).count() >= interval_s)
+            (void)write_locked();
+    }
+};
+
 }  // namespace
 }  // namespace vg
 
@@ -100,10 +254,13 @@ using namespace vg;
 namespace {
 
 // One shard of a scan on one context.  `shared_found` (optional) is the match counter shared by the
-// shards of a multi-device scan; without it the shard counts its own matches.
+// shards of a multi-device scan; without it the shard counts its own matches.  `ck` (optional): the
+// scan's checkpoint; this shard is its slot `ck_slot`, skips the batches already recorded there and
+// commits each batch it finishes.  *range_done: the shard stopped because its range ran out.
 int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cfg, vgen_progress_cb cb, void *user,
                volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
-               std::vector<vgen_generated> &matches, uint64_t &total_ops) {
+               std::vector<vgen_generated> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
+               bool *range_done = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
 
     const uint32_t N = ctx->batch;
@@ -139,12 +296,22 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     bool exhausted = false;
     if (shard) exhausted = scalar_add_u64(current, current, (uint64_t)shard * N) || !scalar_is_valid(current);
     const uint64_t stride = (uint64_t)shards * N;
+    if (ck && !exhausted) {   // resume: this shard's first `skip` batches are already in the checkpoint
+        uint64_t skip = ck->done[ck_slot];
+        while (skip && !exhausted) {
+            const uint64_t step = std::min<uint64_t>(skip, UINT64_MAX / stride);
+            exhausted = scalar_add_u64(current, current, step * stride) || !scalar_is_valid(current);
+            skip -= step;
+        }
+    }
 
     uint64_t dispatched = 0;
     total_ops = 0;
     auto found = [&]() -> uint64_t { return shared_found ? shared_found->load(std::memory_order_relaxed) : matches.size(); };
+    std::vector<vgen_generated> batch_matches;   // matches of the batch being processed (checkpoint commit unit)
     auto push = [&](const vgen_generated &g) {
         matches.push_back(g);
+        if (ck) batch_matches.push_back(g);
         if (shared_found) shared_found->fetch_add(1, std::memory_order_relaxed);
     };
     const uint64_t count = cfg->count;
@@ -243,6 +410,10 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         }
 
         total_ops += N;                              // gpu.rs:1106
+        if (ck) {
+            ck->commit(ck_slot, batch_matches, N);
+            batch_matches.clear();
+        }
         if (cb) cb(shared_ops ? shared_ops->fetch_add(N) + N : total_ops, user);
         if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
         frame = (frame + 1) % nf;
@@ -250,7 +421,42 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
     for (uint32_t f = 0; f < nf; f++)
         if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
+    if (range_done) *range_done = status == VGEN_OK && !in_range();
     return status;
+}
+
+// The base key of a scan without config.start: seeded or drawn from OS entropy.
+void resolve_base(vgen_scan_config &c) {
+    if (c.has_start) return;
+    Scalar k;
+    if (c.seed) seed_key(c.seed, 0, k);
+    else random_valid_key(k);
+    scalar_to_be(k, c.start);
+    c.has_start = 1;
+}
+
+// Sets up the checkpoint of a scan over `slots` shards starting at shard `first_shard`; resumes from the
+// file when there is one (adopting its base key for an unseeded random scan).  VGEN_OK / error.
+int open_checkpoint(vgen_ctx *ctx, Checkpoint &ck, const char *pattern, vgen_scan_config &c, uint32_t batch, uint32_t n_shards,
+                    uint32_t first_shard, uint32_t slots) {
+    const bool pin_base = c.has_start || c.seed;
+    resolve_base(c);
+    ck.path = c.checkpoint_path;
+    ck.pattern = pattern;
+    ck.ci = c.case_insensitive != 0;
+    ck.format = c.format;
+    ck.batch = batch;
+    ck.n_shards = n_shards;
+    ck.first_shard = first_shard;
+    memcpy(ck.base, c.start, 32);
+    ck.has_end = c.has_end != 0;
+    if (ck.has_end) memcpy(ck.end, c.end, 32);
+    if (c.checkpoint_interval_ms) ck.interval_s = c.checkpoint_interval_ms / 1000.0;
+    ck.done.assign(slots, 0);
+    const int r = ck.load(pin_base);
+    if (r < 0) return ctx->fail(VGEN_E_INVALID, ck.error);
+    memcpy(c.start, ck.base, 32);
+    return VGEN_OK;
 }
 
 int finish_result(vgen_ctx *ctx, std::vector<vgen_generated> &matches, uint64_t ops, double secs, vgen_scan_result *out) {
@@ -278,8 +484,29 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
         return ctx->fail(VGEN_E_PATTERN, err);
     std::vector<vgen_generated> matches;
     uint64_t ops = 0;
-    int rc = scan_shard(ctx, flt, cfg, cb, user, stop, nullptr, nullptr, matches, ops);
+    bool range_done = false;
+    if (!cfg->checkpoint_path) {
+        int rc = scan_shard(ctx, flt, cfg, cb, user, stop, nullptr, nullptr, matches, ops, nullptr, 0, &range_done);
+        if (rc != VGEN_OK) return rc;
+        out->complete = range_done;
+        return finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+    }
+    vgen_scan_config c = *cfg;
+    Checkpoint ck;
+    const uint32_t shards = c.n_shards > 1 ? c.n_shards : 1;
+    int rc = open_checkpoint(ctx, ck, pattern, c, ctx->batch, shards, c.n_shards > 1 ? c.shard : 0, 1);
     if (rc != VGEN_OK) return rc;
+    matches = ck.ledger;   // what earlier runs found counts towards `count`
+    if (!ck.complete && matches.size() < c.count)
+        rc = scan_shard(ctx, flt, &c, cb, user, stop, nullptr, nullptr, matches, ops, &ck, 0, &range_done);
+    {
+        std::lock_guard<std::mutex> g(ck.mu);
+        ck.complete = ck.complete || (rc == VGEN_OK && range_done);
+        if (!ck.write_locked() && rc == VGEN_OK) rc = ctx->fail(VGEN_E_INVALID, "cannot write checkpoint file '" + ck.path + "'");
+    }
+    if (rc != VGEN_OK) return rc;
+    out->complete = ck.complete;
+    out->resumed_operations = ck.resumed_operations;
     return finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
 }
 
@@ -298,14 +525,19 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     if (!filter_compile(pattern, cfg->case_insensitive != 0, cfg->format, flt, err))
         return ctxs[0]->fail(VGEN_E_PATTERN, err);
     vgen_scan_config base = *cfg;
-    if (!base.has_start) {   // all shards must walk the same base key
-        Scalar k;
-        if (base.seed) seed_key(base.seed, 0, k);
-        else random_valid_key(k);
-        scalar_to_be(k, base.start);
-        base.has_start = 1;
+    Checkpoint ck;
+    Checkpoint *ckp = nullptr;
+    if (cfg->checkpoint_path) {
+        int rc = open_checkpoint(ctxs[0], ck, pattern, base, ctxs[0]->batch, n_ctx, 0, n_ctx);
+        if (rc != VGEN_OK) return rc;
+        ckp = &ck;
+    } else {
+        resolve_base(base);   // all shards must walk the same base key
     }
     std::atomic<uint64_t> found{0}, ops_shared{0};
+    std::vector<char> range_done(n_ctx, 0);
+    if (ckp) found = ck.ledger.size();
+    const bool skip_all = ckp && (ck.complete || ck.ledger.size() >= cfg->count);
     std::vector<std::vector<vgen_generated>> part(n_ctx);
     std::vector<uint64_t> ops(n_ctx, 0);
     std::vector<int> rcs(n_ctx, VGEN_OK);
@@ -317,21 +549,34 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
         std::lock_guard<std::mutex> g(*c->mu);
         c->cb(o, c->user);
     };
-    for (uint32_t i = 0; i < n_ctx; i++)
+    for (uint32_t i = 0; i < n_ctx && !skip_all; i++)
         th.emplace_back([&, i]() {
             vgen_scan_config c = base;
             c.shard = i;
             c.n_shards = n_ctx;
+            bool rd = false;
             rcs[i] = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
-                                part[i], ops[i]);
+                                part[i], ops[i], ckp, i, &rd);
+            range_done[i] = rd;
         });
     for (auto &x : th) x.join();
+    bool all_done = !skip_all;
+    for (uint32_t i = 0; i < n_ctx; i++) all_done = all_done && rcs[i] == VGEN_OK && range_done[i];
+    if (ckp) {
+        std::lock_guard<std::mutex> g(ck.mu);
+        ck.complete = ck.complete || all_done;
+        if (!ck.write_locked() && rcs[0] == VGEN_OK)
+            rcs[0] = ctxs[0]->fail(VGEN_E_INVALID, "cannot write checkpoint file '" + ck.path + "'");
+        out->resumed_operations = ck.resumed_operations;
+    }
     for (uint32_t i = 0; i < n_ctx; i++)
         if (rcs[i] != VGEN_OK) return rcs[i];
+    out->complete = ckp ? ck.complete : all_done;
     std::vector<vgen_generated> all;
     uint64_t total = 0;
+    if (ckp) all = ck.ledger;   // earlier runs' matches + every batch committed by this one
     for (uint32_t i = 0; i < n_ctx; i++) {
-        all.insert(all.end(), part[i].begin(), part[i].end());
+        if (!ckp) all.insert(all.end(), part[i].begin(), part[i].end());
         total += ops[i];
     }
     std::sort(all.begin(), all.end(), [](const vgen_generated &a, const vgen_generated &b) { return memcmp(a.key, b.key, 32) < 0; });
