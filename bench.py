@@ -104,10 +104,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
+    # VGEN_BENCH_REHEARSE=1: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share
+    # devices, barrier / max over gloo).  Never the measured configuration: one rank per GPU over RCCL is.
+    rehearse = world > 1 and os.environ.get("VGEN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import vgen_amd as vg
     fmt = vg.AddressFormat(FORMATS[args.format])
@@ -153,7 +161,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -178,7 +186,8 @@ def main():
         "data": "synthetic (sequential scalars from k0 = SHA-256('vgen-mi355x'||seed=42||shard=0) mod n)",
         "config": {"workload": f"{args.format} pattern {args.pattern!r}{' -i' if args.ci else ''}, "
                                f"{N} keys/dispatch, compressed pubkey, sequential-range mode",
-                   "keys_per_dispatch": N, "frames_in_flight": F, "parallelism": f"range-striped x{world}",
+                   "keys_per_dispatch": N, "frames_in_flight": F,
+                   "parallelism": f"range-striped x{world}" + (" (REHEARSAL: ranks share a GPU)" if rehearse else ""),
                    "device_filter_kind": pat.device_kind, "candidates_reported": cand},
         "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1),
                      "unit": "Tlaneop/s", "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": traffic,

@@ -24,10 +24,13 @@
 constexpr int CHAINS = 8;    // independent dependency chains per lane
 constexpr int UNROLL = 32;   // ops per chain per loop trip
 
-enum Op { ADD, ADDC, ADD3, MUL_LO, MUL_HI, MAD64, MAD24, MULHI24, ROTXOR, BFI, XOR3, FMA32, FMA64, LSHLADD, PERM, XOR, LSHLADD64, ADDCO };
+enum Op { ADD, ADDC, ADD3, MUL_LO, MUL_HI, MAD64, MAD24, MULHI24, ROTXOR, BFI, XOR3, FMA32, FMA64, LSHLADD, PERM, XOR, LSHLADD64, ADDCO, LSHR64, LSHL64, AND, LSHR32, MOV, BFE, ANDOR, LSHLOR, CNDMASK, MULU24, MADCHAIN };
 
 template <int OP>
-__global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int iters) {
+__global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int iters, unsigned long long *clk) {
+    // shader-clock (s_memtime) and constant 100 MHz (s_memrealtime) stamps around the loop: their ratio is the
+    // clock the SIMDs really ran at under this instruction mix (power management lowers it below the nominal 2.4 GHz)
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     uint32_t x[CHAINS], y = seed | 1, z = seed * 2654435761u + 12345u;
     uint64_t acc[CHAINS];
     float f[CHAINS];
@@ -69,6 +72,17 @@ __global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int
                 if (OP == XOR) A3("v_xor_b32");
                 if (OP == LSHLADD64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[c]) : "v"(acc[(c + 1) % CHAINS]));
                 if (OP == ADDCO) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(x[c]) : "v"(y) : "vcc");
+                if (OP == LSHR64) asm volatile("v_lshrrev_b64 %0, 29, %1" : "=v"(acc[c]) : "v"(acc[(c + 1) % CHAINS]));
+                if (OP == LSHL64) asm volatile("v_lshlrev_b64 %0, 8, %1" : "=v"(acc[c]) : "v"(acc[(c + 1) % CHAINS]));
+                if (OP == AND) A3("v_and_b32");
+                if (OP == LSHR32) asm volatile("v_lshrrev_b32 %0, 29, %1" : "=v"(x[c]) : "v"(x[(c + 1) % CHAINS]));
+                if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(x[c]) : "v"(x[(c + 1) % CHAINS]));
+                if (OP == BFE) asm volatile("v_bfe_u32 %0, %1, 3, 29" : "=v"(x[c]) : "v"(x[(c + 1) % CHAINS]));
+                if (OP == ANDOR) A4("v_and_or_b32");
+                if (OP == LSHLOR) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x[c]) : "v"(y));
+                if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(y) : "vcc");
+                if (OP == MULU24) A3("v_mul_u32_u24");
+                if (OP == MADCHAIN) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(x[c]), "v"(y) : "vcc");
             }
         }
     }
@@ -76,6 +90,10 @@ __global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int
 #pragma unroll
     for (int c = 0; c < CHAINS; c++) r ^= x[c] ^ (uint32_t)acc[c] ^ (uint32_t)(acc[c] >> 32) ^ __float_as_uint(f[c]) ^ (uint32_t)__double_as_longlong(d[c]);
     if (r == 0x12345678u) out[blockIdx.x * blockDim.x + threadIdx.x] = r;  // practically never
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = clock64() - c0;
+        clk[1] = wall_clock64() - w0;
+    }
 }
 
 template <int OP>
@@ -87,10 +105,12 @@ static double run(const char *name, int waves_per_simd, int iters, uint32_t *dou
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_bench<OP>, dim3(blocks), dim3(256), 0, 0, dout, 12345u, iters / 8);  // warm-up
+    static unsigned long long *dclk = nullptr;
+    if (!dclk) CHECK(hipMalloc(&dclk, 16));
+    hipLaunchKernelGGL(k_bench<OP>, dim3(blocks), dim3(256), 0, 0, dout, 12345u, iters / 8, dclk);  // warm-up
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_bench<OP>, dim3(blocks), dim3(256), 0, 0, dout, 12345u, iters);
+    hipLaunchKernelGGL(k_bench<OP>, dim3(blocks), dim3(256), 0, 0, dout, 12345u, iters, dclk);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -100,8 +120,13 @@ static double run(const char *name, int waves_per_simd, int iters, uint32_t *dou
     // cycles per wave-instruction per SIMD at 2.4 GHz nominal
     double wave_instr_per_simd = (double)waves_per_simd * iters * UNROLL * CHAINS * instr_per_op;
     double cyc = (ms * 1e-3 * 2.4e9) / wave_instr_per_simd;
-    printf("{\"op\":\"%s\",\"waves_per_simd\":%d,\"ms\":%.3f,\"Tlaneops\":%.2f,\"cyc_per_waveinstr_at_2.4GHz\":%.2f}\n",
-           name, waves_per_simd, ms, tops, cyc);
+    unsigned long long clk[2];
+    CHECK(hipMemcpy(clk, dclk, 16, hipMemcpyDeviceToHost));
+    const double mhz = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0;   // s_memrealtime ticks at 100 MHz
+    const double true_cyc = (double)clk[0] / ((double)waves_per_simd * iters * UNROLL * CHAINS * instr_per_op);
+    printf("{\"op\":\"%s\",\"waves_per_simd\":%d,\"ms\":%.3f,\"Tlaneops\":%.2f,\"cyc_per_waveinstr_at_2.4GHz\":%.2f,"
+           "\"shader_mhz\":%.0f,\"shader_cycles_per_waveinstr\":%.2f}\n",
+           name, waves_per_simd, ms, tops, cyc, mhz, true_cyc);
     fflush(stdout);
     return tops;
 }
@@ -114,7 +139,7 @@ int main(int argc, char **argv) {
     CHECK(hipGetDeviceProperties(&prop, 0));
     printf("{\"device\":\"%s\",\"cus\":%d,\"clock_khz\":%d,\"lds_per_block\":%zu,\"regs_per_block\":%d}\n", prop.name,
            prop.multiProcessorCount, prop.clockRate, prop.sharedMemPerBlock, prop.regsPerBlock);
-    int ws[] = {1, 2, 4, 8};
+    int ws[] = {1, 4, 8};
     for (int w : ws) {
         run<ADD>("v_add_u32", w, iters, dout, 1);
         run<ADDC>("add64(v_add_co+v_addc)", w, iters, dout, 2);
@@ -134,6 +159,17 @@ int main(int argc, char **argv) {
         run<PERM>("v_perm_b32", w, iters, dout, 1);
         run<FMA32>("v_pk_fma_f32(2 fma/instr)", w, iters, dout, 0.5);
         run<FMA64>("v_fma_f64", w, iters, dout, 1);
+        run<LSHR64>("v_lshrrev_b64", w, iters, dout, 1);
+        run<LSHL64>("v_lshlrev_b64", w, iters, dout, 1);
+        run<AND>("v_and_b32", w, iters, dout, 1);
+        run<LSHR32>("v_lshrrev_b32", w, iters, dout, 1);
+        run<MOV>("v_mov_b32", w, iters, dout, 1);
+        run<BFE>("v_bfe_u32", w, iters, dout, 1);
+        run<ANDOR>("v_and_or_b32", w, iters, dout, 1);
+        run<LSHLOR>("v_lshl_or_b32", w, iters, dout, 1);
+        run<CNDMASK>("v_cndmask_b32", w, iters, dout, 1);
+        run<MULU24>("v_mul_u32_u24", w, iters, dout, 1);
+        run<MADCHAIN>("v_mad_u64_u32(single dependent chain)", w, iters, dout, 1);
     }
     CHECK(hipFree(dout));
     return 0;

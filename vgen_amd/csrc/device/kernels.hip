@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 // key's address is encoded and matched on the device (core/dfa_eval.h).  A separate instantiation so
 // that the extra registers of the Base58Check path do not touch the prefilter kernels' occupancy.
 template <int FMT, bool FULL>
-__global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
     extern __shared__ u32 dyn_lds[];   // [P2TR: fixed-window generator table][FULL: DFA blob]
     constexpr int NW = PayloadWords<FMT>::value;
@@ -229,14 +229,12 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
         fe_mul(inv, ip, sib);
     }
 
-    fe rx, ry, nrx, nry;
+    fe rx, ry;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         rx.n[i] = args.rtab[(size_t)i * lanes + u];
         ry.n[i] = args.rtab[(size_t)(9 + i) * lanes + u];
     }
-    fe_neg(nrx, rx, 1);   // magnitude 2
-    fe_neg(nry, ry, 1);
 
     const u32 half = args.n >> 1;
     const bool dump = args.dump != nullptr;
@@ -256,18 +254,28 @@ __global__ void __launch_bounds__(WG) seq_bwd_kernel(const SeqArgs args) {
         } else {
             idx = inv;
         }
-        fe nsum, nqy;   // -(R.x + Q.x) (magnitude 3) and -Q.y, shared by the +R and -R results
+        // -R.x and -R.y are recomputed where needed (9 subtractions each) instead of living in 18 registers
+        // across the loop; the empty asm keeps the compiler from hoisting them back out as loop invariants.
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            nsum.n[i] = nrx.n[i] + q.nqx[i];
+            asm volatile("" : "+v"(rx.n[i]));
+            asm volatile("" : "+v"(ry.n[i]));
+        }
+        fe nsum, nqy;   // -(R.x + Q.x) (magnitude 3) and -Q.y, shared by the +R and -R results
+        fe_neg(nsum, rx, 1);
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            nsum.n[i] += q.nqx[i];
             nqy.n[i] = q.nqy[i];
         }
 #pragma unroll 1
         for (int sgn = 0; sgn < 2; sgn++) {
             // +R: dy = R.y - Q.y ; -R: dy = -R.y - Q.y
             fe dy, lam, x3, t, y3;
+            if (sgn) fe_neg(dy, ry, 1);
+            else dy = ry;
 #pragma unroll
-            for (int i = 0; i < 9; i++) dy.n[i] = (sgn ? nry.n[i] : ry.n[i]) + q.nqy[i];   // magnitude <= 3
+            for (int i = 0; i < 9; i++) dy.n[i] += q.nqy[i];   // magnitude <= 3
             fe_mul(lam, dy, idx);
             fe_sqr_add(x3, lam, nsum);            // lam^2 - R.x - Q.x, weakly normalised
             fe_canonicalize(x3);
