@@ -8,7 +8,7 @@ There is no CPU fallback: importing works anywhere, creating a GpuRunner needs a
 import os as _os
 
 # one hardware queue per frame stream; read by the HIP runtime when it initialises
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from .api import (AddressFormat, GeneratedAddress, GpuRunner, Pattern, ScanConfig, ScanResult, VgenError,
                   abi_version, address_from_payload, derive, device_count, device_name, key_add, key_to_wif,

@@ -30,7 +30,7 @@ struct Opts {
     std::string cmd, pattern, format = "p2pkh", output = "text", file, range, key, address, devices = "0", checkpoint, provider_table;
     bool has_pattern = false, ignore_case = false, quiet = false, json = false, no_gpu = false;
     uint64_t count = 1, repeat = 1, seed = 0;
-    uint32_t batch = 1u << 20, frames = 6;
+    uint32_t batch = 1u << 20, frames = 16;
     int puzzle = 0;
     long prefix_length = -1;   // -l / --prefix-length (provider patterns)
 };
@@ -423,7 +423,7 @@ const char *argv_pattern(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // one hardware queue per frame stream; before HIP initialises
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);   // one hardware queue per frame stream; before HIP initialises
     Opts o = parse(argc, argv);
     signal(SIGINT, on_sigint);
     if (o.cmd == "generate") {
