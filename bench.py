@@ -154,12 +154,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tw = time.perf_counter()
     run(0, args.warmup, False)
     barrier()
+    per_step_ms = (time.perf_counter() - tw) / max(1, args.warmup) * 1e3
+    # shader-clock probe beside the timed region (one sleeping wave on its own stream), sized to end well
+    # before the region does so that the closing synchronize never waits for it
+    probe_ms = int(min(2000.0, 0.5 * per_step_ms * args.steps))
+    if probe_ms >= 2:
+        runner.clock_probe_start(probe_ms)
     t0 = time.perf_counter()
     cand, kms = run(args.warmup, args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    shader_mhz = runner.clock_probe_read() if probe_ms >= 2 else None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,7 +180,12 @@ def main():
     # seq_fwd_kernel (half an F_p multiplication per key: 74 imul + 60 iop per multiplication)
     w_bwd = w_key - (74 * R_MUL + 60) // 2
     avg_ms = sum(kms) / len(kms)
-    achieved = N * w_bwd / (avg_ms * 1e-3) / 1e12
+    # Launches of different frames execute concurrently (one launch is only 1 wave per SIMD), each taking
+    # correspondingly longer, so the kernel's rate is its per-launch rate times the mean number of its launches
+    # in flight (sum of launch durations / wall time, Little's law) - both factors are reported.
+    per_launch = N * w_bwd / (avg_ms * 1e-3) / 1e12
+    concurrency = sum(kms) * 1e-3 / elapsed
+    achieved = per_launch * concurrency
     traffic = None
     try:   # HBM bytes per launch from the committed PMC passes (profiles/, FETCH_SIZE x2 per the guide)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -191,14 +204,21 @@ def main():
                    "device_filter_kind": pat.device_kind, "candidates_reported": cand},
         "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1),
                      "unit": "Tlaneop/s", "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": traffic,
-                     "kernel": "seq_bwd_kernel", "avg_launch_ms": round(avg_ms, 4), "launches_overlapped": F,
+                     "kernel": "seq_bwd_kernel", "avg_launch_ms": round(avg_ms, 4), "frames_in_flight": F,
+                     "mean_launches_in_flight": round(concurrency, 2), "achieved_per_launch": round(per_launch, 3),
                      "work_per_key": w_bwd, "work_per_key_whole_path": w_key,
                      "chip_achieved": round(value * 1e6 / world * w_key / 1e12, 3),
                      "chip_frac": round(value * 1e6 / world * w_key / 1e12 / PEAK_TLANEOPS, 4),
+                     "shader_clock_mhz": round(shader_mhz) if shader_mhz else None,
+                     "chip_frac_at_shader_clock": round(value * 1e6 / world * w_key / 1e12 /
+                                                        (PEAK_TLANEOPS * shader_mhz / 2400.0), 4) if shader_mhz else None,
                      "note": "integer-VALU bound path (no MFMA; HBM traffic is a few % of peak); achieved = "
-                             "algorithmic lane-op-equivalents of one seq_bwd_kernel launch / its HIP-event duration; "
-                             "launches of different frames overlap on the device (each then runs longer), so chip_* "
-                             "gives the same ratio from whole-run wall time over all kernels"},
+                             "algorithmic lane-op-equivalents of one seq_bwd_kernel launch / its average HIP-event "
+                             "duration (achieved_per_launch) x the mean number of its launches in flight (sum of launch "
+                             "durations / wall time): one launch is 1 wave per SIMD and the frames overlap on the device; "
+                             "chip_* is the same ratio for the whole path from wall time; shader_clock_mhz = "
+                             "s_memtime / s_memrealtime sampled by a probe wave during the timed region (the peak "
+                             "assumes the nominal 2400 MHz, which power management does not sustain under this load)"},
     }
     if rank == 0 and world == 1:
         # time-to-first-match (the second half of BASELINE.json's metric): a `generate -c 1` style scan

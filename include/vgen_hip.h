@@ -125,6 +125,15 @@ const char *vgen_format_charset_name(uint32_t format);
  * index order — the reference kernel's behaviour, src/shaders/search.wgsl:2-31). */
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 
+/* ---- measurement aid -------------------------------------------------------------------------------------- */
+
+/* Starts a one-wave probe on its own stream that, for duration_ms, compares the shader-clock counter with
+ * the constant 100 MHz counter; vgen_clock_probe_read waits for it and returns the clock (MHz) the CUs ran at
+ * meanwhile — i.e. under whatever the frames were executing (bench.py reports it beside the roofline:
+ * power management keeps the MI355X below its nominal 2400 MHz under this integer load). */
+int vgen_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
+int vgen_clock_probe_read(vgen_ctx *ctx, double *mhz);
+
 /* ---- dispatch / readback ----------------------------------------------------------------------------- */
 
 /* GpuRunner::dispatch(start_key, frame) (src/gpu.rs:535-600): asynchronously tests the keys

@@ -104,6 +104,8 @@ _L.vgen_provider_resolve.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_
                                      ctypes.c_char_p]
 _L.vgen_provider_build_pattern.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_set_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+_L.vgen_clock_probe_start.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+_L.vgen_clock_probe_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 _L.vgen_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
 _L.vgen_dispatch_keys.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
 _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match), ctypes.c_uint32,
@@ -348,6 +350,15 @@ class GpuRunner:
         n, tested = ctypes.c_uint32(), ctypes.c_uint64()
         _check(_L.vgen_wait(self._h, frame, None, 0, ctypes.byref(n), ctypes.byref(tested)), self._h)
         return n.value, tested.value
+
+    def clock_probe_start(self, duration_ms: int):
+        """Samples the shader clock for duration_ms on a side stream (vgen_clock_probe_start)."""
+        _check(_L.vgen_clock_probe_start(self._h, duration_ms), self._h)
+
+    def clock_probe_read(self) -> float:
+        mhz = ctypes.c_double()
+        _check(_L.vgen_clock_probe_read(self._h, ctypes.byref(mhz)), self._h)
+        return mhz.value
 
     def kernel_ms(self, frame: int) -> float:
         """HIP-event duration of the dominant kernel (seq_bwd_kernel) of the frame's last dispatch."""

@@ -143,6 +143,16 @@ int vgen_provider_build_pattern(const char *address, uint32_t prefix_length, cha
     return VGEN_OK;
 }
 
+int vgen_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_clock_probe_start(ctx, duration_ms);
+}
+
+int vgen_clock_probe_read(vgen_ctx *ctx, double *mhz) {
+    if (!ctx || !mhz) return VGEN_E_INVALID;
+    return vg::rt_clock_probe_read(ctx, mhz);
+}
+
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f) {
     if (!ctx) return VGEN_E_INVALID;
     return vg::rt_set_filter(ctx, f);

@@ -424,6 +424,28 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---- shader-clock probe -----------------------------------------------------------------------------------
+// One wave that sleeps on the SALU for `ticks` of the constant 100 MHz counter (s_memrealtime) and reports
+// how far the shader-clock counter (s_memtime) moved meanwhile: the clock the CUs really ran at while the scan
+// kernels were executing beside it (power management holds it below the nominal 2.4 GHz under this load).
+// Time-bounded, so it always terminates.
+__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long *out, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned long long w = w0;
+    while (w - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w = wall_clock64();
+    }
+    out[0] = clock64() - c0;
+    out[1] = w - w0;
+}
+
+hipError_t launch_clock_probe(unsigned long long *out, unsigned long long ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, out, ticks);
+    return hipGetLastError();
+}
+
 hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;
     switch (fmt) {

@@ -15,4 +15,6 @@ hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream, hipEve
 namespace vg {
 // Enqueues the arbitrary-scalar scan (one key per lane, full fixed-base multiplication).
 hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream);
+// Enqueues the shader-clock probe: out[0] = shader-clock cycles, out[1] = 100 MHz ticks elapsed (>= ticks).
+hipError_t launch_clock_probe(unsigned long long *out, unsigned long long ticks, hipStream_t stream);
 }  // namespace vg

@@ -134,12 +134,41 @@ void rt_destroy(vgen_ctx *c) {
         if (f.ev_stop) (void)hipEventDestroy(f.ev_stop);
         if (f.stream) (void)hipStreamDestroy(f.stream);
     }
+    if (c->probe_stream) {
+        (void)hipStreamSynchronize(c->probe_stream);
+        (void)hipStreamDestroy(c->probe_stream);
+    }
+    if (c->d_probe) (void)hipFree(c->d_probe);
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
     if (c->d_dfa) (void)hipFree(c->d_dfa);
     if (c->d_filter) (void)hipFree(c->d_filter);
     delete c;
+}
+
+// Shader-clock probe: a single sleeping wave on its own stream, beside whatever the frames are running.
+int rt_clock_probe_start(vgen_ctx *c, uint32_t duration_ms) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->probe_running) return c->fail(VGEN_E_STATE, "a clock probe is already running");
+    if (duration_ms == 0 || duration_ms > 10000) return c->fail(VGEN_E_INVALID, "probe duration must be 1..10000 ms");
+    if (!c->probe_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
+    if (!c->d_probe) HIP_TRY(c, hipMalloc((void **)&c->d_probe, 2 * sizeof(unsigned long long)));
+    HIP_TRY(c, launch_clock_probe(c->d_probe, (unsigned long long)duration_ms * 100000ull, c->probe_stream));   // 100 MHz ticks
+    c->probe_running = true;
+    return VGEN_OK;
+}
+
+int rt_clock_probe_read(vgen_ctx *c, double *mhz) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->probe_running) return c->fail(VGEN_E_STATE, "no clock probe was started");
+    HIP_TRY(c, hipStreamSynchronize(c->probe_stream));
+    c->probe_running = false;
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(v, c->d_probe, sizeof v, hipMemcpyDeviceToHost));
+    if (v[1] == 0) return c->fail(VGEN_E_HIP, "clock probe returned no ticks");
+    *mhz = (double)v[0] / (double)v[1] * 100.0;
+    return VGEN_OK;
 }
 
 int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {

@@ -47,6 +47,9 @@ struct vgen_ctx {
         float last_total_ms = 0.f;       // whole dispatch: fwd + inv + bwd
     };
     std::vector<Frame> fr;
+    hipStream_t probe_stream = nullptr;          // shader-clock probe (vgen_clock_probe_*)
+    unsigned long long *d_probe = nullptr;
+    bool probe_running = false;
     std::string err;
 
     int fail(int status, const std::string &msg) {
@@ -65,5 +68,7 @@ int rt_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint
 int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
             uint64_t *keys_tested);
 int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
+int rt_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
+int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);
 
 }  // namespace vg
