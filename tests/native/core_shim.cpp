@@ -204,6 +204,11 @@ void core_fe_mul_add(const u32 *a, const u32 *b, const u32 *c, u32 *r, int squar
     if (square) fe_sqr_add(w, x, z); else fe_mul_add(w, x, y, z);
     for (int i = 0; i < 9; i++) r[i] = w.n[i];
 }
+u32 core_fe_parity_weak(const u32 *a) {
+    fe x;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    return fe_parity_weak(x);
+}
 void core_fe_canonicalize(const u32 *a, u32 *r) {
     fe x;
     for (int i = 0; i < 9; i++) x.n[i] = a[i];

@@ -162,3 +162,4 @@ def test_canonicalize_weakly_normalised_inputs(core):
         r = A9()
         core.core_fe_canonicalize(A9(*a), r)
         assert list(r) == limbs_of(val(a) % P), a
+        assert core.core_fe_parity_weak(A9(*a)) == (val(a) % P) & 1, a   # parity without the representative

@@ -102,7 +102,101 @@ VG_HD void fe_fold_(fe &r, const u32 *e) {
     r.n[8] = n8 + cc;                 // <= 2^24
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VG_FE_NO_ASM)
+// ---- column form (default) ----------------------------------------------------------------------------------
+// The 17 column sums S_k = sum_{i+j=k} a_i b_j are accumulated INDEPENDENTLY in 64 bits (no carry chain:
+// 9 * m_a*m_b * 2^58 < 2^63.76 for m_a*m_b <= 6), and the high columns are folded into the low ones as whole
+// 64-bit quantities, split only into their two register halves (which costs nothing):
+//     S_k * 2^(29k),  k >= 9,  2^261 = R1*2^29 + R0,  S_k = lo + 2^32 hi,  2^32 = 8 * 2^29
+//       ->  D_{k-9} += lo*R0;   D_{k-8} += lo*R1 + hi*(8 R0);   D_{k-7} += hi*(8 R1)
+// (k descending, so that column 16's spill into D_9 is folded when k reaches 9).  Column 8's high half has
+// weight 2^264 = 2^8 (2^32 + 977):  D_0 += hi8 * (977*256),  D_1 += hi8 * 2^11.  Only then one carry pass and
+// the short top fold.  Against the chained form this trades 17 64-bit shifts + 17 masks + a shift-heavy fold
+// for 34 more v_mad_u64_u32: 664 instead of 787 issue cycles per multiplication on gfx950.
+// Bounds: every D stays below 2^63.76 + 2^51 < 2^64; after folding hi8, D_8 < 2^32.
+// A multiplier the compiler cannot see through: on gfx950 a 32x32+64 multiply-add (v_mad_u64_u32) is cheaper
+// than the shift + zero-extension + 64-bit add that hipcc substitutes for a multiplication by a power of two.
+template <u32 V>
+VG_HD u32 fe_opaque_() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 r;
+    asm("s_mov_b32 %0, %1" : "=s"(r) : "i"(V));
+    return r;
+#else
+    return V;
+#endif
+}
+
+// One routine for a*b (+c) and a^2 (+c).  The high columns are produced first (k = 16 .. 9) and folded at
+// once, so only ten accumulators D_0..D_9 plus the column in hand are alive (22 registers instead of 34).
+template <bool SQR>
+VG_HD void fe_mul_columns_(fe &r, const fe &a, const fe &b, const fe *c3) {
+    const u32 R1 = fe_opaque_<FE_R1>(), R0x8 = FE_R0 * 8u, R1x8 = fe_opaque_<FE_R1 * 8u>();
+    u32 d[9];   // SQR: doubled limbs for the cross terms (a of magnitude 1)
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = SQR ? (a.n[i] << 1) : 0u;
+    u64 D[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) D[k] = 0;
+#pragma unroll
+    for (int k = 16; k >= 0; k--) {
+        u64 s = k <= 9 ? D[k] : 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= 9) continue;
+            if (!SQR) s += (u64)a.n[i] * b.n[j];
+            else if (i < j) s += (u64)d[i] * a.n[j];
+            else if (i == j) s += (u64)a.n[i] * a.n[i];
+        }
+        if (k >= 9) {
+            const u32 lo = (u32)s, hi = (u32)(s >> 32);
+            D[k - 9] += (u64)lo * FE_R0;
+            D[k - 8] += (u64)lo * R1;
+            D[k - 8] += (u64)hi * R0x8;
+            D[k - 7] += (u64)hi * R1x8;   // k = 16 reaches D_9, which is column 9's starting value
+        } else {
+            D[k] = s;
+        }
+    }
+    if (c3) {   // 2^31 per limb against 2^63.76: no effect on the bounds; a mad, not mov + 64-bit add
+        const u32 one = fe_opaque_<1>();
+#pragma unroll
+        for (int k = 0; k < 9; k++) D[k] += (u64)c3->n[k] * one;
+    }
+    {
+        const u32 hi8 = (u32)(D[8] >> 32);
+        D[8] = (u32)D[8];
+        D[0] += (u64)hi8 * (977u * 256u);
+        D[1] += (u64)hi8 * R1x8;
+    }
+    u32 f[8];
+    u64 c = D[0];
+    f[0] = (u32)c & FE_M29; c >>= 29;
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        c += D[k];
+        f[k] = (u32)c & FE_M29; c >>= 29;
+    }
+    c += D[8];                                   // < 2^36 + 2^32
+    const u32 n8 = (u32)c & FE_M24;
+    const u32 ov = (u32)(c >> 24);               // < 2^13, weight 2^256 == 2^32 + 977 = 8*2^29 + 977
+    u32 cc = f[0] + ov * 977u;                   // < 2^29 + 2^23
+    r.n[0] = cc & FE_M29; cc >>= 29;
+    cc += f[1] + ov * 8u;
+    r.n[1] = cc & FE_M29; cc >>= 29;
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        cc += f[k];
+        r.n[k] = cc & FE_M29; cc >>= 29;
+    }
+    r.n[8] = n8 + cc;                            // <= 2^24
+}
+
+#if !defined(VG_FE_CHAINED)
+#define VG_FE_COLUMNS 1
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VG_FE_NO_ASM) && defined(VG_FE_CHAINED)
 #include "fe_gfx950_asm.inc"
 #define VG_FE_ASM 1
 #endif
@@ -161,35 +255,51 @@ VG_HD void fe_square_digits_(u32 *e, const fe &a) {
 
 // r = a * b.  Requires m_a * m_b <= 6.  Result magnitude 1.
 VG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
+#ifdef VG_FE_COLUMNS
+    fe_mul_columns_<false>(r, a, b, nullptr);
+#else
     u32 e[18];
     fe_product_digits_(e, a, b);
     fe_fold_(r, e);
+#endif
 }
 
 // r = a^2.  Requires m_a <= 1 (the doubled cross terms use 2*a_i).  Result magnitude 1.
 VG_HD void fe_sqr(fe &r, const fe &a) {
+#ifdef VG_FE_COLUMNS
+    fe_mul_columns_<true>(r, a, a, nullptr);
+#else
     u32 e[18];
     fe_square_digits_(e, a);
     fe_fold_(r, e);
+#endif
 }
 
 // r = a * b + c, c of magnitude <= 3: c's limbs join the low product digits before the fold, so the
 // sum costs nine 32-bit adds and no extra carry pass.  Result magnitude 1 (as fe_mul).
 VG_HD void fe_mul_add(fe &r, const fe &a, const fe &b, const fe &c3) {
+#ifdef VG_FE_COLUMNS
+    fe_mul_columns_<false>(r, a, b, &c3);
+#else
     u32 e[18];
     fe_product_digits_(e, a, b);
 #pragma unroll
     for (int k = 0; k < 9; k++) e[k] += c3.n[k];   // < 2^29 + 3*2^29 = 2^31: still a u32, the fold takes 64-bit sums
     fe_fold_(r, e);
+#endif
 }
 
 // r = a^2 + c, c of magnitude <= 3 (see fe_mul_add); a of magnitude 1.
 VG_HD void fe_sqr_add(fe &r, const fe &a, const fe &c3) {
+#ifdef VG_FE_COLUMNS
+    fe_mul_columns_<true>(r, a, a, &c3);
+#else
     u32 e[18];
     fe_square_digits_(e, a);
 #pragma unroll
     for (int k = 0; k < 9; k++) e[k] += c3.n[k];
     fe_fold_(r, e);
+#endif
 }
 
 // Canonical representative of a WEAKLY NORMALISED value (output of fe_mul / fe_sqr / fe_*_add /
@@ -222,6 +332,24 @@ VG_HD void fe_canonicalize(fe &r) {
     const bool ge = (cu >> 24) != 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) r.n[k] = ge ? u[k] : v[k];
+}
+
+// Parity (bit 0) of the canonical representative of a WEAKLY NORMALISED value, without producing the
+// representative: the carry chain of u = v + C alone decides v >= p, and subtracting the odd p flips the parity.
+// 25 instructions instead of fe_canonicalize's 61 — all a compressed public key needs of y.
+VG_HD u32 fe_parity_weak(const fe &r) {
+    const u32 ov = r.n[8] >> 24;
+    const u32 v0 = r.n[0] + ov * 977u;
+    u32 cu = (v0 + 977u) >> 29;
+    cu += r.n[1] + ov * 8u + 8u;
+    cu >>= 29;
+#pragma unroll
+    for (int k = 2; k < 8; k++) {
+        cu += r.n[k];
+        cu >>= 29;
+    }
+    cu += r.n[8] & FE_M24;
+    return (v0 ^ (cu >> 24)) & 1u;
 }
 
 // Weak normalisation: any magnitude <= 7 in, magnitude 1 out (value unchanged mod p, < 2^256 + 2^233).

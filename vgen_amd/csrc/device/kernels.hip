@@ -283,7 +283,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
             for (int i = 0; i < 9; i++) t.n[i] += q.qx[i];                                  // magnitude 3
             fe_mul_add(y3, lam, t, nqy);          // lam*(Q.x - x3) - Q.y
-            fe_canonicalize(y3);
+            if (FMT == VGF_P2PKH || FMT == VGF_P2WPKH || FMT == VGF_P2SH_P2WPKH)
+                y3.n[0] = fe_parity_weak(y3);     // a compressed key takes only the parity of y (bit 0 is all that is read)
+            else
+                fe_canonicalize(y3);
 
             u32 pl[NW];
             const bool ok = payload_from_point<FMT>(x3, y3, gtab, pl);
