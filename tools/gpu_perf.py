@@ -36,6 +36,7 @@ if __name__ == "__main__":
     fmt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     sweep = [(1 << 20, 1, 64), (1 << 20, 2, 128), (1 << 20, 4, 128), (1 << 20, 8, 256), (1 << 24, 2, 16)]
     if len(sys.argv) > 2:
-        sweep = [(1 << 20, int(f), 256) for f in sys.argv[2].split(",")]
+        b = int(os.environ.get("VGEN_PERF_BATCH", str(1 << 20)))
+        sweep = [(b, int(f), max(32, 256 * (1 << 20) // b)) for f in sys.argv[2].split(",")]
     for batch, frames, steps in sweep:
         run(batch, frames, steps, fmt)

@@ -67,42 +67,7 @@ VG_HD void fe_neg(fe &r, const fe &a, u32 m) {
     r.n[8] = k * FE_P8 - a.n[8];
 }
 
-// Shared tail of mul/sqr: e[0..16] are 29-bit digits of the product, e[17] the rest (< 2^32 for
-// m_a*m_b <= 6).  Folds digits 9..17 with 2^261 = R1*2^29 + R0 and the bits above 2^256 with
-// 2^256 = 2^32 + 977, leaving magnitude 1 with n[8] <= 2^24 (value < 2^256 + 2^233).
-VG_HD void fe_fold_(fe &r, const u32 *e) {
-    u64 c;
-    u32 f[8];
-    // d_k = e_k + e_{9+k}*R0 + e_{8+k}*R1, carried forward
-    c = (u64)e[9] * FE_R0 + e[0];
-    f[0] = (u32)c & FE_M29; c >>= 29;
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        c += (u64)e[9 + k] * FE_R0 + (u64)e[8 + k] * FE_R1 + e[k];
-        f[k] = (u32)c & FE_M29; c >>= 29;
-    }
-    // top limb (weight 2^232): c < 2^48.  Digit 17's R1 term has weight 2^261 = 2^5 * 2^256 and goes
-    // straight into the overflow word.
-    c += (u64)e[17] * FE_R0 + (u64)e[16] * FE_R1 + e[8];
-    u32 n8 = (u32)c & FE_M24;
-    u64 ov = (c >> 24) + (((u64)e[17] * FE_R1) << 5);   // weight 2^256 == 8*2^29 + 977;  ov < 2^46
-    u64 t0 = ov * 977u + f[0];        // < 2^56
-    u32 r0 = (u32)t0 & FE_M29;
-    u64 t1 = (t0 >> 29) + ov * 8u + f[1];
-    u32 r1 = (u32)t1 & FE_M29;
-    u32 cc = (u32)(t1 >> 29);         // < 2^21
-    r.n[0] = r0;
-    r.n[1] = r1;
-#pragma unroll
-    for (int k = 2; k < 8; k++) {
-        cc += f[k];
-        r.n[k] = cc & FE_M29;
-        cc >>= 29;
-    }
-    r.n[8] = n8 + cc;                 // <= 2^24
-}
-
-// ---- column form (default) ----------------------------------------------------------------------------------
+// ---- multiplication: column form -----------------------------------------------------------------------------
 // The 17 column sums S_k = sum_{i+j=k} a_i b_j are accumulated INDEPENDENTLY in 64 bits (no carry chain:
 // 9 * m_a*m_b * 2^58 < 2^63.76 for m_a*m_b <= 6), and the high columns are folded into the low ones as whole
 // 64-bit quantities, split only into their two register halves (which costs nothing):
@@ -110,9 +75,11 @@ VG_HD void fe_fold_(fe &r, const u32 *e) {
 //       ->  D_{k-9} += lo*R0;   D_{k-8} += lo*R1 + hi*(8 R0);   D_{k-7} += hi*(8 R1)
 // (k descending, so that column 16's spill into D_9 is folded when k reaches 9).  Column 8's high half has
 // weight 2^264 = 2^8 (2^32 + 977):  D_0 += hi8 * (977*256),  D_1 += hi8 * 2^11.  Only then one carry pass and
-// the short top fold.  Against the chained form this trades 17 64-bit shifts + 17 masks + a shift-heavy fold
-// for 34 more v_mad_u64_u32: 664 instead of 787 issue cycles per multiplication on gfx950.
+// the short top fold.  Against a carry-chained column walk (the first version of this file: 219 instructions
+// per multiplication) this trades 17 64-bit shifts, 17 masks and a shift-heavy fold for 34 more
+// v_mad_u64_u32: 173 instructions, ~670 instead of ~790 issue cycles on gfx950 (tools/isa_census.py).
 // Bounds: every D stays below 2^63.76 + 2^51 < 2^64; after folding hi8, D_8 < 2^32.
+
 // A multiplier the compiler cannot see through: on gfx950 a 32x32+64 multiply-add (v_mad_u64_u32) is cheaper
 // than the shift + zero-extension + 64-bit add that hipcc substitutes for a multiplication by a power of two.
 template <u32 V>
@@ -192,114 +159,25 @@ VG_HD void fe_mul_columns_(fe &r, const fe &a, const fe &b, const fe *c3) {
     r.n[8] = n8 + cc;                            // <= 2^24
 }
 
-#if !defined(VG_FE_CHAINED)
-#define VG_FE_COLUMNS 1
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VG_FE_NO_ASM) && defined(VG_FE_CHAINED)
-#include "fe_gfx950_asm.inc"
-#define VG_FE_ASM 1
-#endif
-
-// e[0..16]: 29-bit digits of a*b (column sums chained through their carries), e[17]: the rest.
-VG_HD void fe_product_digits_(u32 *e, const fe &a, const fe &b) {
-#ifdef VG_FE_ASM
-    u64 t[17];
-    fe_mul_cols_asm(a.n, b.n, t);
-#pragma unroll
-    for (int k = 0; k < 17; k++) e[k] = (u32)t[k] & FE_M29;
-    e[17] = (u32)(t[16] >> 29);
-#else
-    u64 c = 0;
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const int j = k - i;
-            if (j >= 0 && j < 9) c += (u64)a.n[i] * b.n[j];
-        }
-        e[k] = (u32)c & FE_M29;
-        c >>= 29;
-    }
-    e[17] = (u32)c;
-#endif
-}
-
-// the same for a^2 (a of magnitude 1): cross terms once, with doubled limbs
-VG_HD void fe_square_digits_(u32 *e, const fe &a) {
-    u32 d[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
-#ifdef VG_FE_ASM
-    u64 t[17];
-    fe_sqr_cols_asm(a.n, d, t);
-#pragma unroll
-    for (int k = 0; k < 17; k++) e[k] = (u32)t[k] & FE_M29;
-    e[17] = (u32)(t[16] >> 29);
-#else
-    u64 c = 0;
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const int j = k - i;
-            if (j >= 0 && j < 9 && i < j) c += (u64)d[i] * a.n[j];
-            if (j == i) c += (u64)a.n[i] * a.n[i];
-        }
-        e[k] = (u32)c & FE_M29;
-        c >>= 29;
-    }
-    e[17] = (u32)c;
-#endif
-}
-
 // r = a * b.  Requires m_a * m_b <= 6.  Result magnitude 1.
 VG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
-#ifdef VG_FE_COLUMNS
     fe_mul_columns_<false>(r, a, b, nullptr);
-#else
-    u32 e[18];
-    fe_product_digits_(e, a, b);
-    fe_fold_(r, e);
-#endif
 }
 
 // r = a^2.  Requires m_a <= 1 (the doubled cross terms use 2*a_i).  Result magnitude 1.
 VG_HD void fe_sqr(fe &r, const fe &a) {
-#ifdef VG_FE_COLUMNS
     fe_mul_columns_<true>(r, a, a, nullptr);
-#else
-    u32 e[18];
-    fe_square_digits_(e, a);
-    fe_fold_(r, e);
-#endif
 }
 
 // r = a * b + c, c of magnitude <= 3: c's limbs join the low product digits before the fold, so the
 // sum costs nine 32-bit adds and no extra carry pass.  Result magnitude 1 (as fe_mul).
 VG_HD void fe_mul_add(fe &r, const fe &a, const fe &b, const fe &c3) {
-#ifdef VG_FE_COLUMNS
     fe_mul_columns_<false>(r, a, b, &c3);
-#else
-    u32 e[18];
-    fe_product_digits_(e, a, b);
-#pragma unroll
-    for (int k = 0; k < 9; k++) e[k] += c3.n[k];   // < 2^29 + 3*2^29 = 2^31: still a u32, the fold takes 64-bit sums
-    fe_fold_(r, e);
-#endif
 }
 
 // r = a^2 + c, c of magnitude <= 3 (see fe_mul_add); a of magnitude 1.
 VG_HD void fe_sqr_add(fe &r, const fe &a, const fe &c3) {
-#ifdef VG_FE_COLUMNS
     fe_mul_columns_<true>(r, a, a, &c3);
-#else
-    u32 e[18];
-    fe_square_digits_(e, a);
-#pragma unroll
-    for (int k = 0; k < 9; k++) e[k] += c3.n[k];
-    fe_fold_(r, e);
-#endif
 }
 
 // Canonical representative of a WEAKLY NORMALISED value (output of fe_mul / fe_sqr / fe_*_add /

@@ -38,6 +38,13 @@ namespace vg {
 
 constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 
+#ifndef VG_SEQ_WAVES_P2TR
+#define VG_SEQ_WAVES_P2TR 2
+#endif
+#ifndef VG_SEQ_WAVES_ETH
+#define VG_SEQ_WAVES_ETH 3
+#endif
+
 // ---- payload per format -----------------------------------------------------------------------------
 
 template <int FMT>
@@ -179,8 +186,17 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 // FULL: the filter is the pattern's whole DFA (DEVF_DFA): its tables are staged into dynamic LDS and every
 // key's address is encoded and matched on the device (core/dfa_eval.h).  A separate instantiation so
 // that the extra registers of the Base58Check path do not touch the prefilter kernels' occupancy.
+// Register budget: 4 waves per SIMD (128 VGPRs) for the 20-byte formats — four launches of different frames
+// then share a SIMD; Keccak (50 state registers) runs better at 3 waves without spills (6.16 vs 5.85 Gkeys/s),
+// the taproot path (a full scalar multiplication per key) keeps its ~240 registers (217 vs 197 Mkeys/s).
+template <int FMT>
+struct SeqWaves {
+    static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH : 4;
+};
+
 template <int FMT, bool FULL>
-__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) seq_bwd_kernel(const SeqArgs args) {
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SeqWaves<FMT>::value, SeqWaves<FMT>::value)))
+seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
     extern __shared__ u32 dyn_lds[];   // [P2TR: fixed-window generator table][FULL: DFA blob]
     constexpr int NW = PayloadWords<FMT>::value;
