@@ -249,20 +249,26 @@ int core_dfa_check(const char *pattern, int ci, unsigned format, const unsigned 
 #include "../../vgen_amd/csrc/core/taproot.h"
 
 extern "C" {
-// Device algorithm for the P2TR output key, on the host: key -> k*G via ec_mul_gen_windows (the same
-// table layout), then taproot_output_x.  out: 32 bytes big-endian x(Q).  0 if invalid.
+// Device algorithm for the P2TR output key, on the host: key -> k*G via the 4-bit AND the 8-bit fixed-window
+// multiplications (must agree), then taproot_output_x.  out: 32 bytes big-endian x(Q).  0 if invalid,
+// -1 if the two multiplications disagree.
 int core_taproot_from_key(const unsigned char *key_be, unsigned char *out32) {
-    static std::vector<uint32_t> tab;
-    if (tab.empty()) host_gen_table_limbs(tab);
+    static std::vector<uint32_t> tab, tab8;
+    if (tab.empty()) {
+        host_gen_table_limbs(tab);
+        host_gen_table8_limbs(tab8);
+    }
     Scalar k;
     scalar_from_be(k, key_be);
     if (!scalar_is_valid(k)) return 0;
-    gej pj;
+    gej pj, pj8;
     ec_mul_gen_windows(pj, k.w, tab.data());
-    ge p;
-    if (!ge_from_gej(p, pj)) return 0;
+    ec_mul_gen_w8(pj8, k.w, tab8.data());
+    ge p, p8;
+    if (!ge_from_gej(p, pj) || !ge_from_gej(p8, pj8)) return 0;
+    if (!fe_equal_canonical(p.x, p8.x) || !fe_equal_canonical(p.y, p8.y)) return -1;
     u32 xw[8];
-    if (!taproot_output_x(p.x, p.y, tab.data(), xw)) return 0;
+    if (!taproot_output_x(p.x, p.y, tab8.data(), xw)) return 0;
     for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) out32[4 * (7 - i) + j] = (unsigned char)(xw[i] >> (24 - 8 * j));
     return 1;
 }

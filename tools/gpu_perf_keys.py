@@ -7,7 +7,8 @@ batch = 1 << 20
 rng = random.Random(1)
 blob = bytes(rng.getrandbits(8) for _ in range(32 * 4096)) * (batch // 4096)
 keys = [blob[32*i:32*i+32] for i in range(batch)]
-r = v.GpuRunner(batch_size=batch, fmt=v.AddressFormat.P2pkh, frames=2)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+r = v.GpuRunner(batch_size=batch, fmt=v.AddressFormat.P2pkh, frames=F)
 p = v.Pattern("^1Cat", False, v.AddressFormat.P2pkh)
 r.set_filter(p)
 import ctypes
@@ -16,11 +17,11 @@ def disp(f):
     api._check(api._L.vgen_dispatch_keys(r._h, f, blob, batch), r._h)
 disp(0); r.wait(0)
 t0 = time.perf_counter()
-steps = 8
-disp(0); disp(1)
+steps = 8 * F
+for f in range(F): disp(f)
 for s in range(steps):
-    f = s % 2
+    f = s % F
     r.wait(f)
-    if s + 2 < steps: disp(f)
+    if s + F < steps: disp(f)
 dt = time.perf_counter() - t0
-print("KEYS mode: %.1f Mkeys/s, kernel %.3f ms per 2^20 keys" % (steps * batch / dt / 1e6, r.kernel_ms(0)))
+print("KEYS mode, %d frames: %.1f Mkeys/s, kernel %.3f ms per 2^20 keys" % (F, steps * batch / dt / 1e6, r.kernel_ms(0)))

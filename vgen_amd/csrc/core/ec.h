@@ -208,25 +208,46 @@ VG_HD void gej_add_ge_nz(gej &r, const gej &a, const ge &b) {
 
 namespace vg {
 
-// acc = k * G by 4-bit fixed windows, least significant window first, with the table layout of
-// host_gen_table_limbs ([64][15][18] limbs: x then y of d * 16^w * G).  k: eight little-endian words,
-// 0 < k < n.  Unsigned digits accumulated low to high keep the running sum below the next addend's
+// acc = k * G by fixed windows of WB bits, least significant window first.  Table: [256/WB windows]
+// [2^WB - 1 entries][ES words]: limbs 0..8 = x, 9..17 = y of d * 2^(WB*w) * G (entry stride ES >= 18 words; a
+// stride that is a multiple of 4 lets the device fetch an entry with 16-byte loads).  k: eight little-endian
+// words, 0 < k < n.  Unsigned digits accumulated low to high keep the running sum below the next addend's
 // scalar, so the branch-free mixed addition never meets P = +/-Q; "still at infinity" is a select.
-// Works on any memory the table lives in (LDS on the device, heap on the host).
-VG_HD void ec_mul_gen_windows(gej &acc, const u32 k[8], const u32 *tab) {
+// Works on any memory the table lives in (global or LDS on the device, heap on the host).
+struct alignas(16) ec_u4 {
+    u32 v[4];
+};
+
+template <int WB, int ES>
+VG_HD void ec_mul_gen_fixed(gej &acc, const u32 k[8], const u32 *tab) {
+    static_assert(32 % WB == 0 && ES >= 18, "window geometry");
+    constexpr u32 NE = (1u << WB) - 1u;
     gej_set_infinity(acc);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int w = 0; w < 64; w++) {
-        const u32 d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+    for (int w = 0; w < 256 / WB; w++) {
+        const u32 d = (k[(w * WB) >> 5] >> ((w * WB) & 31)) & NE;
         const u32 e = (d ? d : 1u) - 1u;
-        const u32 *ent = tab + ((u32)w * 15u + e) * 18u;
+        const u32 *ent = tab + ((u32)w * NE + e) * (u32)ES;
+        u32 raw[20];
+        if (ES % 4 == 0) {
+            const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(ent);
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const ec_u4 t4 = e4[q];
+#pragma unroll
+                for (int i = 0; i < 4; i++) raw[4 * q + i] = t4.v[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 18; i++) raw[i] = ent[i];
+        }
         ge t;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            t.x.n[i] = ent[i];
-            t.y.n[i] = ent[9 + i];
+            t.x.n[i] = raw[i];
+            t.y.n[i] = raw[9 + i];
         }
         gej sum;
         gej_add_ge_nz(sum, acc, t);      // garbage while acc is at infinity; replaced below
@@ -244,5 +265,13 @@ VG_HD void ec_mul_gen_windows(gej &acc, const u32 k[8], const u32 *tab) {
         acc.inf = skip ? acc.inf : 0u;
     }
 }
+
+// 4-bit windows, packed entries: host_gen_table_limbs ([64][15][18]).
+VG_HD void ec_mul_gen_windows(gej &acc, const u32 k[8], const u32 *tab) { ec_mul_gen_fixed<4, 18>(acc, k, tab); }
+
+// 8-bit windows, 80-byte entries: host_gen_table8_limbs ([32][255][20], 652 800 B, global memory on the device:
+// L2-resident, one entry = five 16-byte loads).  Half the additions of the 4-bit form.
+constexpr u32 EC_TABLE8_WORDS = 32u * 255u * 20u;
+VG_HD void ec_mul_gen_w8(gej &acc, const u32 k[8], const u32 *tab8) { ec_mul_gen_fixed<8, 20>(acc, k, tab8); }
 
 }  // namespace vg

@@ -3,8 +3,8 @@
 // What the reference does on the HOST for every key of a P2TR batch (XOnlyPublicKey::from_slice +
 // Address::p2tr(secp, internal_key, None, ..), src/gpu.rs:1287-1291, "CPU bound by design"
 // src/shaders/search_p2tr.wgsl:112): P = lift_x(x) (even Y), t = TapTweak(x), Q = P + t*G, output x(Q).
-// Here it runs per lane on the device: the tweak multiplication uses the same LDS-staged fixed-window
-// table as the arbitrary-scalar kernel.
+// Here it runs per lane on the device: the tweak multiplication walks the 8-bit fixed-window generator table
+// (global memory, L2-resident), and the final 1/Z is shared by the whole workgroup (kernels.hip).
 #pragma once
 #include "ec.h"
 #include "hash.h"
@@ -14,10 +14,11 @@ namespace vg {
 constexpr u32 TAP_ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                                 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
-// x, y: canonical affine internal key.  out_xw: x(Q) as eight words, out_xw[0] least significant.
-// Returns false when the tweak is not a valid scalar (t == 0 or t >= n: probability ~2^-128) or Q is the
-// point at infinity; such keys yield no address (Address::p2tr would panic / fail there).
-VG_HD bool taproot_output_x(const fe &x, const fe &y, const u32 *gtab, u32 out_xw[8]) {
+// x, y: canonical affine internal key; tab8: host_gen_table8_limbs.  q = lift_x(x) + TapTweak(x)*G in Jacobian
+// coordinates.  Returns false when the tweak is not a valid scalar (t == 0 or t >= n: probability ~2^-128;
+// q is then some other valid point) — such keys yield no address (Address::p2tr would fail there).
+// q.z == 0 (t*G == -P) is the caller's to check.
+VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const u32 *tab8, gej &q) {
     u32 xw[8], tb[8], k[8];
     fe_to_words(x, xw);
     sha256_taptweak(xw, tb);
@@ -38,7 +39,7 @@ VG_HD bool taproot_output_x(const fe &x, const fe &y, const u32 *gtab, u32 out_x
         k[0] = 1;
     }
     gej tg;
-    ec_mul_gen_windows(tg, k, gtab);
+    ec_mul_gen_w8(tg, k, tab8);
     // P with even Y
     ge p;
     p.x = x;
@@ -48,17 +49,34 @@ VG_HD bool taproot_output_x(const fe &x, const fe &y, const u32 *gtab, u32 out_x
     const bool odd = (y.n[0] & 1u) != 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) p.y.n[i] = odd ? ny.n[i] : y.n[i];
-    gej q;
-    gej_add_ge_nz(q, tg, p);              // t*G == +/-P would need t = +/-d: negligible, and caught below
-    fe zi, zi2, qx;
-    fe_inv(zi, q.z);
+    gej_add_ge_nz(q, tg, p);              // t*G == +/-P would need t = +/-d: negligible; Z = 0 then
+    return ok;
+}
+
+// True when z represents 0 mod p (z weakly normalised).
+VG_HD bool taproot_z_is_zero(const fe &z) {
+    fe zc = z;
+    fe_canonicalize(zc);
+    return fe_is_zero_canonical(zc);
+}
+
+// x(Q) = X / Z^2 as eight words (out_xw[0] least significant), given zi = 1/Z.
+VG_HD void taproot_affine_x(const gej &q, const fe &zi, u32 out_xw[8]) {
+    fe zi2, qx;
     fe_sqr(zi2, zi);
     fe_mul(qx, q.x, zi2);
     fe_canonicalize(qx);
-    fe zc = q.z;
-    fe_canonicalize(zc);
-    const bool inf = fe_is_zero_canonical(zc);
     fe_to_words(qx, out_xw);
+}
+
+// Single-key form (host: vgen_derive, match confirmation, tests): its own inversion.
+VG_HD bool taproot_output_x(const fe &x, const fe &y, const u32 *tab8, u32 out_xw[8]) {
+    gej q;
+    const bool ok = taproot_tweak_point(x, y, tab8, q);
+    const bool inf = taproot_z_is_zero(q.z);
+    fe zi;
+    fe_inv(zi, q.z);
+    taproot_affine_x(q, zi, out_xw);
     return ok && !inf;
 }
 

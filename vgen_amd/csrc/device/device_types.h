@@ -91,19 +91,19 @@ struct SeqArgs {
     uint32_t match_base;       // value of mhdr->count when this dispatch was enqueued
     uint32_t match_cap;
     const uint32_t *dfa_blob;  // DEVF_DFA: the automaton (device memory), staged into LDS by the kernel
-    const uint32_t *gtab;      // P2TR: fixed-window generator table (KEYS_TABLE_WORDS) for the tweak multiplication
+    const uint32_t *gtab;      // P2TR: 8-bit fixed-window generator table (global memory) for the tweak multiplication
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 
-// Arbitrary-scalar kernel (keys_scan_kernel): one key per lane, full fixed-base multiplication with a
-// 4-bit window table (64 windows x 15 points x 18 limbs = 69 120 B) staged in LDS.
+// Arbitrary-scalar kernel (keys_scan_kernel): one key per lane, full fixed-base multiplication over the 8-bit
+// window table (32 windows x 255 points x 20 words = 652 800 B in global memory, core/ec.h), one shared
+// inversion per workgroup.
 constexpr int KEYS_WG = 256;
-constexpr uint32_t KEYS_TABLE_WORDS = 64 * 15 * 18;
 
 struct KeysArgs {
-    const uint32_t *gtab;      // [64][15][18]: x limbs 0..8, y limbs 0..8 of d * 16^w * G (d = 1..15)
+    const uint32_t *gtab;      // [32][255][20]: x limbs 0..8, y limbs 9..17 of d * 256^w * G (d = 1..255)
     const uint8_t *keys_be;    // n * 32 bytes big-endian, or nullptr: key i = base + i
     const DevFilter *filter;
     uint32_t *dump;            // dump mode: n * 5 words (zeroed for invalid keys)

@@ -45,6 +45,74 @@ constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 #define VG_SEQ_WAVES_ETH 3
 #endif
 
+// ---- LDS / lane helpers ---------------------------------------------------------------------------------
+// All arrays are limb-major ([limb][lane]) so that a wave's access is 64 consecutive dwords.
+
+__device__ __forceinline__ void lds_store_fe(u32 *base, int stride, int col, const fe &a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) base[i * stride + col] = a.n[i];
+}
+
+__device__ __forceinline__ void lds_load_fe(const u32 *base, int stride, int col, fe &a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.n[i] = base[i * stride + col];
+}
+
+__device__ __forceinline__ void shfl_xor_fe(fe &r, const fe &a, int mask) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.n[i] = (u32)__shfl_xor((int)a.n[i], mask);
+}
+
+// 1/z for every lane of the workgroup through ONE Fermat inversion: product tree in LDS (leaf pairs by lane
+// shuffle), the root inverted by lane 0, the tree walked back down (the same tree as seq_fwd / seq_bwd, inside
+// one kernel).  z != 0 in every lane; all WG lanes must call it; `tree` is 9*WG words of LDS.
+__device__ __forceinline__ void wg_batch_inverse(fe &zi, const fe &z, u32 *tree) {
+    const int tid = threadIdx.x;
+    fe sib, pair;
+    shfl_xor_fe(sib, z, 1);
+    fe_mul(pair, z, sib);
+    __syncthreads();   // earlier readers of the tree are done
+    if ((tid & 1) == 0) lds_store_fe(tree, WG, WG / 2 + (tid >> 1), pair);
+    __syncthreads();
+#pragma unroll 1
+    for (int width = WG / 4; width >= 1; width >>= 1) {
+        if (tid < width) {
+            const int k = width + tid;
+            fe a, b, p;
+            lds_load_fe(tree, WG, 2 * k, a);
+            lds_load_fe(tree, WG, 2 * k + 1, b);
+            fe_mul(p, a, b);
+            lds_store_fe(tree, WG, k, p);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        fe r, ri;
+        lds_load_fe(tree, WG, 1, r);
+        fe_inv(ri, r);
+        lds_store_fe(tree, WG, 1, ri);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int width = 1; width <= WG / 4; width <<= 1) {
+        if (tid < width) {
+            const int k = width + tid;
+            fe ik, a, b, ia, ib;
+            lds_load_fe(tree, WG, k, ik);
+            lds_load_fe(tree, WG, 2 * k, a);
+            lds_load_fe(tree, WG, 2 * k + 1, b);
+            fe_mul(ia, ik, b);
+            fe_mul(ib, ik, a);
+            lds_store_fe(tree, WG, 2 * k, ia);
+            lds_store_fe(tree, WG, 2 * k + 1, ib);
+        }
+        __syncthreads();
+    }
+    fe ip;
+    lds_load_fe(tree, WG, WG / 2 + (tid >> 1), ip);
+    fe_mul(zi, ip, sib);
+}
+
 // ---- payload per format -----------------------------------------------------------------------------
 
 template <int FMT>
@@ -56,13 +124,21 @@ struct PayloadWords {
 // gtab: the fixed-window generator table in LDS (P2TR only).  Returns false when the key yields no
 // address (P2TR tweak not a valid scalar — probability ~2^-128).
 template <int FMT>
-__device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, const u32 *gtab, u32 *out) {
+__device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, const u32 *tab8, u32 *tree, u32 *out) {
     u32 xw[8];
     if (FMT == VGF_P2TR) {
-        const bool ok = taproot_output_x(x, y_canon, gtab, xw);
+        // Q = lift_x(x) + t*G per lane (8-bit fixed windows over the global table), then ONE inversion for the
+        // whole workgroup: every lane of the workgroup must be here (the callers' loops are uniform).
+        gej q;
+        bool ok = taproot_tweak_point(x, y_canon, tab8, q);
+        const bool zero = taproot_z_is_zero(q.z);     // t*G == -P: no address; keep the shared product invertible
+        if (zero) fe_set_one(q.z);
+        fe zi;
+        wg_batch_inverse(zi, q.z, tree);
+        taproot_affine_x(q, zi, xw);
 #pragma unroll
         for (int i = 0; i < 8; i++) out[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
-        return ok;
+        return ok && !zero;
     }
     fe_to_words(x, xw);
     if (FMT == VGF_P2PKH || FMT == VGF_P2WPKH) {
@@ -86,24 +162,6 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
         keccak256_pub64_addr(xw, yw, out);
     }
     return true;
-}
-
-// ---- LDS / lane helpers ---------------------------------------------------------------------------------
-// All arrays are limb-major ([limb][lane]) so that a wave's access is 64 consecutive dwords.
-
-__device__ __forceinline__ void lds_store_fe(u32 *base, int stride, int col, const fe &a) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) base[i * stride + col] = a.n[i];
-}
-
-__device__ __forceinline__ void lds_load_fe(const u32 *base, int stride, int col, fe &a) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) a.n[i] = base[i * stride + col];
-}
-
-__device__ __forceinline__ void shfl_xor_fe(fe &r, const fe &a, int mask) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.n[i] = (u32)__shfl_xor((int)a.n[i], mask);
 }
 
 // Scratch layout (global, one region per frame), for a dispatch of `lanes` lanes in lanes/WG groups:
@@ -198,16 +256,14 @@ template <int FMT, bool FULL>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SeqWaves<FMT>::value, SeqWaves<FMT>::value)))
 seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
-    extern __shared__ u32 dyn_lds[];   // [P2TR: fixed-window generator table][FULL: DFA blob]
+    extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
-    const u32 *gtab = dyn_lds;
-    u32 *dfa_lds = dyn_lds + (FMT == VGF_P2TR ? KEYS_TABLE_WORDS : 0);
-    if (FMT == VGF_P2TR)
-        for (u32 i = tid; i < KEYS_TABLE_WORDS; i += WG) dyn_lds[i] = args.gtab[i];
+    const u32 *gtab = args.gtab;       // P2TR: 8-bit fixed-window generator table, read from global memory (L2)
+    u32 *dfa_lds = dyn_lds;
     if (FULL) {
         for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
-        // (visibility: the barriers of the tree phase below come before the first read of either table)
+        // (visibility: the barriers of the tree phase below come before the first read of the table)
     }
     const u32 S = args.s;
     const u32 lanes = args.lanes;
@@ -305,7 +361,7 @@ seq_bwd_kernel(const SeqArgs args) {
                 fe_canonicalize(y3);
 
             u32 pl[NW];
-            const bool ok = payload_from_point<FMT>(x3, y3, gtab, pl);
+            const bool ok = payload_from_point<FMT>(x3, y3, gtab, tree, pl);   // P2TR: workgroup-wide (barriers inside)
 
             const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (dump) {
@@ -343,14 +399,15 @@ constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
 
 template <int FMT, bool FULL>
 __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args) {
-    extern __shared__ u32 tab[];   // KEYS_TABLE_WORDS, then (FULL) the DFA blob
+    __shared__ u32 tree[9 * KEYS_WG];   // product tree of the workgroup-wide inversions
+    extern __shared__ u32 dfa_lds[];    // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
-    for (u32 i = tid; i < KEYS_TABLE_WORDS; i += KEYS_WG) tab[i] = args.gtab[i];
-    const u32 *dfa_lds = tab + KEYS_TABLE_WORDS;
-    if (FULL)
-        for (u32 i = tid; i < args.dfa_bytes / 4; i += KEYS_WG) tab[KEYS_TABLE_WORDS + i] = args.dfa_blob[i];
-    __syncthreads();
+    const u32 *tab = args.gtab;         // 8-bit fixed-window generator table in global memory (L2-resident)
+    if (FULL) {
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += KEYS_WG) dfa_lds[i] = args.dfa_blob[i];
+        __syncthreads();
+    }
 
     const u32 idx = blockIdx.x * KEYS_WG + tid;
     const bool in_range = idx < args.n;
@@ -390,11 +447,11 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
     }
 
     gej acc;
-    ec_mul_gen_windows(acc, k, tab);
+    ec_mul_gen_w8(acc, k, tab);
 
-    // to affine (per-lane Fermat inverse), canonical coordinates
+    // to affine — one Fermat inverse for the 256 keys of the workgroup — and canonical coordinates
     fe zi, zi2, zi3, x, y;
-    fe_inv(zi, acc.z);
+    wg_batch_inverse(zi, acc.z, tree);
     fe_sqr(zi2, zi);
     fe_mul(zi3, zi2, zi);
     fe_mul(x, acc.x, zi2);
@@ -403,7 +460,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
     fe_canonicalize(y);
 
     u32 pl[NW];
-    const bool ok = payload_from_point<FMT>(x, y, tab, pl) && valid;
+    const bool ok = payload_from_point<FMT>(x, y, tab, tree, pl) && valid;
 
     if (!in_range) return;
     if (args.dump) {
@@ -426,20 +483,10 @@ template <int FMT>
 static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream) {
     const bool full = a.dfa_bytes && !a.dump;
     if (full && a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
-    const size_t lds_bytes = KEYS_TABLE_WORDS * sizeof(u32) + (full ? a.dfa_bytes : 0);
+    const size_t lds_bytes = full ? a.dfa_bytes : 0;
     const dim3 grid((a.n + KEYS_WG - 1) / KEYS_WG);
-    hipError_t e;
-    if (full) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&keys_scan_kernel<FMT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((keys_scan_kernel<FMT, true>), grid, dim3(KEYS_WG), lds_bytes, stream, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&keys_scan_kernel<FMT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((keys_scan_kernel<FMT, false>), grid, dim3(KEYS_WG), lds_bytes, stream, a);
-    }
+    if (full) hipLaunchKernelGGL((keys_scan_kernel<FMT, true>), grid, dim3(KEYS_WG), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((keys_scan_kernel<FMT, false>), grid, dim3(KEYS_WG), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -488,23 +535,12 @@ hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream) {
 
 template <int FMT>
 static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
-    const size_t tab_bytes = FMT == VGF_P2TR ? KEYS_TABLE_WORDS * sizeof(u32) : 0;
     if (FMT == VGF_P2TR && !a.gtab) return hipErrorInvalidValue;
-    hipError_t e;
     if (a.dfa_bytes && !a.dump) {
         if (a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
-        const size_t lds = tab_bytes + a.dfa_bytes;
-        if (lds > 48 * 1024 &&
-            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seq_bwd_kernel<FMT, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-            return e;
-        hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), lds, stream, a);
+        hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     } else {
-        if (tab_bytes > 48 * 1024 &&
-            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&seq_bwd_kernel<FMT, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes)) != hipSuccess)
-            return e;
-        hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), tab_bytes, stream, a);
+        hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
     }
     return hipGetLastError();
 }

@@ -261,7 +261,7 @@ int payload_from_key(uint32_t format, const uint8_t key_be[32], uint8_t out[32])
         // BIP-341 key path, no script tree (address.rs:136-140): the single-source device algorithm
         static std::vector<uint32_t> tab;
         static std::once_flag once;
-        std::call_once(once, [] { host_gen_table_limbs(tab); });
+        std::call_once(once, [] { host_gen_table8_limbs(tab); });
         u32 xw[8];
         if (!taproot_output_x(p.x, p.y, tab.data(), xw)) return 0;
         for (int i = 0; i < 8; i++) {

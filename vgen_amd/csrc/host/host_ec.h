@@ -48,4 +48,6 @@ namespace vg {
 // The 4-bit fixed-window generator table as the device wants it: [64][15][18] limbs
 // (x limbs 0..8 then y limbs 0..8 of d * 16^w * G, d = 1..15).
 void host_gen_table_limbs(std::vector<uint32_t> &out);
+// The same generator multiples for 8-bit windows: [32][255][20] words (ec_mul_gen_w8, core/ec.h).
+void host_gen_table8_limbs(std::vector<uint32_t> &out);
 }  // namespace vg

@@ -202,7 +202,7 @@ namespace {
 int ensure_gtab(vgen_ctx *c) {
     if (!c->d_gtab) {
         std::vector<uint32_t> tab;
-        host_gen_table_limbs(tab);
+        host_gen_table8_limbs(tab);   // 8-bit windows, 652 800 B (core/ec.h)
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
         HIP_TRY(c, hipMemcpy(c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
