@@ -494,3 +494,28 @@ def test_checkpointed_striped_and_seeded_scans(vg, vo, tmp_path):
         vg.scan_gpu_with_runner("^1zzzzzzzz", vg.ScanConfig(count=None, seed=6, max_batches=1, checkpoint_path=ck4), rs[0])
     for r in rs:
         r.close()
+
+
+# ---- BASELINE-size cross-checks for every format: two independent device algorithms + sampled oracle -------------
+
+
+@pytest.mark.parametrize("fmt", [0, 2, 3, 4, 5])
+def test_full_size_sequential_and_arbitrary_scalar_paths_agree(vg, vo, fmt):
+    """2^20 keys: the sequential path (Q_j +/- R_u with the batched inverse over three kernels) and the
+    arbitrary-scalar path (fixed-window k*G per key, workgroup-shared inverse) must produce the same payloads,
+    and both must equal the oracle on a sample; a dispatch shifted by half a batch must agree on the overlap."""
+    batch, pb = 1 << 20, 32 if fmt == 3 else 20
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt))
+    start = vo.seed_key(7, fmt)
+    seq = dump(r, start)
+    assert len(seq) == pb * batch
+    r.set_filter(None)
+    keys = b"".join((start + i).to_bytes(32, "big") for i in range(batch))
+    r.dispatch_keys(keys, 1)
+    arb, _, _ = r.await_result(1)
+    assert hashlib.sha256(seq).digest() == hashlib.sha256(arb).digest()
+    for i in [0, 1, 7, batch // 2 - 1, batch // 2, batch - 2, batch - 1] + list(range(777, batch, 99991)):
+        assert seq[pb * i:pb * i + pb] == vo.payload(fmt, start + i), i
+    shifted = dump(r, start + batch // 2)
+    assert shifted[: pb * (batch // 2)] == seq[pb * (batch // 2):]
+    r.close()

@@ -328,10 +328,13 @@ class GpuRunner:
         _check(_L.vgen_dispatch(self._h, frame, _key(start_key)), self._h)
 
     def dispatch_keys(self, keys, frame: int):
-        """vgen_dispatch_keys: arbitrary scalars (ints or 32-byte strings), full k*G per key."""
-        blob = b"".join(_key(k) for k in keys)
-        self._n_keys = len(keys)
-        _check(_L.vgen_dispatch_keys(self._h, frame, blob, len(keys)), self._h)
+        """vgen_dispatch_keys: arbitrary scalars (ints, 32-byte strings, or one n*32-byte blob), full k*G per key."""
+        if isinstance(keys, (bytes, bytearray)):     # already n * 32 big-endian bytes
+            blob, n = bytes(keys), len(keys) // 32
+        else:
+            blob, n = b"".join(_key(k) for k in keys), len(keys)
+        self._n_keys = n
+        _check(_L.vgen_dispatch_keys(self._h, frame, blob, n), self._h)
 
     def await_result(self, frame: int):
         """Filter mode: (list of (index, payload20), n_found, keys_tested).  Dump mode: (bytes, 0, keys_tested)."""
