@@ -145,6 +145,13 @@ int core_filter_check(const char *pattern, int ci, unsigned format, const unsign
     }
     return 0;
 }
+// Number of device tests the filter compiler produced (ranges / masked tests), or -1 on pattern error.
+int core_filter_ntests(const char *pattern, int ci, unsigned format) {
+    vgen_filter f;
+    std::string err;
+    if (!filter_compile(pattern, ci != 0, format, f, err)) return -1;
+    return (int)f.dev.count;
+}
 int core_regex_match(const char *pattern, int ci, const char *text) {
     Dfa d;
     std::string err;

@@ -11,6 +11,14 @@
 #include "../device/device_types.h"
 #include "hash.h"
 
+// "some lane of the wave" on the device (a wave-uniform branch the compiler cannot turn into selects), the
+// plain condition on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VG_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+#else
+#define VG_ANY_LANE(cond) (cond)
+#endif
+
 namespace vg {
 
 // -1 / 0 / +1 for 160-bit big-endian word arrays
@@ -95,9 +103,13 @@ VG_HD bool filter_eval_n(const DevFilter *f, const u32 *payload) {
     const u32 n = f->count;
     bool hit = false;
     if (kind == DEVF_RANGES) {   // Base58 prefixes: 20-byte payloads only
+        // The leading word decides almost every key (a range of a k-character prefix spans ~58^-k of the
+        // word space): two compares per range; the five-word comparison runs only for keys whose leading
+        // word falls inside [lo_0, hi_0].
         for (u32 t = 0; t < n; t++) {
             const DevFilterTest &T = f->tests[t];
-            hit = hit || (cmp160(H, T.a) >= 0 && cmp160(H, T.b) <= 0);
+            const bool near = H[0] >= T.a[0] && H[0] <= T.b[0];
+            if (VG_ANY_LANE(near)) hit = hit || (near && cmp160(H, T.a) >= 0 && cmp160(H, T.b) <= 0);
         }
         return hit;
     }

@@ -325,28 +325,29 @@ void derive_symbols(const Dfa &d, const SymSpec &sp, DevFilter &dev, double &sel
     const size_t A = strlen(sp.alphabet);
 
     // (1) accepted prefixes over the data symbols
+    // the shallowest depth that reaches the best selectivity: deeper enumerations of the same language
+    // (e.g. "q" + any symbol for ^bc1qq.*) only multiply the tests
     std::vector<Prefix> prefixes;
     size_t pdepth = 0;
-    for (size_t depth = std::min<size_t>(12, sp.n_data); depth >= 1; depth--) {
-        std::vector<Prefix> p;
-        if (!enumerate_prefixes(d, s, sp.alphabet, depth, 100000, p)) continue;
-        if (p.size() > DEVF_MAX_TESTS) continue;
-        prefixes.swap(p);
-        pdepth = depth;
-        break;
-    }
-    bool prefix_constrains = pdepth > 0;
-    if (prefix_constrains && prefixes.size() == 1 && prefixes[0].s.empty()) prefix_constrains = false;
     double prefix_sel = 1.0;
-    if (prefix_constrains) {
-        prefix_sel = 0;
-        for (auto &p : prefixes) {
+    for (size_t depth = 1; depth <= std::min<size_t>(12, sp.n_data); depth++) {
+        std::vector<Prefix> p;
+        if (!enumerate_prefixes(d, s, sp.alphabet, depth, 100000, p) || p.size() > DEVF_MAX_TESTS) break;
+        double sel_d = 0;
+        for (auto &q : p) {
             double f = 1.0;
-            for (size_t i = 0; i < p.s.size(); i++) f /= (double)A;
-            prefix_sel += f;
+            for (size_t i = 0; i < q.s.size(); i++) f /= (double)A;
+            sel_d += f;
         }
-        if (prefixes.empty()) prefix_sel = 0;
+        if (pdepth == 0 || sel_d < prefix_sel * (1.0 - 1e-9)) {
+            prefixes.swap(p);
+            pdepth = depth;
+            prefix_sel = sel_d;
+        }
     }
+    // prefixes that together cover every string (e.g. the 32 one-symbol prefixes of an unanchored or
+    // suffix-only pattern) constrain nothing: crossing them with the suffixes would only multiply tests
+    bool prefix_constrains = pdepth > 0 && prefix_sel < 0.999999;
 
     // (2) required suffixes: states reachable after t symbols, then suffixes that can accept
     std::vector<std::set<uint32_t>> reach(n_total + 1);
