@@ -212,6 +212,14 @@ VG_HD void fe_canonicalize(fe &r) {
     for (int k = 0; k < 9; k++) r.n[k] = ge ? u[k] : v[k];
 }
 
+// "some lane of the wave" on the device (a wave-uniform branch the compiler cannot turn into selects), the
+// plain condition on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VG_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+#else
+#define VG_ANY_LANE(cond) (cond)
+#endif
+
 // Parity (bit 0) of the canonical representative of a WEAKLY NORMALISED value, without producing the
 // representative: the carry chain of u = v + C alone decides v >= p, and subtracting the odd p flips the parity.
 // 25 instructions instead of fe_canonicalize's 61 — all a compressed public key needs of y.

@@ -11,14 +11,6 @@
 #include "../device/device_types.h"
 #include "hash.h"
 
-// "some lane of the wave" on the device (a wave-uniform branch the compiler cannot turn into selects), the
-// plain condition on the host.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define VG_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
-#else
-#define VG_ANY_LANE(cond) (cond)
-#endif
-
 namespace vg {
 
 // -1 / 0 / +1 for 160-bit big-endian word arrays
