@@ -13,13 +13,19 @@ FULL = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xo
         "v_cmp_le_u32", "v_cmp_ge_u32"}
 
 
-def cost(op):
+def cost(op, mixed=True):
+    """Issue cycles per wave-instruction.  Half-rate ops cost 4.1 (v_mad_u64_u32 4.35) in any stream.  Full-rate
+    ops cost 2.2-2.4 only in a stream of their own kind; next to half-rate ops they cost ~3.4 (a 1:1 mix of
+    v_add_u32 and v_alignbit_b32 measures 3.7-3.8 per instruction, 2:1 3.5-3.6: profiles/r01_ubench_valu.jsonl),
+    which is what the path's code is, so that is the default."""
     base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
     if base == "v_mad_u64_u32":
         return 4.35
     if base == "v_bitop3_b32":
-        return 2.44
-    return 2.25 if base in FULL else 4.1
+        return 3.4 if mixed else 2.44
+    if base in FULL:
+        return 3.4 if mixed else 2.25
+    return 4.1
 
 
 def main():

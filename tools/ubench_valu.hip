@@ -24,7 +24,7 @@
 constexpr int CHAINS = 8;    // independent dependency chains per lane
 constexpr int UNROLL = 32;   // ops per chain per loop trip
 
-enum Op { ADD, ADDC, ADD3, MUL_LO, MUL_HI, MAD64, MAD24, MULHI24, ROTXOR, BFI, XOR3, FMA32, FMA64, LSHLADD, PERM, XOR, LSHLADD64, ADDCO, LSHR64, LSHL64, AND, LSHR32, MOV, BFE, ANDOR, LSHLOR, CNDMASK, MULU24, MADCHAIN };
+enum Op { ADD, ADDC, ADD3, MUL_LO, MUL_HI, MAD64, MAD24, MULHI24, ROTXOR, BFI, XOR3, FMA32, FMA64, LSHLADD, PERM, XOR, LSHLADD64, ADDCO, LSHR64, LSHL64, AND, LSHR32, MOV, BFE, ANDOR, LSHLOR, CNDMASK, MULU24, MADCHAIN, MIX_ADD_ALIGN, MIX_ADD2_ALIGN, MIX_BITOP_ALIGN, MIX_ADD_MAD };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int iters, unsigned long long *clk) {
@@ -82,6 +82,10 @@ __global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int
                 if (OP == LSHLOR) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x[c]) : "v"(y));
                 if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(y) : "vcc");
                 if (OP == MULU24) A3("v_mul_u32_u24");
+                if (OP == MIX_ADD_ALIGN) { if (u & 1) A3("v_add_u32"); else asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[c])); }
+                if (OP == MIX_ADD2_ALIGN) { if (u % 3) A3("v_add_u32"); else asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[c])); }
+                if (OP == MIX_BITOP_ALIGN) { if (u & 1) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x[c]) : "v"(y), "v"(z)); else asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[c])); }
+                if (OP == MIX_ADD_MAD) { if (u & 1) A3("v_add_u32"); else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(x[c]), "v"(y) : "vcc"); }
                 if (OP == MADCHAIN) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(x[c]), "v"(y) : "vcc");
             }
         }
@@ -170,6 +174,10 @@ int main(int argc, char **argv) {
         run<CNDMASK>("v_cndmask_b32", w, iters, dout, 1);
         run<MULU24>("v_mul_u32_u24", w, iters, dout, 1);
         run<MADCHAIN>("v_mad_u64_u32(single dependent chain)", w, iters, dout, 1);
+        run<MIX_ADD_ALIGN>("mix 1:1 v_add_u32 / v_alignbit_b32 (same chain alternates per op)", w, iters, dout, 1);
+        run<MIX_ADD2_ALIGN>("mix 2:1 v_add_u32 / v_alignbit_b32", w, iters, dout, 1);
+        run<MIX_BITOP_ALIGN>("mix 1:1 v_bitop3_b32 / v_alignbit_b32", w, iters, dout, 1);
+        run<MIX_ADD_MAD>("mix 1:1 v_add_u32 / v_mad_u64_u32", w, iters, dout, 1);
     }
     CHECK(hipFree(dout));
     return 0;
