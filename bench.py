@@ -92,8 +92,8 @@ def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1 << 20, help="keys per dispatch (BASELINE config: 2^20)")
     ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "16")))
     ap.add_argument("--format", default="p2pkh", choices=sorted(FORMATS))

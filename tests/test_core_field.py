@@ -37,21 +37,32 @@ def limbs_of(v):
     return out
 
 
+# A product leaves its top fold un-rippled in limbs 0 and 1 (fe.h, "weakly normalised"):
+W0, W1 = M29 + (1 << 23), M29 + (1 << 16)
+
+
 def rand_limbs(rng, mag, style):
-    """limbs of magnitude `mag`: n[0..7] <= mag*(2^29-1), n[8] <= mag*2^24"""
-    hi, top = mag * M29, mag * (1 << 24)
+    """limbs of magnitude `mag` = a sum of `mag` weakly normalised values: n[0] <= mag*(2^29 + 2^23),
+    n[1] <= mag*(2^29 + 2^16), n[2..7] <= mag*(2^29-1), n[8] <= mag*2^24"""
+    his, top = [mag * W0, mag * W1] + [mag * M29] * 6, mag * (1 << 24)
     if style == "max":
-        return [hi] * 8 + [top]
+        return his + [top]
     if style == "min":
         return [0] * 9
     if style == "mixed":
-        return [rng.choice([0, 1, hi, hi - 1, rng.randrange(hi + 1)]) for _ in range(8)] + \
+        return [rng.choice([0, 1, hi, hi - 1, rng.randrange(hi + 1)]) for hi in his] + \
                [rng.choice([0, top, top - 1, rng.randrange(top + 1)])]
-    return [rng.randrange(hi + 1) for _ in range(8)] + [rng.randrange(top + 1)]
+    return [rng.randrange(hi + 1) for hi in his] + [rng.randrange(top + 1)]
 
 
 def check_mag1(limbs):
+    """strictly normalised limbs (fe_normalize / fe_normalize_weak / fe_canonicalize)"""
     assert all(0 <= x <= M29 for x in limbs[:8]) and 0 <= limbs[8] <= (1 << 24), limbs
+
+
+def check_weak(limbs):
+    """the form a product comes out in"""
+    assert limbs[0] <= W0 and limbs[1] <= W1 and all(x <= M29 for x in limbs[2:8]) and limbs[8] < (1 << 24), limbs
 
 
 @pytest.mark.parametrize("ma,mb", [(1, 1), (2, 1), (1, 2), (2, 3), (3, 2), (6, 1), (1, 6), (2, 2)])
@@ -64,7 +75,7 @@ def test_mul_all_magnitudes(core, ma, mb):
                 a, b = rand_limbs(rng, ma, sa), rand_limbs(rng, mb, sb)
                 r = A9()
                 core.core_fe_mul(A9(*a), A9(*b), r)
-                check_mag1(list(r))
+                check_weak(list(r))
                 assert val(r) % P == (val(a) * val(b)) % P, (a, b)
 
 
@@ -74,7 +85,7 @@ def test_sqr(core):
         a = rand_limbs(rng, 1, style)
         r = A9()
         core.core_fe_sqr(A9(*a), r)
-        check_mag1(list(r))
+        check_weak(list(r))
         assert val(r) % P == (val(a) ** 2) % P
 
 
@@ -105,7 +116,7 @@ def test_neg(core, mag):
         r = A9()
         core.core_fe_neg(A9(*a), mag, r)
         assert (val(r) + val(a)) % P == 0
-        assert all(0 <= x <= (mag + 1) * M29 for x in list(r)[:8]) and r[8] <= (mag + 1) * (1 << 24)
+        assert all(0 <= x <= (mag + 1) * W0 for x in list(r)[:8]) and r[8] <= (mag + 1) * (1 << 24)
         assert all(x < 2**32 for x in r)
 
 
@@ -141,11 +152,11 @@ def test_mul_add_and_sqr_add(core, ma, mb, mc):
                     c = rand_limbs(rng, mc, sc) if mc else [0] * 9
                     r = A9()
                     core.core_fe_mul_add(A9(*a), A9(*b), A9(*c), r, 0)
-                    check_mag1(list(r))
+                    check_weak(list(r))
                     assert val(r) % P == (val(a) * val(b) + val(c)) % P
                     if ma == 1:
                         core.core_fe_mul_add(A9(*a), A9(*a), A9(*c), r, 1)
-                        check_mag1(list(r))
+                        check_weak(list(r))
                         assert val(r) % P == (val(a) ** 2 + val(c)) % P
 
 
@@ -158,6 +169,14 @@ def test_canonicalize_weakly_normalised_inputs(core):
     cases = specials + [[rng.choice([0, 1, M29, M29 - 1, rng.randrange(M29 + 1)]) for _ in range(8)] +
                         [rng.choice([0, 1 << 24, (1 << 24) - 1, (1 << 24) + 1, rng.randrange((1 << 24) + 2)])]
                         for _ in range(3000)]
+    # the form products come out in: limbs 0 and 1 carry an un-rippled top fold, n[8] < 2^24 — incl. values that
+    # reach p or 2^256 only once the carries are propagated
+    top = [M29] * 6 + [(1 << 24) - 1]
+    cases += [[W0, W1] + top, [W0, 0] + top, [0, W1] + top, [M29 + 1, M29] + top, [M29 - 976, M29 - 8] + top,
+              [M29 - 975, M29 - 8] + top, [M29 + 1 - 977, M29 - 8] + top]
+    cases += [[rng.choice([0, M29, W0, W0 - 1, rng.randrange(W0 + 1)]), rng.choice([0, M29, W1, rng.randrange(W1 + 1)])] +
+              [rng.choice([0, M29, M29 - 1, rng.randrange(M29 + 1)]) for _ in range(6)] +
+              [rng.choice([0, (1 << 24) - 1, rng.randrange(1 << 24)])] for _ in range(3000)]
     for a in cases:
         r = A9()
         core.core_fe_canonicalize(A9(*a), r)

@@ -37,6 +37,6 @@ if __name__ == "__main__":
     sweep = [(1 << 20, 1, 64), (1 << 20, 2, 128), (1 << 20, 4, 128), (1 << 20, 8, 256), (1 << 24, 2, 16)]
     if len(sys.argv) > 2:
         b = int(os.environ.get("VGEN_PERF_BATCH", str(1 << 20)))
-        sweep = [(b, int(f), max(32, 256 * (1 << 20) // b)) for f in sys.argv[2].split(",")]
+        sweep = [(b, int(f), max(32, int(os.environ.get("VGEN_PERF_STEPS", "256")) * (1 << 20) // b)) for f in sys.argv[2].split(",")]
     for batch, frames, steps in sweep:
         run(batch, frames, steps, fmt)

@@ -1,0 +1,44 @@
+"""Host-side cost of one step of the scan loop, call by call (run on the GPU box)."""
+import sys, time
+sys.path.insert(0, ".")
+import vgen_amd as v
+
+F = 16
+r = v.GpuRunner(batch_size=1 << 20, fmt=v.AddressFormat.P2pkh, frames=F)
+r.set_filter(v.Pattern("^1Cat", False, v.AddressFormat.P2pkh))
+key = 0x3a8ae174e51b7b1117ab406c6570970f453c4376b6d381977db7c02fb5a993e0
+for f in range(F):
+    r.dispatch(key, f); key += 1 << 20
+for f in range(F):
+    r.wait(f)
+# (1) dispatch cost with an idle device
+t = time.perf_counter()
+for f in range(F):
+    r.dispatch(key, f); key += 1 << 20
+td = (time.perf_counter() - t) / F
+time.sleep(0.05)   # everything has finished by now
+# (2) wait cost when the frame is already complete
+t = time.perf_counter()
+for f in range(F):
+    r.wait(f)
+tw = (time.perf_counter() - t) / F
+t = time.perf_counter()
+for f in range(F):
+    r.kernel_ms(f)
+tk = (time.perf_counter() - t) / F
+print("dispatch %.1f us, wait(completed) %.1f us, kernel_ms %.1f us per call" % (td * 1e6, tw * 1e6, tk * 1e6))
+# (3) steady state: how long does wait() block, how long does dispatch take while the device is busy
+N = 512
+tb = tdd = 0.0
+for f in range(F):
+    r.dispatch(key, f); key += 1 << 20
+t0 = time.perf_counter()
+for s in range(N):
+    f = s % F
+    a = time.perf_counter(); r.wait(f); b = time.perf_counter(); r.dispatch(key, f); c = time.perf_counter()
+    key += 1 << 20
+    tb += b - a; tdd += c - b
+dt = time.perf_counter() - t0
+for f in range(F):
+    r.wait(f)
+print("steady state: %.1f us/step = wait %.1f us + dispatch %.1f us  (%.0f Mkeys/s)" % (dt / N * 1e6, tb / N * 1e6, tdd / N * 1e6, N * (1 << 20) / dt / 1e6))

@@ -187,15 +187,13 @@ int vgen_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len) 
 }
 
 int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {
-    if (!ctx || !ms || frame >= ctx->frames) return VGEN_E_INVALID;
-    *ms = ctx->fr[frame].last_ms;
-    return VGEN_OK;
+    if (!ctx || !ms) return VGEN_E_INVALID;
+    return vg::rt_frame_times(ctx, frame, ms, nullptr);
 }
 
 int vgen_frame_dispatch_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {
-    if (!ctx || !ms || frame >= ctx->frames) return VGEN_E_INVALID;
-    *ms = ctx->fr[frame].last_total_ms;
-    return VGEN_OK;
+    if (!ctx || !ms) return VGEN_E_INVALID;
+    return vg::rt_frame_times(ctx, frame, nullptr, ms);
 }
 
 int vgen_address_from_payload(uint32_t format, const uint8_t *payload, char *out, size_t cap) {

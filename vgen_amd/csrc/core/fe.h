@@ -11,11 +11,12 @@
 // be accumulated in 64-bit column sums by chained v_mad_u64_u32 with no carry handling at all,
 // and makes field add/sub/negate nine independent full-rate 32-bit adds.
 //
-// Representation: value = sum n[i] * 2^(29 i).  "magnitude m": n[0..7] <= m*(2^29-1) and
-// n[8] <= m*2^24; m <= 7 always (7*2^29 < 2^32).  Every function states the magnitudes it accepts
-// and returns; products require m_a * m_b <= 6 so that a column sum of nine products of size
-// m_a*m_b*2^58 plus the incoming carry stays below 2^64.  Canonical = magnitude 1 and value < p
-// (fe_normalize).
+// Representation: value = sum n[i] * 2^(29 i).  "magnitude m": a sum of m weakly normalised values, i.e.
+// n[0] <= m*(2^29 + 2^23), n[1] <= m*(2^29 + 2^16), n[2..7] <= m*(2^29-1), n[8] <= m*2^24 (a product leaves its
+// top fold un-rippled in limbs 0 and 1); m <= 7 always (7*(2^29 + 2^23) < 2^32).  Every function states the
+// magnitudes it accepts and returns; products require m_a * m_b <= 6 so that a column sum of nine products
+// of size m_a*m_b*2^58 (1.6 % more where limb 0 takes part) plus the fold terms stays below 2^64.
+// Canonical = strictly normalised limbs (< 2^29, top < 2^24) and value < p (fe_normalize / fe_canonicalize).
 #pragma once
 #include <stdint.h>
 
@@ -147,16 +148,15 @@ VG_HD void fe_mul_columns_(fe &r, const fe &a, const fe &b, const fe *c3) {
     c += D[8];                                   // < 2^36 + 2^32
     const u32 n8 = (u32)c & FE_M24;
     const u32 ov = (u32)(c >> 24);               // < 2^13, weight 2^256 == 2^32 + 977 = 8*2^29 + 977
-    u32 cc = f[0] + ov * 977u;                   // < 2^29 + 2^23
-    r.n[0] = cc & FE_M29; cc >>= 29;
-    cc += f[1] + ov * 8u;
-    r.n[1] = cc & FE_M29; cc >>= 29;
+    // The top fold lands in limbs 0 and 1 and is NOT rippled further: a product is "weakly normalised" with
+    // n[0] < 2^29 + 2^23, n[1] < 2^29 + 2^16, n[2..7] < 2^29, n[8] < 2^24 (value < 2^256 + 2^53).  Every consumer
+    // (products: 1.6 % on one limb against 19 % of slack; fe_neg; the carry chains of fe_canonicalize /
+    // fe_parity_weak / fe_normalize_weak) takes that; the ripple would be 22 instructions per multiplication.
+    r.n[0] = f[0] + ov * 977u;
+    r.n[1] = f[1] + ov * 8u;
 #pragma unroll
-    for (int k = 2; k < 8; k++) {
-        cc += f[k];
-        r.n[k] = cc & FE_M29; cc >>= 29;
-    }
-    r.n[8] = n8 + cc;                            // <= 2^24
+    for (int k = 2; k < 8; k++) r.n[k] = f[k];
+    r.n[8] = n8;
 }
 
 // r = a * b.  Requires m_a * m_b <= 6.  Result magnitude 1.
@@ -180,8 +180,8 @@ VG_HD void fe_sqr_add(fe &r, const fe &a, const fe &c3) {
     fe_mul_columns_<true>(r, a, a, &c3);
 }
 
-// Canonical representative of a WEAKLY NORMALISED value (output of fe_mul / fe_sqr / fe_*_add /
-// fe_normalize_weak: limbs < 2^29, n[8] <= 2^24 + 1).  One carry pass computing both v = value with the
+// Canonical representative of a WEAKLY NORMALISED value (magnitude 1: output of fe_mul / fe_sqr / fe_*_add /
+// fe_normalize_weak; limbs 0 and 1 may carry an un-rippled top fold, n[8] <= 2^24 + 1).  One carry pass computing both v = value with the
 // bits above 2^256 folded back and u = v + C (C = 2^32 + 977 = 2^256 - p); u reaching 2^256 means
 // v >= p and the answer is u - 2^256, otherwise it is v.
 VG_HD void fe_canonicalize(fe &r) {

@@ -343,8 +343,7 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(f.stream));
     f.in_flight = false;
-    (void)hipEventElapsedTime(&f.last_ms, f.ev_mid, f.ev_stop);
-    (void)hipEventElapsedTime(&f.last_total_ms, f.ev_start, f.ev_stop);
+    f.timing_fresh = false;   // elapsed times are read from the events on demand (rt_frame_times)
     if (keys_tested) *keys_tested = f.keys_tested;
     uint32_t found = 0;
     if (!f.dumped) {
@@ -368,6 +367,22 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
         }
     }
     if (n_matches) *n_matches = found;
+    return VGEN_OK;
+}
+
+// Durations of the frame's last completed dispatch: the dominant kernel (seq_bwd / keys) and the whole dispatch.
+int rt_frame_times(vgen_ctx *c, uint32_t frame, float *kernel_ms, float *total_ms) {
+    if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (f.in_flight) return c->fail(VGEN_E_STATE, "frame still in flight");
+    if (!f.timing_fresh) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        (void)hipEventElapsedTime(&f.last_ms, f.ev_mid, f.ev_stop);
+        (void)hipEventElapsedTime(&f.last_total_ms, f.ev_start, f.ev_stop);
+        f.timing_fresh = true;
+    }
+    if (kernel_ms) *kernel_ms = f.last_ms;
+    if (total_ms) *total_ms = f.last_total_ms;
     return VGEN_OK;
 }
 

@@ -43,6 +43,7 @@ struct vgen_ctx {
         bool in_flight = false;
         bool dumped = false;             // last dispatch ran in dump mode
         vg::Scalar start{};
+        bool timing_fresh = true;        // last_ms / last_total_ms already read from the events
         float last_ms = 0.f;             // dominant kernel (seq_bwd) of the last completed dispatch
         float last_total_ms = 0.f;       // whole dispatch: fwd + inv + bwd
     };
@@ -68,6 +69,7 @@ int rt_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint
 int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
             uint64_t *keys_tested);
 int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
+int rt_frame_times(vgen_ctx *ctx, uint32_t frame, float *kernel_ms, float *total_ms);
 int rt_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
 int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);
 
