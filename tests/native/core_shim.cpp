@@ -216,6 +216,12 @@ u32 core_fe_parity_weak(const u32 *a) {
     for (int i = 0; i < 9; i++) x.n[i] = a[i];
     return fe_parity_weak(x);
 }
+void core_fe_canonicalize_product(const u32 *a, u32 *r) {
+    fe x;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    fe_canonicalize_product(x);
+    for (int i = 0; i < 9; i++) r[i] = x.n[i];
+}
 void core_fe_canonicalize(const u32 *a, u32 *r) {
     fe x;
     for (int i = 0; i < 9; i++) x.n[i] = a[i];

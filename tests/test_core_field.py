@@ -182,3 +182,5 @@ def test_canonicalize_weakly_normalised_inputs(core):
         core.core_fe_canonicalize(A9(*a), r)
         assert list(r) == limbs_of(val(a) % P), a
         assert core.core_fe_parity_weak(A9(*a)) == (val(a) % P) & 1, a   # parity without the representative
+        core.core_fe_canonicalize_product(A9(*a), r)                      # one carry pass + rare slow path
+        assert list(r) == limbs_of(val(a) % P), a

@@ -350,7 +350,7 @@ seq_bwd_kernel(const SeqArgs args) {
             for (int i = 0; i < 9; i++) dy.n[i] += q.nqy[i];   // magnitude <= 3
             fe_mul(lam, dy, idx);
             fe_sqr_add(x3, lam, nsum);            // lam^2 - R.x - Q.x, weakly normalised
-            fe_canonicalize(x3);
+            fe_canonicalize_product(x3);
             fe_neg(t, x3, 1);
 #pragma unroll
             for (int i = 0; i < 9; i++) t.n[i] += q.qx[i];                                  // magnitude 3
@@ -358,7 +358,7 @@ seq_bwd_kernel(const SeqArgs args) {
             if (FMT == VGF_P2PKH || FMT == VGF_P2WPKH || FMT == VGF_P2SH_P2WPKH)
                 y3.n[0] = fe_parity_weak(y3);     // a compressed key takes only the parity of y (bit 0 is all that is read)
             else
-                fe_canonicalize(y3);
+                fe_canonicalize_product(y3);
 
             u32 pl[NW];
             const bool ok = payload_from_point<FMT>(x3, y3, gtab, tree, pl);   // P2TR: workgroup-wide (barriers inside)
