@@ -280,7 +280,25 @@ VG_HD void ripemd160_of_sha(const u32 sha[8], u32 out[5]) {
 
 // ---- Keccak-256 of exactly 64 bytes (Ethereum: X || Y) ---------------------------------------------
 
-VG_HD u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+// 64-bit rotate by a constant as two 32-bit funnel shifts (v_alignbit_b32 on the device; hipcc would build it
+// from two 64-bit shifts and two ors).
+VG_HD u32 funnel_r32(u32 hi, u32 lo, int s) {   // low word of {hi,lo} >> s, 0 < s < 32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, (u32)s);
+#else
+    return (lo >> s) | (hi << (32 - s));
+#endif
+}
+template <int N>
+VG_HD u64 rotl64(u64 x) {
+    static_assert(N > 0 && N < 64, "rotation");
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    if (N == 32) return ((u64)lo << 32) | hi;
+    constexpr int M = N & 31;
+    const u32 a = funnel_r32(hi, lo, 32 - M);   // (hi << M) | (lo >> (32 - M))
+    const u32 b = funnel_r32(lo, hi, 32 - M);   // (lo << M) | (hi >> (32 - M))
+    return N < 32 ? (((u64)a << 32) | b) : (((u64)b << 32) | a);
+}
 
 // 3-input boolean on 64-bit lanes = the 32-bit v_bitop3 on each half
 template <u32 TT>
@@ -307,7 +325,7 @@ VG_HD void keccak_f1600(u64 a[25]) {
         const u64 c2 = bitop3_64<0x96>(bitop3_64<0x96>(a[2], a[7], a[12]), a[17], a[22]);
         const u64 c3 = bitop3_64<0x96>(bitop3_64<0x96>(a[3], a[8], a[13]), a[18], a[23]);
         const u64 c4 = bitop3_64<0x96>(bitop3_64<0x96>(a[4], a[9], a[14]), a[19], a[24]);
-        const u64 r0 = rotl64(c0, 1), r1 = rotl64(c1, 1), r2 = rotl64(c2, 1), r3 = rotl64(c3, 1), r4 = rotl64(c4, 1);
+        const u64 r0 = rotl64<1>(c0), r1 = rotl64<1>(c1), r2 = rotl64<1>(c2), r3 = rotl64<1>(c3), r4 = rotl64<1>(c4);
 #define VG_TH0(x) bitop3_64<0x96>(x, c4, r1)
 #define VG_TH1(x) bitop3_64<0x96>(x, c0, r2)
 #define VG_TH2(x) bitop3_64<0x96>(x, c1, r3)
@@ -315,11 +333,11 @@ VG_HD void keccak_f1600(u64 a[25]) {
 #define VG_TH4(x) bitop3_64<0x96>(x, c3, r0)
         // theta + rho + pi into b
         u64 b0 = VG_TH0(a[0]);
-        u64 b10 = rotl64(VG_TH1(a[1]), 1), b20 = rotl64(VG_TH2(a[2]), 62), b5 = rotl64(VG_TH3(a[3]), 28), b15 = rotl64(VG_TH4(a[4]), 27);
-        u64 b16 = rotl64(VG_TH0(a[5]), 36), b1 = rotl64(VG_TH1(a[6]), 44), b11 = rotl64(VG_TH2(a[7]), 6), b21 = rotl64(VG_TH3(a[8]), 55), b6 = rotl64(VG_TH4(a[9]), 20);
-        u64 b7 = rotl64(VG_TH0(a[10]), 3), b17 = rotl64(VG_TH1(a[11]), 10), b2 = rotl64(VG_TH2(a[12]), 43), b12 = rotl64(VG_TH3(a[13]), 25), b22 = rotl64(VG_TH4(a[14]), 39);
-        u64 b23 = rotl64(VG_TH0(a[15]), 41), b8 = rotl64(VG_TH1(a[16]), 45), b18 = rotl64(VG_TH2(a[17]), 15), b3 = rotl64(VG_TH3(a[18]), 21), b13 = rotl64(VG_TH4(a[19]), 8);
-        u64 b14 = rotl64(VG_TH0(a[20]), 18), b24 = rotl64(VG_TH1(a[21]), 2), b9 = rotl64(VG_TH2(a[22]), 61), b19 = rotl64(VG_TH3(a[23]), 56), b4 = rotl64(VG_TH4(a[24]), 14);
+        u64 b10 = rotl64<1>(VG_TH1(a[1])), b20 = rotl64<62>(VG_TH2(a[2])), b5 = rotl64<28>(VG_TH3(a[3])), b15 = rotl64<27>(VG_TH4(a[4]));
+        u64 b16 = rotl64<36>(VG_TH0(a[5])), b1 = rotl64<44>(VG_TH1(a[6])), b11 = rotl64<6>(VG_TH2(a[7])), b21 = rotl64<55>(VG_TH3(a[8])), b6 = rotl64<20>(VG_TH4(a[9]));
+        u64 b7 = rotl64<3>(VG_TH0(a[10])), b17 = rotl64<10>(VG_TH1(a[11])), b2 = rotl64<43>(VG_TH2(a[12])), b12 = rotl64<25>(VG_TH3(a[13])), b22 = rotl64<39>(VG_TH4(a[14]));
+        u64 b23 = rotl64<41>(VG_TH0(a[15])), b8 = rotl64<45>(VG_TH1(a[16])), b18 = rotl64<15>(VG_TH2(a[17])), b3 = rotl64<21>(VG_TH3(a[18])), b13 = rotl64<8>(VG_TH4(a[19]));
+        u64 b14 = rotl64<18>(VG_TH0(a[20])), b24 = rotl64<2>(VG_TH1(a[21])), b9 = rotl64<61>(VG_TH2(a[22])), b19 = rotl64<56>(VG_TH3(a[23])), b4 = rotl64<14>(VG_TH4(a[24]));
 #undef VG_TH0
 #undef VG_TH1
 #undef VG_TH2
