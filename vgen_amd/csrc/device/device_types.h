@@ -97,9 +97,10 @@ struct SeqArgs {
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 
-// Arbitrary-scalar kernel (keys_scan_kernel): one key per lane, full fixed-base multiplication over the 8-bit
-// window table (32 windows x 255 points x 20 words = 652 800 B in global memory, core/ec.h), one shared
-// inversion per workgroup.
+// Arbitrary-scalar path (keys_fwd_kernel -> seq_inv_kernel -> keys_bwd_kernel): one key per lane, full
+// fixed-base multiplication over the 8-bit window table (32 windows x 255 points x 20 words = 652 800 B in
+// global memory, core/ec.h); the Jacobian results go through global scratch and share their inversions exactly as
+// the sequential path does (workgroup product tree, one root per lane in seq_inv_kernel).
 constexpr int KEYS_WG = 256;
 
 struct KeysArgs {
@@ -116,7 +117,10 @@ struct KeysArgs {
     uint32_t fmt;              // VGF_* of the context
     const uint32_t *dfa_blob;  // DEVF_DFA (see SeqArgs)
     uint32_t dfa_bytes;
-    uint32_t pad;
+    uint32_t groups;           // workgroups = ceil(n / KEYS_WG)
+    uint32_t *xyz;             // scratch: Jacobian results, limb-major [27][groups * KEYS_WG] (X, Y, Z limbs)
+    uint32_t *tree;            // scratch: product-tree nodes [groups][9][KEYS_WG]
+    uint32_t *root;            // scratch: tree roots / their inverses [9][groups]
 };
 
 }  // namespace vg

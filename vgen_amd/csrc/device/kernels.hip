@@ -385,34 +385,26 @@ seq_bwd_kernel(const SeqArgs args) {
 
 // ---- arbitrary scalars: full fixed-base multiplication per key ------------------------------------------------
 //
-// The shape of the reference's CPU path (an independent key per iteration, src/scanner.rs:151-155,
-// full ec_pubkey_create each time) on the device: one key per lane, 4-bit fixed windows processed from
-// the least significant one, the 64 x 15 point table staged in LDS (69 KB; entries of one window are
-// 18 dwords apart, i.e. on distinct even banks, identical digits broadcast).  Accumulating low to high
-// with unsigned digits means the running sum is always smaller than the next addend's scalar, so the
-// mixed addition never meets P = +/-Q and needs no branches; the only special case is "still at
-// infinity", handled by a select.  One Fermat inverse per key (this mode is ~45x the work of the
-// sequential mode per key; it also serves the rare sequential batches that touch the group order).
+// The shape of the reference's CPU path (an independent key per iteration, src/scanner.rs:151-155, full
+// ec_pubkey_create each time) on the device, in the same three stages as the sequential path:
+//   keys_fwd_kernel   one key per lane: k*G by 8-bit fixed windows over the global table (31 branch-free mixed
+//                     additions: unsigned digits accumulated low to high keep the running sum below the next
+//                     addend's scalar, so P = +/-Q cannot occur; "still at infinity" is a select); the Jacobian
+//                     result goes to scratch, the Z's of the workgroup into a product tree, its root out.
+//   seq_inv_kernel    the roots of all workgroups, one per lane (shared with the sequential path).
+//   keys_bwd_kernel   tree down-sweep, 1/Z per lane, affine + canonical coordinates, payload, filter.
+// A fused single kernel with the inversion inside (one lone wave inverting while the other three of its
+// workgroup wait) measured 430 Mkeys/s; this form removes that serial section.
+// This mode is ~18x the work of the sequential mode per key; it also serves the rare sequential batches that
+// touch the group order.
 
 constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                             0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
-template <int FMT, bool FULL>
-__global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args) {
-    __shared__ u32 tree[9 * KEYS_WG];   // product tree of the workgroup-wide inversions
-    extern __shared__ u32 dfa_lds[];    // FULL: the DFA blob
-    constexpr int NW = PayloadWords<FMT>::value;
-    const int tid = threadIdx.x;
-    const u32 *tab = args.gtab;         // 8-bit fixed-window generator table in global memory (L2-resident)
-    if (FULL) {
-        for (u32 i = tid; i < args.dfa_bytes / 4; i += KEYS_WG) dfa_lds[i] = args.dfa_blob[i];
-        __syncthreads();
-    }
-
-    const u32 idx = blockIdx.x * KEYS_WG + tid;
+// Scalar of lane `idx` as eight little-endian words; false (and k = 1, a harmless stand-in whose result is
+// discarded) unless 0 < k < n (SecretKey::from_slice, src/address.rs:93) and idx < n.
+__device__ __forceinline__ bool keys_load_scalar(const KeysArgs &args, u32 idx, u32 k[8]) {
     const bool in_range = idx < args.n;
-    // scalar as eight little-endian words
-    u32 k[8];
     if (args.keys_be) {
         const u32 *src = reinterpret_cast<const u32 *>(args.keys_be) + (size_t)(in_range ? idx : 0) * 8;
 #pragma unroll
@@ -430,7 +422,6 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
             for (int i = 0; i < 8; i++) k[i] = 0;
         }
     }
-    // valid iff 0 < k < n (SecretKey::from_slice, src/address.rs:93)
     u32 nz = 0;
     int cmp = 0;
 #pragma unroll
@@ -440,29 +431,113 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
         cmp = cmp == 0 ? d : cmp;
     }
     const bool valid = in_range && nz != 0 && cmp < 0;
-    if (!valid) {   // keep the lane busy with a harmless scalar; its result is discarded
+    if (!valid) {
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = 0;
         k[0] = 1;
     }
+    return valid;
+}
+
+__global__ void __launch_bounds__(KEYS_WG) keys_fwd_kernel(const KeysArgs args) {
+    __shared__ u32 tree[9 * KEYS_WG];
+    const int tid = threadIdx.x;
+    const u32 idx = blockIdx.x * KEYS_WG + tid;
+    const u32 lanes = args.groups * KEYS_WG;
+    u32 k[8];
+    (void)keys_load_scalar(args, idx, k);
 
     gej acc;
-    ec_mul_gen_w8(acc, k, tab);
+    ec_mul_gen_w8(acc, k, args.gtab);
 
-    // to affine — one Fermat inverse for the 256 keys of the workgroup — and canonical coordinates
-    fe zi, zi2, zi3, x, y;
-    wg_batch_inverse(zi, acc.z, tree);
+    u32 *o = args.xyz + idx;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        o[(size_t)i * lanes] = acc.x.n[i];
+        o[(size_t)(9 + i) * lanes] = acc.y.n[i];
+        o[(size_t)(18 + i) * lanes] = acc.z.n[i];
+    }
+    // product tree of the Z's (never zero: 0 < k < n); the leaf level is exchanged by a lane shuffle
+    fe sib, pair;
+    shfl_xor_fe(sib, acc.z, 1);
+    fe_mul(pair, acc.z, sib);
+    if ((tid & 1) == 0) lds_store_fe(tree, KEYS_WG, KEYS_WG / 2 + (tid >> 1), pair);
+    __syncthreads();
+#pragma unroll 1
+    for (int width = KEYS_WG / 4; width >= 1; width >>= 1) {
+        if (tid < width) {
+            const int kk = width + tid;
+            fe a, b, p;
+            lds_load_fe(tree, KEYS_WG, 2 * kk, a);
+            lds_load_fe(tree, KEYS_WG, 2 * kk + 1, b);
+            fe_mul(p, a, b);
+            lds_store_fe(tree, KEYS_WG, kk, p);
+        }
+        __syncthreads();
+    }
+    u32 *tg = args.tree + (size_t)blockIdx.x * 9 * KEYS_WG;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tg[i * KEYS_WG + tid] = tree[i * KEYS_WG + tid];
+    if (tid < 9) args.root[(size_t)tid * args.groups + blockIdx.x] = tree[tid * KEYS_WG + 1];
+}
+
+template <int FMT, bool FULL>
+__global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) {
+    __shared__ u32 tree[9 * KEYS_WG];
+    extern __shared__ u32 dfa_lds[];    // FULL: the DFA blob
+    constexpr int NW = PayloadWords<FMT>::value;
+    const int tid = threadIdx.x;
+    if (FULL)
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += KEYS_WG) dfa_lds[i] = args.dfa_blob[i];
+    const u32 idx = blockIdx.x * KEYS_WG + tid;
+    const u32 lanes = args.groups * KEYS_WG;
+
+    const u32 *tg = args.tree + (size_t)blockIdx.x * 9 * KEYS_WG;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tree[i * KEYS_WG + tid] = tg[i * KEYS_WG + tid];
+    __syncthreads();
+    if (tid < 9) tree[tid * KEYS_WG + 1] = args.root[(size_t)tid * args.groups + blockIdx.x];   // root^-1
+    __syncthreads();
+#pragma unroll 1
+    for (int width = 1; width <= KEYS_WG / 4; width <<= 1) {
+        if (tid < width) {
+            const int kk = width + tid;
+            fe ik, a, b, ia, ib;
+            lds_load_fe(tree, KEYS_WG, kk, ik);
+            lds_load_fe(tree, KEYS_WG, 2 * kk, a);
+            lds_load_fe(tree, KEYS_WG, 2 * kk + 1, b);
+            fe_mul(ia, ik, b);
+            fe_mul(ib, ik, a);
+            lds_store_fe(tree, KEYS_WG, 2 * kk, ia);
+            lds_store_fe(tree, KEYS_WG, 2 * kk + 1, ib);
+        }
+        __syncthreads();
+    }
+    // 1/Z = 1/(Z * Z_sib) * Z_sib
+    fe ip, zs, zi, zi2, zi3, X, Y, x, y;
+    lds_load_fe(tree, KEYS_WG, KEYS_WG / 2 + (tid >> 1), ip);
+    const u32 *in = args.xyz + idx;
+    const u32 *ins = args.xyz + (idx ^ 1u);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        X.n[i] = in[(size_t)i * lanes];
+        Y.n[i] = in[(size_t)(9 + i) * lanes];
+        zs.n[i] = ins[(size_t)(18 + i) * lanes];
+    }
+    fe_mul(zi, ip, zs);
     fe_sqr(zi2, zi);
     fe_mul(zi3, zi2, zi);
-    fe_mul(x, acc.x, zi2);
-    fe_mul(y, acc.y, zi3);
-    fe_canonicalize(x);
-    fe_canonicalize(y);
+    fe_mul(x, X, zi2);
+    fe_mul(y, Y, zi3);
+    fe_canonicalize_product(x);
+    fe_canonicalize_product(y);
 
+    u32 k[8];
+    const bool valid = keys_load_scalar(args, idx, k);
     u32 pl[NW];
-    const bool ok = payload_from_point<FMT>(x, y, tab, tree, pl) && valid;
+    const bool ok = payload_from_point<FMT>(x, y, args.gtab, tree, pl) && valid;   // P2TR: workgroup-wide
 
-    if (!in_range) return;
+    if (idx >= args.n) return;
     if (args.dump) {
         u32 *o = args.dump + (size_t)idx * NW;
 #pragma unroll
@@ -480,13 +555,19 @@ __global__ void __launch_bounds__(KEYS_WG) keys_scan_kernel(const KeysArgs args)
 }
 
 template <int FMT>
-static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream) {
+static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEvent_t before_bwd) {
     const bool full = a.dfa_bytes && !a.dump;
     if (full && a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
-    const size_t lds_bytes = full ? a.dfa_bytes : 0;
-    const dim3 grid((a.n + KEYS_WG - 1) / KEYS_WG);
-    if (full) hipLaunchKernelGGL((keys_scan_kernel<FMT, true>), grid, dim3(KEYS_WG), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((keys_scan_kernel<FMT, false>), grid, dim3(KEYS_WG), 0, stream, a);
+    if (!a.xyz || !a.tree || !a.root || a.groups != (a.n + KEYS_WG - 1) / KEYS_WG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(keys_fwd_kernel, dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (before_bwd && (e = hipEventRecord(before_bwd, stream)) != hipSuccess) return e;
+    if (full) hipLaunchKernelGGL((keys_bwd_kernel<FMT, true>), dim3(a.groups), dim3(KEYS_WG), a.dfa_bytes, stream, a);
+    else hipLaunchKernelGGL((keys_bwd_kernel<FMT, false>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -512,20 +593,20 @@ hipError_t launch_clock_probe(unsigned long long *out, unsigned long long ticks,
     return hipGetLastError();
 }
 
-hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream) {
+hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream, hipEvent_t before_bwd) {
     if (a.n == 0) return hipSuccess;
     switch (fmt) {
     case VGF_P2PKH:
     case VGF_P2WPKH:
-        return launch_keys_fmt<VGF_P2PKH>(a, stream);
+        return launch_keys_fmt<VGF_P2PKH>(a, stream, before_bwd);
     case VGF_P2SH_P2WPKH:
-        return launch_keys_fmt<VGF_P2SH_P2WPKH>(a, stream);
+        return launch_keys_fmt<VGF_P2SH_P2WPKH>(a, stream, before_bwd);
     case VGF_P2PKH_UNCOMPRESSED:
-        return launch_keys_fmt<VGF_P2PKH_UNCOMPRESSED>(a, stream);
+        return launch_keys_fmt<VGF_P2PKH_UNCOMPRESSED>(a, stream, before_bwd);
     case VGF_ETHEREUM:
-        return launch_keys_fmt<VGF_ETHEREUM>(a, stream);
+        return launch_keys_fmt<VGF_ETHEREUM>(a, stream, before_bwd);
     case VGF_P2TR:
-        return launch_keys_fmt<VGF_P2TR>(a, stream);
+        return launch_keys_fmt<VGF_P2TR>(a, stream, before_bwd);
     default:
         return hipErrorInvalidValue;
     }

@@ -126,6 +126,7 @@ void rt_destroy(vgen_ctx *c) {
         if (f.stream) (void)hipStreamSynchronize(f.stream);
         if (f.d_dump) (void)hipFree(f.d_dump);
         if (f.d_keys) (void)hipFree(f.d_keys);
+        if (f.d_keys_scratch) (void)hipFree(f.d_keys_scratch);
         if (f.d_scratch) (void)hipFree(f.d_scratch);
         if (f.d_match) (void)hipFree(f.d_match);
         if (f.h_match) (void)hipHostFree(f.h_match);
@@ -220,6 +221,15 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     a.filter = c->d_filter;
     a.n = n;
     a.fmt = c->format;
+    // scratch of the three stages, sized for a full batch on first use: xyz | tree | root
+    const uint32_t max_groups = (c->batch + KEYS_WG - 1) / KEYS_WG;
+    if (!f.d_keys_scratch)
+        HIP_TRY(c, hipMalloc((void **)&f.d_keys_scratch,
+                             ((size_t)27 * max_groups * KEYS_WG + (size_t)max_groups * 9 * KEYS_WG + (size_t)9 * max_groups) * sizeof(uint32_t)));
+    a.groups = (n + KEYS_WG - 1) / KEYS_WG;
+    a.xyz = f.d_keys_scratch;
+    a.tree = a.xyz + (size_t)27 * max_groups * KEYS_WG;
+    a.root = a.tree + (size_t)max_groups * 9 * KEYS_WG;
     const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
     if (dump) {
         if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
@@ -236,8 +246,7 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
         }
     }
     HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
-    HIP_TRY(c, hipEventRecord(f.ev_mid, f.stream));
-    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.stream));
+    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.stream, f.ev_mid));
     HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
     if (!dump)
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
