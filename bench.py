@@ -114,6 +114,8 @@ def main():
     # devices, barrier / max over gloo).  Never the measured configuration: one rank per GPU over RCCL is.
     rehearse = world > 1 and os.environ.get("VGEN_BENCH_REHEARSE") == "1"
     if rehearse:
+        per_dev = -(-world // torch.cuda.device_count())   # ranks sharing one GPU: split the frames between them,
+        args.frames = max(2, args.frames // per_dev)       # more than ~20 streams per device oversubscribe its queues
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:

@@ -56,7 +56,7 @@ typedef struct vgen_params {
     uint32_t batch_size;   /* keys per dispatch; reference default 524288 (gpu.rs:83); must be a
                               multiple of 8192; 0 selects 1048576 */
     uint32_t format;       /* vgen_format */
-    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 32 */
+    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 20: beyond ~22 streams per device the hardware queues are oversubscribed and throughput collapses */
     uint32_t match_cap;    /* match records kept per dispatch in filter mode; 0 -> 4096 */
     uint32_t flags;        /* reserved, 0 */
 } vgen_params;

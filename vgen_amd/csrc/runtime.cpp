@@ -75,7 +75,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         rt_destroy(c);
         return st;
     };
-    if (c->frames > 32) return bail(VGEN_E_INVALID, "frames must be <= 32");
+    if (c->frames > 20) return bail(VGEN_E_INVALID, "frames must be <= 20 (more streams than hardware queues collapse the throughput)");
     if (c->S < 2 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two in [2, 16]");
     if (c->batch % 8192 != 0 || c->batch % (2 * SEQ_WG * c->S) != 0 || c->batch < 8192)
         return bail(VGEN_E_INVALID, "batch_size must be a multiple of 8192 (and of 512*S)");
