@@ -94,6 +94,11 @@ struct SeqArgs {
     const uint32_t *gtab;      // P2TR: 8-bit fixed-window generator table (global memory) for the tweak multiplication
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
+    // P2TR only: the tweaked points Q = P + t*G of a dispatch wait for a second shared inversion.
+    uint32_t *tq;              // [2S key steps][27][lanes]: X(Q), Z(Q), running product of the lane's Z's
+    uint32_t *tq_flag;         // [2S][lanes]: 1 = the key has an address (valid tweak, Q finite)
+    uint32_t *tree2;           // product tree / roots of the lanes' final products, laid out like tree / root
+    uint32_t *root2;
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 

@@ -310,6 +310,8 @@ seq_bwd_kernel(const SeqArgs args) {
 
     const u32 half = args.n >> 1;
     const bool dump = args.dump != nullptr;
+    fe zrun;            // P2TR: running product of this lane's Z(Q)
+    u32 step = 0;       // P2TR: key step 0 .. 2S-1 in loop order
 
 #pragma unroll 1
     for (int j = (int)S - 1; j >= 0; j--) {
@@ -360,8 +362,29 @@ seq_bwd_kernel(const SeqArgs args) {
             else
                 fe_canonicalize_product(y3);
 
+            if (FMT == VGF_P2TR) {
+                // Taproot, stage A: the tweaked point Q = lift_x(x) + t*G stays Jacobian; X, Z and the lane's
+                // running product of Z's are parked for the second shared inversion (p2tr_finish_kernel).
+                gej qq;
+                const bool okq = taproot_tweak_point(x3, y3, gtab, qq);
+                const bool zero = taproot_z_is_zero(qq.z);   // t*G == -P: no address; keep the products invertible
+                if (zero) fe_set_one(qq.z);
+                if (step == 0) zrun = qq.z;
+                else fe_mul(zrun, zrun, qq.z);
+                u32 *o = args.tq + (size_t)step * 27 * lanes + u;
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    o[(size_t)i * lanes] = qq.x.n[i];
+                    o[(size_t)(9 + i) * lanes] = qq.z.n[i];
+                    o[(size_t)(18 + i) * lanes] = zrun.n[i];
+                }
+                args.tq_flag[(size_t)step * lanes + u] = (okq && !zero) ? 1u : 0u;
+                step++;
+                continue;
+            }
+
             u32 pl[NW];
-            const bool ok = payload_from_point<FMT>(x3, y3, gtab, tree, pl);   // P2TR: workgroup-wide (barriers inside)
+            const bool ok = payload_from_point<FMT>(x3, y3, gtab, tree, pl);
 
             const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (dump) {
@@ -378,6 +401,125 @@ seq_bwd_kernel(const SeqArgs args) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? pl[i] : 0u;
                 }
+            }
+        }
+    }
+    if (FMT == VGF_P2TR) {
+        // product tree of the lanes' final products (as seq_fwd_kernel does for the denominators)
+        __syncthreads();
+        fe sib, pair;
+        shfl_xor_fe(sib, zrun, 1);
+        fe_mul(pair, zrun, sib);
+        if ((tid & 1) == 0) lds_store_fe(tree, WG, WG / 2 + (tid >> 1), pair);
+        __syncthreads();
+#pragma unroll 1
+        for (int width = WG / 4; width >= 1; width >>= 1) {
+            if (tid < width) {
+                const int k = width + tid;
+                fe a, b, p;
+                lds_load_fe(tree, WG, 2 * k, a);
+                lds_load_fe(tree, WG, 2 * k + 1, b);
+                fe_mul(p, a, b);
+                lds_store_fe(tree, WG, k, p);
+            }
+            __syncthreads();
+        }
+        u32 *t2 = args.tree2 + (size_t)blockIdx.x * 9 * WG;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t2[i * WG + tid] = tree[i * WG + tid];
+        if (tid < 9) args.root2[(size_t)tid * args.groups + blockIdx.x] = tree[tid * WG + 1];
+    }
+}
+
+// ---- taproot, stage C: second shared inversion walked back, x(Q), filter ---------------------------------------
+//
+// After seq_bwd_kernel<P2TR> (stage A) and seq_inv_kernel on root2: every lane recovers 1/(product of its 2S
+// Z's) from the tree, then peels 1/Z of each key step off it in reverse order (two multiplications per key, as
+// seq_bwd does for the denominators), x(Q) = X / Z^2, and the usual dump / prefilter / DFA output.
+template <bool FULL>
+__global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
+    __shared__ u32 tree[9 * WG];
+    extern __shared__ u32 dfa_lds[];
+    const int tid = threadIdx.x;
+    if (FULL)
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
+    const u32 S = args.s, lanes = args.lanes;
+    const u32 u = blockIdx.x * WG + tid;
+    const u32 steps = 2 * S;
+
+    const u32 *t2 = args.tree2 + (size_t)blockIdx.x * 9 * WG;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tree[i * WG + tid] = t2[i * WG + tid];
+    __syncthreads();
+    if (tid < 9) tree[tid * WG + 1] = args.root2[(size_t)tid * args.groups + blockIdx.x];   // root^-1
+    __syncthreads();
+#pragma unroll 1
+    for (int width = 1; width <= WG / 4; width <<= 1) {
+        if (tid < width) {
+            const int k = width + tid;
+            fe ik, a, b, ia, ib;
+            lds_load_fe(tree, WG, k, ik);
+            lds_load_fe(tree, WG, 2 * k, a);
+            lds_load_fe(tree, WG, 2 * k + 1, b);
+            fe_mul(ia, ik, b);
+            fe_mul(ib, ik, a);
+            lds_store_fe(tree, WG, 2 * k, ia);
+            lds_store_fe(tree, WG, 2 * k + 1, ib);
+        }
+        __syncthreads();
+    }
+    fe inv;   // 1 / (product of this lane's Z's up to the step being peeled)
+    {
+        fe ip, sib;
+        lds_load_fe(tree, WG, WG / 2 + (tid >> 1), ip);
+#pragma unroll
+        for (int i = 0; i < 9; i++) sib.n[i] = args.tq[((size_t)(steps - 1) * 27 + 18 + i) * lanes + (u ^ 1u)];
+        fe_mul(inv, ip, sib);
+    }
+    const u32 half = args.n >> 1;
+    const bool dump = args.dump != nullptr;
+#pragma unroll 1
+    for (int step = (int)steps - 1; step >= 0; step--) {
+        const u32 *in = args.tq + (size_t)step * 27 * lanes + u;
+        fe X, Z, zi;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            X.n[i] = in[(size_t)i * lanes];
+            Z.n[i] = in[(size_t)(9 + i) * lanes];
+        }
+        if (step > 0) {
+            fe pprev;   // the lane's running product up to the previous step
+            const u32 *prev = args.tq + (size_t)(step - 1) * 27 * lanes + u;
+#pragma unroll
+            for (int i = 0; i < 9; i++) pprev.n[i] = prev[(size_t)(18 + i) * lanes];
+            fe_mul(zi, inv, pprev);
+            fe_mul(inv, inv, Z);
+        } else {
+            zi = inv;
+        }
+        gej qq;
+        qq.x = X;
+        u32 xw[8], pl[8];
+        taproot_affine_x(qq, zi, xw);
+#pragma unroll
+        for (int i = 0; i < 8; i++) pl[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
+        const bool ok = args.tq_flag[(size_t)step * lanes + u] != 0;
+
+        // stage A walks j = S-1 .. 0 and, within j, +R then -R
+        const u32 j = S - 1 - ((u32)step >> 1), sgn = (u32)step & 1u;
+        const u32 index = sgn ? (half - (u + 1) * S + j) : (half + u * S + j);
+        if (dump) {
+            u32 *o = args.dump + (size_t)index * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
+        } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
+            const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+            if (slot < args.match_cap) {
+                DevMatch *m = args.mrec + slot;
+                m->index = index;
+                m->reserved = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) m->payload[i] = pl[i];
             }
         }
     }
@@ -616,13 +758,23 @@ hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream, hipE
 
 template <int FMT>
 static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
-    if (FMT == VGF_P2TR && !a.gtab) return hipErrorInvalidValue;
-    if (a.dfa_bytes && !a.dump) {
-        if (a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
-    } else {
+    const bool full = a.dfa_bytes && !a.dump;
+    if (full && a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
+    if (FMT == VGF_P2TR) {
+        // stage A (tweaked points parked) -> second root inversion -> stage C (finish + filter)
+        if (!a.gtab || !a.tq || !a.tq_flag || !a.tree2 || !a.root2) return hipErrorInvalidValue;
         hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root2, a.groups);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (full) hipLaunchKernelGGL((p2tr_finish_kernel<true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+        else hipLaunchKernelGGL((p2tr_finish_kernel<false>), dim3(a.groups), dim3(WG), 0, stream, a);
+        return hipGetLastError();
     }
+    if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+    else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
     return hipGetLastError();
 }
 

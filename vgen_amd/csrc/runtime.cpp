@@ -127,6 +127,7 @@ void rt_destroy(vgen_ctx *c) {
         if (f.d_dump) (void)hipFree(f.d_dump);
         if (f.d_keys) (void)hipFree(f.d_keys);
         if (f.d_keys_scratch) (void)hipFree(f.d_keys_scratch);
+        if (f.d_p2tr_scratch) (void)hipFree(f.d_p2tr_scratch);
         if (f.d_scratch) (void)hipFree(f.d_scratch);
         if (f.d_match) (void)hipFree(f.d_match);
         if (f.h_match) (void)hipHostFree(f.h_match);
@@ -318,9 +319,19 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         }
     }
     a.fmt = c->format;
-    if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table
+    if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
         if (int rc = ensure_gtab(c)) return rc;
         a.gtab = c->d_gtab;
+        // ... and the tweaked points of the dispatch wait in scratch for their shared inversion:
+        // tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
+        const size_t tq_words = (size_t)2 * S * 27 * c->lanes, flag_words = (size_t)2 * S * c->lanes;
+        const size_t tree_words = (size_t)c->groups * 9 * SEQ_WG, root_words = (size_t)9 * c->groups;
+        if (!f.d_p2tr_scratch)
+            HIP_TRY(c, hipMalloc((void **)&f.d_p2tr_scratch, (tq_words + flag_words + tree_words + root_words) * sizeof(uint32_t)));
+        a.tq = f.d_p2tr_scratch;
+        a.tq_flag = a.tq + tq_words;
+        a.tree2 = a.tq_flag + flag_words;
+        a.root2 = a.tree2 + tree_words;
     }
     HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
     HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream, f.ev_mid));

@@ -36,6 +36,7 @@ struct vgen_ctx {
         uint32_t *d_dump = nullptr;
         uint8_t *d_keys = nullptr;       // explicit keys of vgen_dispatch_keys
         uint32_t *d_keys_scratch = nullptr;   // arbitrary-scalar path: Jacobian results | tree | roots (first use)
+        uint32_t *d_p2tr_scratch = nullptr;   // P2TR: tweaked points | flags | second tree | second roots (first use)
         uint64_t keys_tested = 0;
         uint32_t *d_scratch = nullptr;   // pre | tree | root (device_types.h / kernels.hip)
         uint32_t match_base = 0;         // candidate counter value when the last dispatch was enqueued
