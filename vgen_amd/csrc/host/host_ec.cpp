@@ -2,6 +2,7 @@
 #include "host_ec.h"
 
 #include <mutex>
+#include <thread>
 
 namespace vg {
 
@@ -74,8 +75,11 @@ bool host_ec_mul_gen(const Scalar &k, ge &out) {
     return ge_from_gej(out, acc);
 }
 
-void host_build_stride_table(uint64_t first, uint64_t step, uint32_t count, std::vector<ge> &out) {
-    out.resize(count);
+namespace {
+
+// out[i] = (first + i*step) * G for i in [0, count): one fixed-base multiplication, then a chain of mixed
+// additions converted to affine 4096 at a time (one inversion per chunk).
+void stride_table_range(uint64_t first, uint64_t step, uint32_t count, ge *out) {
     if (count == 0) return;
     Scalar s;
     memset(&s, 0, sizeof s);
@@ -97,10 +101,35 @@ void host_build_stride_table(uint64_t first, uint64_t step, uint32_t count, std:
             jac[i] = cur;
             gej_add_ge(cur, cur, st);
         }
-        host_batch_to_affine(jac.data(), out.data() + done, n);
-        // restart the chain from an affine point to keep Z small-degree (not required, but cheap)
+        host_batch_to_affine(jac.data(), out + done, n);
         done += n;
     }
+}
+
+}  // namespace
+
+// The offset table of a context (65 536 points at the default batch size) is most of vgen_create's time when
+// built by one thread (~55 ms): the range is split over the host's cores.
+void host_build_stride_table(uint64_t first, uint64_t step, uint32_t count, std::vector<ge> &out) {
+    out.resize(count);
+    if (count == 0) return;
+    {
+        Scalar one{};
+        one.w[0] = 1;
+        ge g;
+        host_ec_mul_gen(one, g);
+    }
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : nt > 16 ? 16 : nt;
+    if (count < 8192) nt = 1;
+    const uint32_t per = (count + nt - 1) / nt;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint32_t lo = t * per, hi = lo + per < count ? lo + per : count;
+        if (lo >= hi) break;
+        th.emplace_back([=, &out]() { stride_table_range(first + (uint64_t)lo * step, step, hi - lo, out.data() + lo); });
+    }
+    for (auto &x : th) x.join();
 }
 
 }  // namespace vg

@@ -104,17 +104,24 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     e = hipMalloc((void **)&c->d_filter, sizeof(DevFilter));
     if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(filter): ") + hipGetErrorString(e));
 
+    // One device slab and one pinned slab for all frames: sixteen frames as separate allocations cost ~85 ms of
+    // vgen_create (time to first match, cold); slices are 256-byte aligned.
     c->fr.resize(c->frames);
-    for (auto &f : c->fr) {
-        if ((e = hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)) != hipSuccess ||
-            (e = hipEventCreate(&f.ev_start)) != hipSuccess || (e = hipEventCreate(&f.ev_mid)) != hipSuccess ||
-            (e = hipEventCreate(&f.ev_stop)) != hipSuccess ||
-            (e = hipMalloc((void **)&f.d_scratch, scratch_words(c) * sizeof(uint32_t))) != hipSuccess ||
-            (e = hipMalloc((void **)&f.d_match, match_bytes(c->match_cap))) != hipSuccess ||
-            (e = hipMemset(f.d_match, 0, match_bytes(c->match_cap))) != hipSuccess ||
-            (e = hipHostMalloc((void **)&f.h_match, match_bytes(c->match_cap), hipHostMallocDefault)) != hipSuccess)
-            return bail(VGEN_E_NOMEM, std::string("frame allocation: ") + hipGetErrorString(e));
+    auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    const size_t scratch_b = up256(scratch_words(c) * sizeof(uint32_t)), match_b = up256(match_bytes(c->match_cap));
+    if ((e = hipMalloc((void **)&c->d_slab, (scratch_b + match_b) * c->frames)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_slab, match_b * c->frames, hipHostMallocDefault)) != hipSuccess)
+        return bail(VGEN_E_NOMEM, std::string("frame allocation: ") + hipGetErrorString(e));
+    for (uint32_t i = 0; i < c->frames; i++) {
+        vgen_ctx::Frame &f = c->fr[i];
+        f.d_scratch = reinterpret_cast<uint32_t *>(c->d_slab + (scratch_b + match_b) * i);
+        f.d_match = c->d_slab + (scratch_b + match_b) * i + scratch_b;
+        f.h_match = c->h_slab + match_b * i;
+        // (the frame's stream and events are created on its first dispatch: a stream costs ~5 ms, and a scan's
+        // first frames should be running while the later ones are still being set up)
     }
+    if ((e = hipMemset(c->d_slab, 0, (scratch_b + match_b) * c->frames)) != hipSuccess)
+        return bail(VGEN_E_NOMEM, std::string("frame setup: ") + hipGetErrorString(e));
     *out = c;
     return VGEN_OK;
 }
@@ -128,9 +135,6 @@ void rt_destroy(vgen_ctx *c) {
         if (f.d_keys) (void)hipFree(f.d_keys);
         if (f.d_keys_scratch) (void)hipFree(f.d_keys_scratch);
         if (f.d_p2tr_scratch) (void)hipFree(f.d_p2tr_scratch);
-        if (f.d_scratch) (void)hipFree(f.d_scratch);
-        if (f.d_match) (void)hipFree(f.d_match);
-        if (f.h_match) (void)hipHostFree(f.h_match);
         if (f.ev_start) (void)hipEventDestroy(f.ev_start);
         if (f.ev_mid) (void)hipEventDestroy(f.ev_mid);
         if (f.ev_stop) (void)hipEventDestroy(f.ev_stop);
@@ -141,6 +145,8 @@ void rt_destroy(vgen_ctx *c) {
         (void)hipStreamDestroy(c->probe_stream);
     }
     if (c->d_probe) (void)hipFree(c->d_probe);
+    if (c->d_slab) (void)hipFree(c->d_slab);      // scratch + match rings of all frames
+    if (c->h_slab) (void)hipHostFree(c->h_slab);
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
@@ -200,6 +206,16 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
 
 namespace {
 
+// The frame's stream and timing events, created on first use.
+int ensure_stream(vgen_ctx *c, vgen_ctx::Frame &f) {
+    if (f.stream) return VGEN_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreate(&f.ev_start));
+    HIP_TRY(c, hipEventCreate(&f.ev_mid));
+    HIP_TRY(c, hipEventCreate(&f.ev_stop));
+    return VGEN_OK;
+}
+
 // Enqueues the arbitrary-scalar kernel on frame f: explicit keys (keys_dev != nullptr) or base + i.
 int ensure_gtab(vgen_ctx *c) {
     if (!c->d_gtab) {
@@ -213,6 +229,7 @@ int ensure_gtab(vgen_ctx *c) {
 
 int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
     if (int rc = ensure_gtab(c)) return rc;
+    if (int rc = ensure_stream(c, f)) return rc;
     KeysArgs a;
     memset(&a, 0, sizeof a);
     a.gtab = c->d_gtab;
@@ -267,6 +284,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     scalar_from_be(k0, start_key_be);
     if (!scalar_is_valid(k0)) return c->fail(VGEN_E_RANGE, "start key is not a valid secp256k1 scalar");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_stream(c, f)) return rc;
     f.start = k0;
     // The batched affine additions have no exceptional cases as long as every scalar involved stays
     // below n (SURVEY.md §7 "hard parts"): k0 + N + S < n.  The (astronomically rare) batches that touch
@@ -350,6 +368,7 @@ int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_stream(c, f)) return rc;
     if (!f.d_keys) HIP_TRY(c, hipMalloc((void **)&f.d_keys, (size_t)c->batch * 32));
     HIP_TRY(c, hipMemcpyAsync(f.d_keys, keys_be, (size_t)n * 32, hipMemcpyHostToDevice, f.stream));
     memset(&f.start, 0, sizeof f.start);
@@ -395,7 +414,7 @@ int rt_frame_times(vgen_ctx *c, uint32_t frame, float *kernel_ms, float *total_m
     if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame still in flight");
-    if (!f.timing_fresh) {
+    if (!f.timing_fresh && f.stream) {
         HIP_TRY(c, hipSetDevice(c->device));
         (void)hipEventElapsedTime(&f.last_ms, f.ev_mid, f.ev_stop);
         (void)hipEventElapsedTime(&f.last_total_ms, f.ev_start, f.ev_stop);

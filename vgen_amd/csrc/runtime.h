@@ -50,6 +50,8 @@ struct vgen_ctx {
         float last_total_ms = 0.f;       // whole dispatch: fwd + inv + bwd
     };
     std::vector<Frame> fr;
+    uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch | match ring, per frame)
+    uint8_t *h_slab = nullptr;                   // pinned mirrors of the match rings
     hipStream_t probe_stream = nullptr;          // shader-clock probe (vgen_clock_probe_*)
     unsigned long long *d_probe = nullptr;
     bool probe_running = false;
