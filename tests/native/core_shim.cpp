@@ -100,6 +100,28 @@ int core_mul_gen(const unsigned char *key_be, unsigned char *xy) {
     for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[32 + 4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
     return 1;
 }
+// host_seq_points on one persistent cache: call k asks for the S points of base key kb_be[k] (32 bytes each);
+// xy receives S * 64 bytes per call (x||y big-endian).  Returns the number of successful calls.
+int core_seq_points_walk(const unsigned char *kb_be, int calls, unsigned S, unsigned char *xy) {
+    SeqBaseCache cache;
+    int ok = 0;
+    for (int k = 0; k < calls; k++) {
+        Scalar kb;
+        scalar_from_be(kb, kb_be + 32 * k);
+        ge pts[32];
+        if (!host_seq_points(cache, kb, S, pts)) continue;
+        ok++;
+        for (unsigned e = 0; e < S; e++) {
+            unsigned char *o = xy + ((size_t)k * S + e) * 64;
+            u32 w[8];
+            fe_to_words(pts[e].x, w);
+            for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) o[4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
+            fe_to_words(pts[e].y, w);
+            for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) o[32 + 4 * (7 - i) + j] = (unsigned char)(w[i] >> (24 - 8 * j));
+        }
+    }
+    return ok;
+}
 // stride table entry check: out = x||y of entries
 void core_stride_table(uint64_t first, uint64_t step, uint32_t count, unsigned char *xy) {
     std::vector<ge> t;

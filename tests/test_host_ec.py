@@ -77,3 +77,22 @@ def test_taproot_output_key_device_algorithm(core):
         assert core.core_taproot_from_key(k.to_bytes(32, "big"), out) == 1
         assert out.raw == vo.payload(vo.FMT_P2TR, k), hex(k)
     assert vo.segwit_addr("bc", 1, vo.payload(vo.FMT_P2TR, 1)) == "bc1pmfr3p9j00pfxjh0zmgp99y8zftmd3s5pmedqhyptwy6lm87hf5sspknck9"
+
+
+def test_seq_base_points_cache_walks_jumps_and_rewinds(core):
+    """host_seq_points: per-dispatch uniform points (kb + j)*G from the cache — single incremental steps, the
+    eight-dispatch look-ahead once the stride has repeated, a change of stride, a jump and a rewind."""
+    S = 8
+    base = 0x3a8ae174e51b7b1117ab406c6570970f453c4376b6d381977db7c02fb5a993e0
+    stride = 1 << 20
+    walk = [base + i * stride for i in range(30)]                  # fills and drains the look-ahead three times
+    walk += [walk[-1] + 3 * stride * (i + 1) for i in range(12)]   # another stride
+    walk += [walk[-1] + (1 << 70), walk[-1] + (1 << 70) + stride]  # a jump too large for the incremental path
+    walk += [base + 5 * stride + i * stride for i in range(12)]    # rewind, then the old stride again
+    walk += [N - 100, 1, 2, 3]
+    blob = b"".join(k.to_bytes(32, "big") for k in walk)
+    out = ctypes.create_string_buffer(64 * S * len(walk))
+    assert core.core_seq_points_walk(blob, len(walk), S, out) == len(walk)
+    for c, kb in enumerate(walk):
+        for j in (0, 1, S - 1):
+            assert out.raw[64 * (c * S + j):64 * (c * S + j) + 64] == vo.pubkey(kb + j)[1:], (c, j)

@@ -174,6 +174,71 @@ bool batch_affine_add(const ge *q, const ge &d, uint32_t S, ge *out) {
     return true;
 }
 
+// out[i] = a[i] + b[i] for n <= 256 pairs of affine points, one shared inversion.  false on an exceptional
+// pair (equal x).
+bool batch_affine_add_pairs(const ge *a, const ge *b, uint32_t n, ge *out) {
+    fe dx[256], pre[256];
+    if (n == 0 || n > 256) return false;
+    for (uint32_t j = 0; j < n; j++) {
+        fe_sub_n(dx[j], b[j].x, a[j].x);
+        if (fe_is_zero_any(dx[j])) return false;
+        if (j == 0) pre[0] = dx[0];
+        else fe_mul(pre[j], pre[j - 1], dx[j]);
+    }
+    fe inv;
+    fe_inv(inv, pre[n - 1]);
+    for (uint32_t j = n; j-- > 0;) {
+        fe idx;
+        if (j > 0) {
+            fe_mul(idx, inv, pre[j - 1]);
+            fe_mul(inv, inv, dx[j]);
+        } else {
+            idx = inv;
+        }
+        fe dy, lam, x3, t, y3;
+        fe_sub_n(dy, b[j].y, a[j].y);
+        fe_mul(lam, dy, idx);
+        fe_sqr(x3, lam);
+        fe_sub_n(x3, x3, a[j].x);
+        fe_sub_n(x3, x3, b[j].x);
+        fe_sub_n(t, a[j].x, x3);
+        fe_mul(y3, lam, t);
+        fe_sub_n(y3, y3, a[j].y);
+        fe_normalize(x3);
+        fe_normalize(y3);
+        out[j].x = x3;
+        out[j].y = y3;
+    }
+    return true;
+}
+
+// Fills the look-ahead of `c` (whose q / kb are current and whose stride point is valid).
+void fill_ahead(SeqBaseCache &c) {
+    constexpr uint32_t K = SeqBaseCache::LOOK;
+    c.ahead_n = c.ahead_pos = 0;
+    if (!c.mvalid) {   // (i+1) * delta * G: a chain of mixed additions, one conversion
+        gej jac[K];
+        gej_from_ge(jac[0], c.dpt);
+        for (uint32_t i = 1; i < K; i++) {
+            gej_add_ge(jac[i], jac[i - 1], c.dpt);
+            if (jac[i].inf) return;
+        }
+        host_batch_to_affine(jac, c.mult, K);
+        c.mvalid = true;
+    }
+    ge a[256], b[256], o[256];
+    const uint32_t S = c.S;
+    for (uint32_t i = 0; i < K; i++)
+        for (uint32_t j = 0; j < S; j++) {
+            a[i * S + j] = c.q[j];
+            b[i * S + j] = c.mult[i];
+        }
+    if (!batch_affine_add_pairs(a, b, K * S, o)) return;
+    for (uint32_t i = 0; i < K; i++)
+        for (uint32_t j = 0; j < S; j++) c.ahead[i][j] = o[i * S + j];
+    c.ahead_n = K;
+}
+
 bool seq_points_full(const Scalar &kb, uint32_t S, ge *out) {
     ge base, g;
     if (!host_ec_mul_gen(kb, base)) return false;
@@ -192,6 +257,18 @@ bool seq_points_full(const Scalar &kb, uint32_t S, ge *out) {
 
 bool host_seq_points(SeqBaseCache &c, const Scalar &kb, uint32_t S, ge *out) {
     bool done = false;
+    bool stride_repeated = false;
+    if (c.valid && c.S == S && c.ahead_pos < c.ahead_n && c.dvalid) {
+        // the look-ahead holds kb_prev + delta next: hand it out if that is what is asked for
+        Scalar expect;
+        if (!scalar_add_u64(expect, c.kb, c.delta) && scalar_cmp(expect, kb) == 0) {
+            for (uint32_t j = 0; j < S; j++) out[j] = c.q[j] = c.ahead[c.ahead_pos][j];
+            c.ahead_pos++;
+            c.kb = kb;
+            return true;
+        }
+        c.ahead_n = c.ahead_pos = 0;   // the walk changed course
+    }
     if (c.valid && c.S == S && scalar_cmp(kb, c.kb) > 0) {
         // diff = kb - cache.kb, must fit 64 bits
         Scalar diff;
@@ -211,6 +288,9 @@ bool host_seq_points(SeqBaseCache &c, const Scalar &kb, uint32_t S, ge *out) {
                 ds.w[1] = diff.w[1];
                 c.dvalid = host_ec_mul_gen(ds, c.dpt);
                 c.delta = d;
+                c.mvalid = false;
+            } else {
+                stride_repeated = true;
             }
             if (c.dvalid) done = batch_affine_add(c.q, c.dpt, S, out);
         }
@@ -223,6 +303,8 @@ bool host_seq_points(SeqBaseCache &c, const Scalar &kb, uint32_t S, ge *out) {
     c.S = S;
     c.kb = kb;
     for (uint32_t j = 0; j < S; j++) c.q[j] = out[j];
+    c.ahead_n = c.ahead_pos = 0;
+    if (done && stride_repeated && SeqBaseCache::LOOK * S <= 256) fill_ahead(c);
     return true;
 }
 

@@ -28,8 +28,10 @@ namespace vg {
 // Per-context cache for the per-dispatch uniform points Q_j = (kb + j)*G, j < S.  A scan walks its
 // base scalar forward by a constant stride, so after the first dispatch the S points are advanced by
 // ONE shared-inversion batch of affine additions with the cached stride point instead of a fresh
-// fixed-base multiplication.
+// fixed-base multiplication — and, once the stride has repeated, eight dispatches' worth of points at a time
+// (the Fermat inversion is most of the host's per-dispatch cost).
 struct SeqBaseCache {
+    static constexpr uint32_t LOOK = 8;   // dispatches computed ahead once the stride has repeated
     bool valid = false;
     uint32_t S = 0;
     Scalar kb{};
@@ -37,6 +39,12 @@ struct SeqBaseCache {
     bool dvalid = false;
     uint64_t delta = 0;
     ge dpt;
+    // look-ahead: the point sets of kb + (i+1)*delta, i < ahead_n, all from ONE shared inversion
+    // (LOOK*S affine additions q[j] + (i+1)*delta*G); ahead_pos = next one to hand out
+    bool mvalid = false;
+    ge mult[LOOK];        // (i+1) * delta * G
+    uint32_t ahead_n = 0, ahead_pos = 0;
+    ge ahead[LOOK][32];
 };
 
 // out[j] = (kb + j)*G for j < S.  false if any point is the point at infinity (kb + j == 0 mod n).
