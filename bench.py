@@ -95,7 +95,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1 << 20, help="keys per dispatch (BASELINE config: 2^20)")
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "16")))
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "0")),
+                    help="dispatches in flight per GPU (0 = 16, or 14 beside an RCCL communicator)")
     ap.add_argument("--format", default="p2pkh", choices=sorted(FORMATS))
     ap.add_argument("--pattern", default="^1Cat")
     ap.add_argument("--ci", action="store_true")
@@ -105,6 +106,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.frames <= 0:
+        # A device serves ~22 busy streams before its hardware queues are oversubscribed and throughput collapses;
+        # torch.distributed's RCCL communicator brings streams of its own, so leave it room when it is there.
+        args.frames = 16 if world == 1 else 14
 
     import torch   # first: the process then shares torch's HIP runtime with libvgen_hip.so
     import torch.distributed as dist
