@@ -308,16 +308,8 @@ VG_HD u64 bitop3_64(u64 a, u64 b, u64 c) {
     return ((u64)hi << 32) | lo;
 }
 
-VG_HD void keccak_f1600(u64 a[25]) {
-    constexpr u64 RC[24] = {
-        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
-        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
-        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
-        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-#pragma unroll 1
-    for (int round = 0; round < 24; round++) {
+// One round of Keccak-f[1600] (theta, rho, pi, chi, iota) on the 25 lanes.
+VG_HD void keccak_round(u64 a[25], u64 rc) {
         // theta: column parities as two xor3 each; the "a ^ d" of every lane is one more xor3
         // (d_x = c_{x-1} ^ rotl(c_{x+1}, 1) is never materialised)
         const u64 c0 = bitop3_64<0x96>(bitop3_64<0x96>(a[0], a[5], a[10]), a[15], a[20]);
@@ -345,13 +337,28 @@ VG_HD void keccak_f1600(u64 a[25]) {
 #undef VG_TH4
         // chi: x ^ (~y & z) is the 3-input truth table 0xD2
 #define VG_CHI(x, y, z) bitop3_64<0xD2>(x, y, z)
-        a[0] = VG_CHI(b0, b1, b2) ^ RC[round]; a[1] = VG_CHI(b1, b2, b3); a[2] = VG_CHI(b2, b3, b4); a[3] = VG_CHI(b3, b4, b0); a[4] = VG_CHI(b4, b0, b1);
+        a[0] = VG_CHI(b0, b1, b2) ^ rc; a[1] = VG_CHI(b1, b2, b3); a[2] = VG_CHI(b2, b3, b4); a[3] = VG_CHI(b3, b4, b0); a[4] = VG_CHI(b4, b0, b1);
         a[5] = VG_CHI(b5, b6, b7); a[6] = VG_CHI(b6, b7, b8); a[7] = VG_CHI(b7, b8, b9); a[8] = VG_CHI(b8, b9, b5); a[9] = VG_CHI(b9, b5, b6);
         a[10] = VG_CHI(b10, b11, b12); a[11] = VG_CHI(b11, b12, b13); a[12] = VG_CHI(b12, b13, b14); a[13] = VG_CHI(b13, b14, b10); a[14] = VG_CHI(b14, b10, b11);
         a[15] = VG_CHI(b15, b16, b17); a[16] = VG_CHI(b16, b17, b18); a[17] = VG_CHI(b17, b18, b19); a[18] = VG_CHI(b18, b19, b15); a[19] = VG_CHI(b19, b15, b16);
         a[20] = VG_CHI(b20, b21, b22); a[21] = VG_CHI(b21, b22, b23); a[22] = VG_CHI(b22, b23, b24); a[23] = VG_CHI(b23, b24, b20); a[24] = VG_CHI(b24, b20, b21);
 #undef VG_CHI
-    }
+}
+
+VG_HD void keccak_f1600(u64 a[25]) {
+    constexpr u64 RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    // The first and the last round stand outside the loop so that the compiler specialises them: in round 0 most
+    // lanes of the padded 64-byte message are zero or constants, and of round 23 only lanes 1..3 are read.
+    keccak_round(a, RC[0]);
+#pragma unroll 1
+    for (int round = 1; round < 23; round++) keccak_round(a, RC[round]);
+    keccak_round(a, RC[23]);
 }
 
 // Keccak-256(X || Y) for a 64-byte public key, returning the low 20 bytes of the digest (the
