@@ -225,6 +225,8 @@ def main():
                    "device_filter_kind": pat.device_kind, "candidates_reported": cand},
         "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1),
                      "unit": "Tlaneop/s", "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": traffic,
+                     "hbm_gb_per_s": round(traffic * args.steps / elapsed / 1e9, 1) if traffic else None,
+                     "hbm_frac_of_8TBps": round(traffic * args.steps / elapsed / 8e12, 4) if traffic else None,
                      "kernel": "seq_bwd_kernel", "avg_launch_ms": round(avg_ms, 4), "frames_in_flight": F,
                      "mean_launches_in_flight": round(concurrency, 2), "achieved_per_launch": round(per_launch, 3),
                      "work_per_key": w_bwd, "work_per_key_whole_path": w_key,
