@@ -15,7 +15,8 @@ import ctypes
 from vgen_amd import api
 def disp(f):
     api._check(api._L.vgen_dispatch_keys(r._h, f, blob, batch), r._h)
-disp(0); r.wait(0)
+for f in range(F): disp(f)      # warm-up on every frame (streams and scratch are created on first use)
+for f in range(F): r.wait(f)
 t0 = time.perf_counter()
 steps = 8 * F
 for f in range(F): disp(f)
