@@ -8,8 +8,8 @@
 // (v_add_co/v_addc) issues at half rate AND needs a wait state before its consumer, while
 // v_mad_u64_u32 (32x32+64 -> 64) and v_lshl_add_u64 run at the same half rate with no flags.
 // A reduced radix with 3 spare bits per limb lets all 81 partial products of a multiplication
-// be accumulated in 64-bit column sums by chained v_mad_u64_u32 with no carry handling at all,
-// and makes field add/sub/negate nine independent full-rate 32-bit adds.
+// be accumulated in 64-bit column sums by v_mad_u64_u32 with no carry handling at all (see "column form"
+// below), and makes field add/sub/negate nine independent full-rate 32-bit adds.
 //
 // Representation: value = sum n[i] * 2^(29 i).  "magnitude m": a sum of m weakly normalised values, i.e.
 // n[0] <= m*(2^29 + 2^23), n[1] <= m*(2^29 + 2^16), n[2..7] <= m*(2^29-1), n[8] <= m*2^24 (a product leaves its

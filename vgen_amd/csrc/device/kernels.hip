@@ -121,8 +121,9 @@ struct PayloadWords {
 };
 
 // x, y: canonical affine public key.  out: the payload words in memory order (PayloadWords<FMT>).
-// gtab: the fixed-window generator table in LDS (P2TR only).  Returns false when the key yields no
-// address (P2TR tweak not a valid scalar — probability ~2^-128).
+// tab8: the 8-bit fixed-window generator table in global memory, tree: 9*WG words of LDS (both P2TR only: the
+// arbitrary-scalar path's taproot keys; the sequential path parks its tweaked points instead, see seq_bwd_kernel).
+// Returns false when the key yields no address (P2TR tweak not a valid scalar — probability ~2^-128).
 template <int FMT>
 __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, const u32 *tab8, u32 *tree, u32 *out) {
     u32 xw[8];

@@ -23,7 +23,7 @@ struct vgen_ctx {
     uint32_t payload_words = 5;
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
-    uint32_t *d_gtab = nullptr;          // 4-bit fixed-window generator table (keys kernel), built on first use
+    uint32_t *d_gtab = nullptr;          // 8-bit fixed-window generator table (arbitrary-scalar path, P2TR), built on first use
     vg::DevFilter *d_filter = nullptr;   // current device filter program
     uint32_t *d_dfa = nullptr;           // DEVF_DFA automaton of the current filter
     uint32_t *d_chk_lut = nullptr;       // Bech32 checksum tables of the current filter (when it tests the checksum)
