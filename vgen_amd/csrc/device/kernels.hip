@@ -24,6 +24,12 @@
 //     this is integer work bound by VALU issue, not a contraction.
 //   * Output: dump mode writes 20 B per key (parity / reference-equivalent mode); filter mode writes
 //     only candidate records through a wave-aggregated atomic slot counter.
+//   * The same staging (per-lane work -> product tree -> one root per lane inverted -> finish) carries the two
+//     paths that need a scalar multiplication per key: arbitrary scalars (keys_fwd / keys_bwd) and the taproot
+//     tweak (seq_bwd<P2TR> parks Q = P + t*G, p2tr_finish_kernel completes it).  Fused forms with the inversion
+//     inside one kernel were measured first and lost a third to a half to the lone inverting wave.
+//   * One launch is ~1 wave per SIMD at the default batch, so the device is filled by frames in flight (16
+//     streams, runtime.cpp); seq_bwd is capped at 128 VGPRs so that four launches share a SIMD.
 #include <hip/hip_runtime.h>
 
 #include "../core/dfa_eval.h"
