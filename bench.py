@@ -80,7 +80,7 @@ def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
     # and one thread (SURVEY 8(d) asks for both), on a sample of ~3 s
     n1 = int(max(20000, min(rate / cores * 3.0, 5e6)))
     one = vo.scan_range(fmt, pattern, start, start + n1 - 1, count=10**9, ci=ci, threads=1)
-    return {"value": res["operations"] / res["elapsed_secs"] / 1e6, "unit": "Mkeys/s", "cores": cores, "kind": "port",
+    return {"value": res["operations"] / res["elapsed_secs"] / 1e6, "unit": "Mkeys/sec", "cores": cores, "kind": "port",
             "single_thread_value": one["operations"] / one["elapsed_secs"] / 1e6,
             "sample": f"oracle scan_range (full scalar mult + hash + encode + regex per key) over {res['operations']} "
                       f"consecutive keys from k0(seed=42), {cores} threads, {res['elapsed_secs']:.1f} s "
@@ -214,7 +214,7 @@ def main():
     except (OSError, ValueError):
         pass
     out = {
-        "metric": "Mkeys/s (keys tried per second)", "value": round(value, 2), "unit": "Mkeys/s", "n_gpus": world,
+        "metric": "Mkeys/sec (keys tried per second)", "value": round(value, 2), "unit": "Mkeys/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic (sequential scalars from k0 = SHA-256('vgen-mi355x'||seed=42||shard=0) mod n)",
