@@ -50,6 +50,11 @@ typedef enum vgen_format {
 
 /* Parameters of vgen_create; replaces the arguments of GpuRunner::new(batch_size, backend)
  * (src/gpu.rs:138) plus the buffer sizing it derives from them (src/gpu.rs:391-500). */
+/* vgen_params.flags */
+#define VGEN_FLAG_TIMING 1u   /* record HIP events around every dispatch so that vgen_frame_kernel_ms /
+                                 vgen_frame_dispatch_ms report durations (bench.py); without it a dispatch is
+                                 three kernels and one copy, and the host loop is ~10 us per step cheaper */
+
 typedef struct vgen_params {
     uint32_t struct_size;  /* = sizeof(vgen_params) */
     int32_t device;        /* HIP device ordinal */
@@ -58,7 +63,7 @@ typedef struct vgen_params {
     uint32_t format;       /* vgen_format */
     uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 20: beyond ~22 streams per device the hardware queues are oversubscribed and throughput collapses */
     uint32_t match_cap;    /* match records kept per dispatch in filter mode; 0 -> 4096 */
-    uint32_t flags;        /* reserved, 0 */
+    uint32_t flags;        /* VGEN_FLAG_* */
 } vgen_params;
 
 /* One candidate reported by the device filter.  key = start_key + index.  payload is the 20-byte

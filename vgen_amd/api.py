@@ -302,8 +302,9 @@ class GpuRunner:
     """GpuRunner (src/gpu.rs:116-131): one device, `frames` dispatches in flight."""
 
     def __init__(self, batch_size: int = 1 << 20, fmt: AddressFormat = AddressFormat.P2pkh, device: int = 0,
-                 frames: int = 2, match_cap: int = 4096):
-        p = _Params(ctypes.sizeof(_Params), device, batch_size, int(fmt), frames, match_cap, 0)
+                 frames: int = 2, match_cap: int = 4096, timing: bool = True):
+        # timing: VGEN_FLAG_TIMING — events around every dispatch so that kernel_ms() / dispatch_ms() work
+        p = _Params(ctypes.sizeof(_Params), device, batch_size, int(fmt), frames, match_cap, 1 if timing else 0)
         h = ctypes.c_void_p()
         _check(_L.vgen_create(ctypes.byref(p), ctypes.byref(h)))
         self._h = h

@@ -69,6 +69,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     c->match_cap = p->match_cap ? p->match_cap : 4096;
     c->format = p->format;
     c->payload_words = p->format == VGF_P2TR ? 8 : 5;
+    c->timing = (p->flags & VGEN_FLAG_TIMING) != 0;
     c->S = env_u32("VGEN_SEQ_S", 8);
     auto bail = [&](int st, const std::string &m) {
         err = m;
@@ -120,8 +121,12 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         // (the frame's stream and events are created on its first dispatch: a stream costs ~5 ms, and a scan's
         // first frames should be running while the later ones are still being set up)
     }
-    if ((e = hipMemset(c->d_slab, 0, (scratch_b + match_b) * c->frames)) != hipSuccess)
-        return bail(VGEN_E_NOMEM, std::string("frame setup: ") + hipGetErrorString(e));
+    // The match rings start at zero (monotonic counters); the scratch needs no initialisation.  The frames'
+    // streams do not synchronise with the null stream, so the clears must have finished before vgen_create returns.
+    for (uint32_t i = 0; i < c->frames; i++)
+        if ((e = hipMemset(c->fr[i].d_match, 0, match_bytes(c->match_cap))) != hipSuccess)
+            return bail(VGEN_E_NOMEM, std::string("frame setup: ") + hipGetErrorString(e));
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(VGEN_E_HIP, std::string("frame setup: ") + hipGetErrorString(e));
     *out = c;
     return VGEN_OK;
 }
@@ -263,9 +268,9 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
             a.dfa_bytes = c->h_filter.dfa_bytes;
         }
     }
-    HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
-    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.stream, f.ev_mid));
-    HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
+    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.stream, c->timing ? f.ev_mid : nullptr));
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
     if (!dump)
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
     f.in_flight = true;
@@ -351,9 +356,9 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         a.tree2 = a.tq_flag + flag_words;
         a.root2 = a.tree2 + tree_words;
     }
-    HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
-    HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream, f.ev_mid));
-    HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
+    HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream, c->timing ? f.ev_mid : nullptr));
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
     if (!dump)
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
     f.in_flight = true;
@@ -414,6 +419,7 @@ int rt_frame_times(vgen_ctx *c, uint32_t frame, float *kernel_ms, float *total_m
     if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame still in flight");
+    if (!c->timing) return c->fail(VGEN_E_STATE, "the context was created without VGEN_FLAG_TIMING");
     if (!f.timing_fresh && f.stream) {
         HIP_TRY(c, hipSetDevice(c->device));
         (void)hipEventElapsedTime(&f.last_ms, f.ev_mid, f.ev_stop);

@@ -21,6 +21,7 @@ struct vgen_ctx {
     uint32_t S = 0, lanes = 0, groups = 0;
     vg::SeqBaseCache base_cache;         // host-side incremental base points (host_ec.h)
     uint32_t payload_words = 5;
+    bool timing = false;                 // VGEN_FLAG_TIMING: events around every dispatch
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
     uint32_t *d_gtab = nullptr;          // 8-bit fixed-window generator table (arbitrary-scalar path, P2TR), built on first use
