@@ -205,6 +205,8 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
         c->h_filter.dfa_blob = c->d_dfa;
     }
     HIP_TRY(c, hipMemcpy(c->d_filter, &c->h_filter, sizeof(DevFilter), hipMemcpyHostToDevice));
+    // the uploads ran on the null stream, which the frames' non-blocking streams do not wait for
+    HIP_TRY(c, hipDeviceSynchronize());
     c->have_filter = true;
     return VGEN_OK;
 }
@@ -228,6 +230,7 @@ int ensure_gtab(vgen_ctx *c) {
         host_gen_table8_limbs(tab);   // 8-bit windows, 652 800 B (core/ec.h)
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
         HIP_TRY(c, hipMemcpy(c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipDeviceSynchronize());   // (null-stream upload: see rt_set_filter)
     }
     return VGEN_OK;
 }
