@@ -519,3 +519,21 @@ def test_full_size_sequential_and_arbitrary_scalar_paths_agree(vg, vo, fmt):
     shifted = dump(r, start + batch // 2)
     assert shifted[: pb * (batch // 2)] == seq[pb * (batch // 2):]
     r.close()
+
+
+def test_first_dispatch_right_after_create_is_not_raced_by_setup(vg, vo):
+    """vgen_create clears device memory on the null stream; the frames' streams do not wait for that stream, so
+    the clears must be finished when vgen_create returns (a slab-wide clear once zeroed a running dispatch's
+    scratch).  Fresh contexts, dispatched at once, on several frames."""
+    batch = 1 << 18
+    start = vo.seed_key(99, 0)
+    want = hashlib.sha256(vo.payload_seq(0, start, batch)).digest()
+    for i in range(6):
+        r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=4)
+        r.set_filter(None)
+        for f in range(4):
+            r.dispatch(start, f)
+        for f in range(4):
+            blob, _, _ = r.await_result(f)
+            assert hashlib.sha256(blob).digest() == want, (i, f)
+        r.close()
