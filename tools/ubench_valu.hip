@@ -24,7 +24,7 @@
 constexpr int CHAINS = 8;    // independent dependency chains per lane
 constexpr int UNROLL = 32;   // ops per chain per loop trip
 
-enum Op { ADD, ADDC, ADD3, MUL_LO, MUL_HI, MAD64, MAD24, MULHI24, ROTXOR, BFI, XOR3, FMA32, FMA64, LSHLADD, PERM, XOR, LSHLADD64, ADDCO, LSHR64, LSHL64, AND, LSHR32, MOV, BFE, ANDOR, LSHLOR, CNDMASK, MULU24, MADCHAIN, MIX_ADD_ALIGN, MIX_ADD2_ALIGN, MIX_BITOP_ALIGN, MIX_ADD_MAD };
+enum Op { ADD, ADDC, ADD3, MUL_LO, MUL_HI, MAD64, MAD24, MULHI24, ROTXOR, BFI, XOR3, FMA32, FMA64, LSHLADD, PERM, XOR, LSHLADD64, ADDCO, LSHR64, LSHL64, AND, LSHR32, MOV, BFE, ANDOR, LSHLOR, CNDMASK, MULU24, MADCHAIN, MIX_ADD_ALIGN, MIX_ADD2_ALIGN, MIX_BITOP_ALIGN, MIX_ADD_MAD, MIX_ALT1, MIX_RUN32 };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int iters, unsigned long long *clk) {
@@ -86,6 +86,8 @@ __global__ void __launch_bounds__(256) k_bench(uint32_t *out, uint32_t seed, int
                 if (OP == MIX_ADD2_ALIGN) { if (u % 3) A3("v_add_u32"); else asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[c])); }
                 if (OP == MIX_BITOP_ALIGN) { if (u & 1) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x[c]) : "v"(y), "v"(z)); else asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[c])); }
                 if (OP == MIX_ADD_MAD) { if (u & 1) A3("v_add_u32"); else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(x[c]), "v"(y) : "vcc"); }
+                if (OP == MIX_ALT1) { if ((u + c) & 1) A3("v_add_u32"); else asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[c])); }
+                if (OP == MIX_RUN32) { if (u & 4) A3("v_add_u32"); else asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[c])); }
                 if (OP == MADCHAIN) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(x[c]), "v"(y) : "vcc");
             }
         }
@@ -178,6 +180,8 @@ int main(int argc, char **argv) {
         run<MIX_ADD2_ALIGN>("mix 2:1 v_add_u32 / v_alignbit_b32", w, iters, dout, 1);
         run<MIX_BITOP_ALIGN>("mix 1:1 v_bitop3_b32 / v_alignbit_b32", w, iters, dout, 1);
         run<MIX_ADD_MAD>("mix 1:1 v_add_u32 / v_mad_u64_u32", w, iters, dout, 1);
+        run<MIX_ALT1>("mix 1:1 v_add_u32 / v_alignbit_b32, alternating every instruction", w, iters, dout, 1);
+        run<MIX_RUN32>("mix 1:1 v_add_u32 / v_alignbit_b32, runs of 32 instructions", w, iters, dout, 1);
     }
     CHECK(hipFree(dout));
     return 0;
