@@ -90,34 +90,52 @@ void host_hash160(const uint8_t *msg, size_t len, uint8_t out[20]) {
 static const char B58[] = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz";
 static const char BECH32[] = "qpzry9x8gf2tvdw0s3jn54khce6mua7l";
 
+// Base-58 digits by repeated division of the big-endian number by 58^5 (five digits per pass over the words)
+// instead of one pass per input byte: a match is encoded twice (address, WIF) on the scan thread.
 std::string base58_encode(const uint8_t *data, size_t len) {
     size_t zeros = 0;
     while (zeros < len && data[zeros] == 0) zeros++;
-    std::vector<uint8_t> digits;   // little-endian base 58
-    for (size_t i = zeros; i < len; i++) {
-        uint32_t carry = data[i];
-        for (auto &d : digits) {
-            carry += (uint32_t)d << 8;
-            d = (uint8_t)(carry % 58);
-            carry /= 58;
+    const size_t n = len - zeros;
+    std::string out(zeros, '1');
+    if (n == 0) return out;
+    if (n > 128) return std::string();   // not an address-sized payload
+    uint32_t w[32];
+    const size_t nw = (n + 3) / 4;
+    for (size_t i = 0; i < nw; i++) w[i] = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t pos = nw * 4 - n + i;   // right-aligned
+        w[pos / 4] |= (uint32_t)data[zeros + i] << (8 * (3 - pos % 4));
+    }
+    const uint64_t D5 = 656356768ull;   // 58^5
+    uint8_t digits[256];                // least significant first
+    size_t nd = 0, first = 0;
+    while (first < nw) {
+        uint64_t rem = 0;
+        for (size_t i = first; i < nw; i++) {
+            const uint64_t cur = (rem << 32) | w[i];
+            w[i] = (uint32_t)(cur / D5);
+            rem = cur % D5;
         }
-        while (carry) {
-            digits.push_back((uint8_t)(carry % 58));
-            carry /= 58;
+        while (first < nw && w[first] == 0) first++;
+        uint32_t r = (uint32_t)rem;
+        for (int k = 0; k < 5; k++) {
+            digits[nd++] = (uint8_t)(r % 58);
+            r /= 58;
         }
     }
-    std::string out(zeros, '1');
-    for (size_t i = digits.size(); i-- > 0;) out.push_back(B58[digits[i]]);
+    while (nd > 0 && digits[nd - 1] == 0) nd--;   // leading zero digits of the top chunk
+    for (size_t i = nd; i-- > 0;) out.push_back(B58[digits[i]]);
     return out;
 }
 
 std::string base58check(const uint8_t *payload, size_t len) {
-    std::vector<uint8_t> buf(payload, payload + len);
-    uint8_t d1[32], d2[32];
+    if (len > 64) return std::string();
+    uint8_t buf[68], d1[32], d2[32];
+    memcpy(buf, payload, len);
     host_sha256(payload, len, d1);
     host_sha256(d1, 32, d2);
-    buf.insert(buf.end(), d2, d2 + 4);
-    return base58_encode(buf.data(), buf.size());
+    memcpy(buf + len, d2, 4);
+    return base58_encode(buf, len + 4);
 }
 
 static uint32_t polymod_step(uint32_t c, uint32_t v) {
