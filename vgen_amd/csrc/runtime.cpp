@@ -143,7 +143,6 @@ void rt_destroy(vgen_ctx *c) {
         if (f.ev_start) (void)hipEventDestroy(f.ev_start);
         if (f.ev_mid) (void)hipEventDestroy(f.ev_mid);
         if (f.ev_stop) (void)hipEventDestroy(f.ev_stop);
-        if (f.ev_done) (void)hipEventDestroy(f.ev_done);
         if (f.stream) (void)hipStreamDestroy(f.stream);
     }
     if (c->probe_stream) {
@@ -221,7 +220,6 @@ int ensure_stream(vgen_ctx *c, vgen_ctx::Frame &f) {
     HIP_TRY(c, hipEventCreate(&f.ev_start));
     HIP_TRY(c, hipEventCreate(&f.ev_mid));
     HIP_TRY(c, hipEventCreate(&f.ev_stop));
-    HIP_TRY(c, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
     return VGEN_OK;
 }
 
@@ -278,7 +276,6 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
     if (!dump)
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
-    HIP_TRY(c, hipEventRecord(f.ev_done, f.stream));   // what vgen_wait waits on (see rt_wait)
     f.in_flight = true;
     f.dumped = dump;
     f.keys_tested = n;
@@ -367,7 +364,6 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
     if (!dump)
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
-    HIP_TRY(c, hipEventRecord(f.ev_done, f.stream));   // what vgen_wait waits on (see rt_wait)
     f.in_flight = true;
     f.dumped = dump;
     f.keys_tested = c->batch;
@@ -392,10 +388,7 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
     vgen_ctx::Frame &f = c->fr[frame];
     if (!f.in_flight) return c->fail(VGEN_E_STATE, "No pending operation on frame " + std::to_string(frame));
     HIP_TRY(c, hipSetDevice(c->device));
-    // Waiting on an event recorded after the dispatch's last command costs ~1 us once it has fired;
-    // hipStreamSynchronize on a stream that ends in a kernel or a copy submits a marker and waits for its round
-    // trip (~17 us even when everything finished long ago).
-    HIP_TRY(c, hipEventSynchronize(f.ev_done));
+    HIP_TRY(c, hipStreamSynchronize(f.stream));
     f.in_flight = false;
     f.timing_fresh = false;   // elapsed times are read from the events on demand (rt_frame_times)
     if (keys_tested) *keys_tested = f.keys_tested;

@@ -34,7 +34,6 @@ struct vgen_ctx {
     struct Frame {
         hipStream_t stream = nullptr;
         hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;   // before fwd / before bwd / after bwd
-        hipEvent_t ev_done = nullptr;    // after the dispatch's last command: what vgen_wait waits on
         uint32_t *d_dump = nullptr;
         uint8_t *d_keys = nullptr;       // explicit keys of vgen_dispatch_keys
         uint32_t *d_keys_scratch = nullptr;   // arbitrary-scalar path: Jacobian results | tree | roots (first use)
