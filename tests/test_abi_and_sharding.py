@@ -104,3 +104,31 @@ def test_cli_warns_about_impossible_patterns_before_touching_the_device():
     assert "Base58 excludes" not in out.stderr
     out = subprocess.run([exe, "generate", "-p", "^1Cat"], capture_output=True, text=True, timeout=60)
     assert "Warning" not in out.stderr
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/vgen_hip.h must compile as C99 and a C program must link against
+    libvgen_hip.so (no C++ types or torch in the signatures).  Only calls that need no device are made."""
+    import vgen_amd as vg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "vgen_hip.h"\n'
+                   'int main(void) {\n'
+                   '  unsigned char k[32] = {0}, out[32]; char addr[128], wif[128], bad[8]; size_t n = 0; unsigned long long d = 0;\n'
+                   '  k[31] = 1;\n'
+                   '  if (vgen_abi_version() != VGEN_ABI_VERSION) return 1;\n'
+                   '  if (vgen_derive(VGEN_FMT_P2PKH, k, addr, sizeof addr, wif, sizeof wif) != VGEN_OK) return 2;\n'
+                   '  if (strcmp(addr, "1BgGZ9tcN4rm9KBzDn7KprQz87SZ26SAMH")) return 3;\n'
+                   '  if (vgen_key_add(k, 41, out) != VGEN_OK || out[31] != 42) return 4;\n'
+                   '  if (vgen_pattern_invalid_chars("^1O0", 0, VGEN_FMT_P2PKH, bad, sizeof bad, &n) != VGEN_OK || n != 2) return 5;\n'
+                   '  if (vgen_pattern_difficulty("^1Ab", 0, VGEN_FMT_P2PKH, (uint64_t *)&d) != VGEN_OK || d != 3364) return 6;\n'
+                   '  printf("%s %s\\n", addr, wif);\n  return 0;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(vg.library_path())
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                         "-o", str(exe), "-L", libdir, "-lvgen_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0, (run.returncode, run.stderr)
+    assert run.stdout.split()[0] == "1BgGZ9tcN4rm9KBzDn7KprQz87SZ26SAMH"
