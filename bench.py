@@ -2,19 +2,24 @@
 """bench.py — headline benchmark of the MI355X scan engine (driver contract: see README/DESIGN.md).
 
 Metric (BASELINE.json): Mkeys/s = keys tested per second, whole job over all GPUs.
-Workload at N=1 (BASELINE configs[1]): P2PKH, pattern "^1Cat", 2^20 keys per dispatch, compressed
-public keys, sequential scalars k0(seed=42) + i, inputs resident on the device (the only per-dispatch
-upload is the 1-2 KB of base points).  A "step" is one dispatch of the hot path over 2^20 keys;
-`frames` dispatches are kept in flight the way the reference's scan loop keeps 2 (src/gpu.rs:399); the
-default here is 6, one HIP stream / hardware queue each, so that one dispatch's serial root inversion
-overlaps the others' full-chip stages.
-For N>1 (python -m torch.distributed.run ... bench.py --gpus N) every rank drives its own GPU over
-batch-striped disjoint scalar ranges — no data-path collective; torch.distributed only provides the
-barriers and the max-over-ranks of the elapsed time.
+Workload at N=1 (BASELINE configs[1]): P2PKH, pattern "^1Cat", 2^20 keys per dispatch, compressed public keys,
+sequential scalars k0(seed=42) + i, inputs resident on the device (the only per-dispatch upload is the 1-2 KB of
+base points in the kernel arguments).  A "step" is one dispatch of the hot path over 2^20 keys; `frames`
+dispatches are kept in flight the way the reference's scan loop keeps 2 (src/gpu.rs:399) — 20 here, every frame on
+a stream that owns a hardware queue (no GPU_MAX_HW_QUEUES involved), because one launch of the per-key kernel is
+only one wave per SIMD and a dispatch is a chain of dependent launches.
+For N>1 (python -m torch.distributed.run ... bench.py --gpus N) every rank drives its own GPU over batch-striped
+disjoint scalar ranges — no data-path collective; torch.distributed only provides the barriers and the
+max-over-ranks of the elapsed time.
 
-Extra objects on the JSON line: "roofline" (integer-VALU bound: SURVEY.md §8(d), re-based on the
-measured issue rates in profiles/r01_ubench_valu.jsonl) and, on rank 0 at N=1, "cpu_baseline" (the
-CPU oracle — a port of the reference's rayon path — timed on a bounded sample on this box's cores).
+The JSON line: `value` is measured over EXACTLY --steps dispatches between two barrier+synchronize brackets (the
+contract).  Because a short region is mostly pipeline fill and drain (20 steps = 2 ms), the same loop is also run
+for >= 3 s of wall time: `sustained`.  Further objects: `roofline` (integer-VALU bound; SURVEY.md §8(d) yardstick
+re-based on measured issue rates; chip-level fraction from wall time, the kernel's lone-launch rate from a
+frames=1 pass timed with HIP events, and the issue-side counters VALU-busy / instructions per key from the
+committed PMC pass under profiles/), `other_configs` (the other single-GPU BASELINE configurations and modes,
+>= 1 s each), `time_to_first_match`, and `cpu_baseline` (the CPU oracle — a port of the reference's rayon path —
+on this box's cores; rank 0, N=1 only).
 """
 import argparse
 import hashlib
@@ -25,9 +30,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# One hardware queue per frame stream (the HIP default of 4 makes frames share queues and serialise);
-# must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 N_ORDER = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 FORMATS = {"p2pkh": 0, "p2wpkh": 1, "p2sh-p2wpkh": 2, "p2tr": 3, "p2pkh-uncompressed": 4, "ethereum": 5}
@@ -44,8 +46,13 @@ W_IOP = {"p2pkh": 550 + 1450 + 1130 + 20, "p2wpkh": 550 + 1450 + 1130 + 20 + 500
          "ethereum": 550 + 6400 + 20, "p2tr": 550 + 1450 + 20 + 500 + 990 * 60}
 R_MUL = 2
 # peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz full-rate integer lane-ops (MI355X_MICROARCH.md: SIMD-32,
-# 2400 MHz; equals the 157.3 TFLOP/s fp32 vector peak / 2).  Measured sustained: 64.7 T/s.
+# 2400 MHz; equals the 157.3 TFLOP/s fp32 vector peak / 2).
 PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+N_SIMD = 256 * 4
+
+
+def work_per_key(fmt_name):
+    return W_IMUL[fmt_name] * R_MUL + W_IOP[fmt_name]
 
 
 def seed_key(seed, shard=0):
@@ -53,6 +60,11 @@ def seed_key(seed, shard=0):
     k = int.from_bytes(d, "big") % N_ORDER
     assert k != 0
     return k
+
+
+def batch_key(k0, step, world, rank, n):
+    """Batch striping: global batch b = step * world + rank covers [k0 + b*n, k0 + (b+1)*n)."""
+    return k0 + (step * world + rank) * n
 
 
 def usable_cores():
@@ -89,46 +101,178 @@ def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
                       "rayon path (README.md:175)"}
 
 
+class Pipeline:
+    """The benchmark's dispatch loop over one runner: keep `frames` dispatches in flight, consume in order."""
+
+    def __init__(self, runner, k0, world=1, rank=0):
+        self.r, self.k0, self.world, self.rank = runner, k0, world, rank
+        self.n, self.f = runner.batch_size, runner.frames
+        self.next_step = 0
+
+    def run_steps(self, n_steps, collect=False):
+        """Exactly n_steps dispatches, all completed on return.  -> (candidates, [seq_bwd ms])"""
+        r, F = self.r, self.f
+        cand, kms, issued, done, fi, fw = 0, [], 0, 0, 0, 0
+        first = self.next_step
+        while issued < min(F, n_steps):
+            r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), fi)
+            issued += 1
+            fi = (fi + 1) % F
+        while done < n_steps:
+            n, _ = r.wait(fw)
+            if collect:
+                kms.append(r.kernel_ms(fw))
+            cand += n
+            done += 1
+            if issued < n_steps:
+                r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), fw)
+                issued += 1
+            fw = (fw + 1) % F
+        self.next_step = first + n_steps
+        return cand, kms
+
+    def run_seconds(self, seconds, min_steps=0):
+        """Dispatches until `seconds` of wall time have passed (checked every `frames` completions), then drains.
+        -> (dispatches, elapsed seconds incl. fill and drain)"""
+        r, F = self.r, self.f
+        first = self.next_step
+        t0 = time.perf_counter()
+        issued = done = 0
+        for f in range(F):
+            r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), f)
+            issued += 1
+        fw = 0
+        stop = False
+        while done < issued:
+            r.wait(fw)
+            done += 1
+            if not stop and fw == F - 1:
+                stop = time.perf_counter() - t0 >= seconds and issued >= min_steps
+            if not stop:
+                r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), fw)
+                issued += 1
+            fw = (fw + 1) % F
+        self.next_step = first + issued
+        return issued, time.perf_counter() - t0
+
+
+def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, label, note=None):
+    """One `other_configs` entry: sustained rate of the dispatch loop for another format / pattern."""
+    fmt = vg.AddressFormat(FORMATS[fmt_name])
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False)
+    pat = vg.Pattern(pattern, ci, fmt)
+    r.set_filter(pat if pat.device_kind != 0 else None)
+    p = Pipeline(r, seed_key(42, 0))
+    p.run_steps(2 * frames)
+    n, dt = p.run_seconds(seconds)
+    r.close()
+    rate = n * batch / dt
+    out = {"config": label, "format": fmt_name, "pattern": pattern + (" -i" if ci else ""), "value": round(rate / 1e6, 1),
+           "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": n, "device_filter_kind": pat.device_kind,
+           "chip_frac": round(rate * work_per_key(fmt_name) / 1e12 / PEAK_TLANEOPS, 4)}
+    if note:
+        out["note"] = note
+    return out
+
+
+def keys_mode_config(vg, batch, frames, device, seconds):
+    """Arbitrary-scalar (KEYS) mode: the 'random 256-bit scalar' reading of north_star — a full fixed-base
+    multiplication per key; the 32 B/key are uploaded by every dispatch (the rate includes that PCIe traffic)."""
+    import random
+    fmt = vg.AddressFormat.P2pkh
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False)
+    r.set_filter(vg.Pattern("^1Cat", False, fmt))
+    rng = random.Random(42)
+    blob = b"".join((rng.getrandbits(256) % (N_ORDER - 1) + 1).to_bytes(32, "big") for _ in range(4096)) * (batch // 4096)
+    for f in range(frames):
+        r.dispatch_keys(blob, f)
+    for f in range(frames):
+        r.wait(f)
+    t0 = time.perf_counter()
+    issued = done = fw = 0
+    for f in range(frames):
+        r.dispatch_keys(blob, f)
+        issued += 1
+    while done < issued:
+        r.wait(fw)
+        done += 1
+        if time.perf_counter() - t0 < seconds:
+            r.dispatch_keys(blob, fw)
+            issued += 1
+        fw = (fw + 1) % frames
+    dt = time.perf_counter() - t0
+    r.close()
+    return {"config": "arbitrary-scalar (KEYS) mode, P2PKH '^1Cat'", "format": "p2pkh", "pattern": "^1Cat",
+            "value": round(issued * batch / dt / 1e6, 1), "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": issued,
+            "note": "vgen_dispatch_keys: 2^20 independent scalars per dispatch, full k*G each (8-bit fixed windows); "
+                    "includes the 32 MB host-to-device upload of every dispatch"}
+
+
+def dump_mode_configs(vg, batch, device, seconds):
+    """The reference's own mode (every payload back to the host, src/gpu.rs:602-658,1030-1093): (a) the device +
+    PCIe side alone, (b) a whole scan whose pattern is too permissive for the match ring, filtered on the host."""
+    fmt = vg.AddressFormat.P2pkh
+    frames = 4
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False)
+    r.set_filter(None)
+    p = Pipeline(r, seed_key(42, 0))
+    p.run_steps(2 * frames)
+    n, dt = p.run_seconds(seconds)
+    out = [{"config": "dump mode, device + PCIe only (20 B/key copied to pinned host memory by every dispatch)",
+            "format": "p2pkh", "pattern": None, "value": round(n * batch / dt / 1e6, 1), "unit": "Mkeys/sec",
+            "seconds": round(dt, 2), "dispatches": n,
+            "pcie_gb_per_s": round(n * batch * 20 / dt / 1e9, 1),
+            "note": "bound by the 20 B/key device-to-host copy, not by the kernels"}]
+    t0 = time.perf_counter()
+    res = vg.scan_gpu_with_runner("^1C", vg.ScanConfig(format=fmt, count=None, seed=42, max_batches=8), r)
+    dt = time.perf_counter() - t0
+    r.close()
+    out.append({"config": "host-filter scan (pattern too permissive for the match ring: every key encoded and matched on the host)",
+                "format": "p2pkh", "pattern": "^1C", "value": round(res.operations / dt / 1e6, 2), "unit": "Mkeys/sec",
+                "seconds": round(dt, 2), "dispatches": res.operations // batch, "matches": len(res.matches),
+                "host_threads": usable_cores(),
+                "note": "the reference's only mode; bound by Base58Check encoding + regex on the host cores"})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1 << 20, help="keys per dispatch (BASELINE config: 2^20)")
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "0")),
-                    help="dispatches in flight per GPU (0 = 16, or 14 beside an RCCL communicator)")
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "20")),
+                    help="dispatches in flight per GPU")
     ap.add_argument("--format", default="p2pkh", choices=sorted(FORMATS))
     ap.add_argument("--pattern", default="^1Cat")
     ap.add_argument("--ci", action="store_true")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0, help="wall time of the `sustained` leg (0 = skip)")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.frames <= 0:
-        # A device serves ~22 busy streams before its hardware queues are oversubscribed and throughput collapses;
-        # torch.distributed's RCCL communicator brings streams of its own, so leave it room when it is there.
-        args.frames = 16 if world == 1 else 14
 
     import torch   # first: the process then shares torch's HIP runtime with libvgen_hip.so
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
     # VGEN_BENCH_REHEARSE=1: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share
-    # devices, barrier / max over gloo).  Never the measured configuration: one rank per GPU over RCCL is.
+    # devices).  Never the measured configuration: one rank per GPU is.
     rehearse = world > 1 and os.environ.get("VGEN_BENCH_REHEARSE") == "1"
     if rehearse:
-        per_dev = -(-world // torch.cuda.device_count())   # ranks sharing one GPU: split the frames between them,
-        args.frames = max(2, args.frames // per_dev)       # more than ~20 streams per device oversubscribe its queues
+        per_dev = -(-world // torch.cuda.device_count())   # ranks sharing one GPU split the frames between them:
+        args.frames = max(2, args.frames // per_dev)       # more than ~20 busy queues per device collapse the throughput
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # The data path has no collective (disjoint scalar ranges): the process group only carries the barriers and
+        # the max of the elapsed time, so it runs over gloo — no RCCL communicator, no extra device queues beside
+        # the frames' own.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
     import vgen_amd as vg
     fmt = vg.AddressFormat(FORMATS[args.format])
@@ -136,83 +280,104 @@ def main():
     pat = vg.Pattern(args.pattern, args.ci, fmt)
     runner.set_filter(pat if pat.device_kind != 0 else None)
     N, F = runner.batch_size, runner.frames
-    k0 = seed_key(42, 0)
-
-    def key_of(step):   # batch striping: global batch b = step * world + rank
-        return k0 + (step * world + rank) * N
-
-    def run(first_step, n_steps, collect):
-        cand = 0
-        kms = []
-        issued = done = 0
-        frame_issue = frame_wait = 0
-        while issued < min(F, n_steps):
-            runner.dispatch(key_of(first_step + issued), frame_issue)
-            issued += 1
-            frame_issue = (frame_issue + 1) % F
-        while done < n_steps:
-            n, _ = runner.wait(frame_wait)
-            if collect:
-                kms.append(runner.kernel_ms(frame_wait))
-            cand += n
-            done += 1
-            if issued < n_steps:
-                runner.dispatch(key_of(first_step + issued), frame_wait)
-                issued += 1
-            frame_wait = (frame_wait + 1) % F
-        return cand, kms
+    pipe = Pipeline(runner, seed_key(42, 0), world, rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # warm-up: the first pass over the frames also creates their streams (milliseconds each), so the step time
     # that sizes the clock probe is taken from the rest of the warm-up only
     if args.warmup < F:   # set-up, not a step: every frame gets its stream before anything is timed
-        run(0, F, False)
+        pipe.run_steps(F)
     w_first = min(args.warmup, F)
-    run(0, w_first, False)
+    pipe.run_steps(w_first)
     tw = time.perf_counter()
-    run(w_first, args.warmup - w_first, False)
+    pipe.run_steps(args.warmup - w_first)
     barrier()
     per_step_ms = (time.perf_counter() - tw) / max(1, args.warmup - w_first) * 1e3 if args.warmup > w_first else 0.0
-    # shader-clock probe beside the timed region (one sleeping wave on its own stream), sized to end well
-    # before the region does so that the closing synchronize never waits for it
-    probe_ms = int(min(2000.0, 0.4 * per_step_ms * args.steps))
-    if os.environ.get("VGEN_BENCH_PROBE") == "0":
-        probe_ms = 0
-    if probe_ms >= 2:
-        runner.clock_probe_start(probe_ms)
-    t0 = time.perf_counter()
-    cand, kms = run(args.warmup, args.steps, True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    shader_mhz = runner.clock_probe_read() if probe_ms >= 2 else None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
+    # ---- the contract's timed region: exactly --steps dispatches between two barrier + synchronize brackets ----
+    t0 = time.perf_counter()
+    cand, kms = pipe.run_steps(args.steps, collect=True)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     keys = world * args.steps * N
     value = keys / elapsed / 1e6
-    w_key = W_IMUL[args.format] * R_MUL + W_IOP[args.format]
+
+    # ---- the same loop for >= 3 s of wall time, with the shader-clock probe beside it ----
+    sustained = None
+    shader_mhz = None
+    if args.sustained_seconds > 0:
+        probe_ms = int(min(2000.0, 0.5 * args.sustained_seconds * 1e3))
+        if os.environ.get("VGEN_BENCH_PROBE") == "0":
+            probe_ms = 0
+        barrier()
+        if probe_ms >= 2:
+            runner.clock_probe_start(probe_ms)
+        ts = time.perf_counter()
+        n_s, _ = pipe.run_seconds(args.sustained_seconds)
+        barrier()
+        dt_s = max_over_ranks(time.perf_counter() - ts)
+        if world > 1:   # every rank stops on its own clock: sum the dispatches
+            t = torch.tensor([float(n_s)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            n_total = int(t.item())
+        else:
+            n_total = n_s
+        if probe_ms >= 2:
+            shader_mhz = runner.clock_probe_read()
+        sustained = {"value": round(n_total * N / dt_s / 1e6, 2), "unit": "Mkeys/sec", "seconds": round(dt_s, 3),
+                     "dispatches": n_total, "frames_in_flight": F}
+
+    w_key = work_per_key(args.format)
     # the dominant kernel (seq_bwd_kernel) does everything except the per-lane prefix products of
     # seq_fwd_kernel (half an F_p multiplication per key: 74 imul + 60 iop per multiplication)
     w_bwd = w_key - (74 * R_MUL + 60) // 2
     avg_ms = sum(kms) / len(kms)
-    # Launches of different frames execute concurrently (one launch is only 1 wave per SIMD), each taking
-    # correspondingly longer, so the kernel's rate is its per-launch rate times the mean number of its launches
-    # in flight (sum of launch durations / wall time, Little's law) - both factors are reported.
-    per_launch = N * w_bwd / (avg_ms * 1e-3) / 1e12
-    concurrency = sum(kms) * 1e-3 / elapsed
-    achieved = per_launch * concurrency
+    chip = value * 1e6 / world * w_key / 1e12
     traffic = None
-    try:   # HBM bytes per launch from the committed PMC passes (profiles/, FETCH_SIZE x2 per the guide)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        traffic = pm.get(f"{args.format}:{N}", {}).get("seq_bwd_kernel_bytes_per_launch")
+    pmc = {}
+    try:   # issue-side counters and HBM bytes per launch from the committed PMC passes (profiles/)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json"))).get(f"{args.format}:{N}", {})
+        traffic = pmc.get("seq_bwd_kernel_hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
+    roofline = {
+        "bound": "valu", "achieved": round(chip, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
+        "frac": round(chip / PEAK_TLANEOPS, 4), "traffic": traffic,
+        "work_per_key": w_key, "kernel": "seq_bwd_kernel", "kernel_work_per_key": w_bwd,
+        "hbm_gb_per_s": round(traffic * args.steps / elapsed / 1e9, 1) if traffic else None,
+        "hbm_frac_of_8TBps": round(traffic * args.steps / elapsed / 8e12, 4) if traffic else None,
+        "avg_launch_ms_overlapped": round(avg_ms, 4),
+        "mean_launches_in_flight": round(sum(kms) * 1e-3 / elapsed, 2),
+        "note": "integer-VALU bound path (no MFMA; HBM traffic is a few % of peak).  achieved/frac: keys per second of "
+                "the timed region x the frozen algorithmic work per key W (SURVEY.md 8(d), r_mul re-based to the "
+                "measured 2) against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz — a chip-level figure from wall time.  "
+                "Kernel-level evidence: lone_launch (frames = 1, HIP events around every seq_bwd launch: one wave per "
+                "SIMD, nothing else on the chip) and issue (VALU-busy and instructions per key from the committed "
+                "rocprofv3 PMC pass).  avg_launch_ms_overlapped is the HIP-event duration of a launch while ~"
+                "mean_launches_in_flight of them share the chip; it is reported, not multiplied back.",
+    }
+    if sustained:
+        s_chip = sustained["value"] * 1e6 / world * w_key / 1e12
+        roofline["achieved_sustained"] = round(s_chip, 3)
+        roofline["frac_sustained"] = round(s_chip / PEAK_TLANEOPS, 4)
+        if shader_mhz:
+            roofline["shader_clock_mhz"] = round(shader_mhz)
+            roofline["frac_sustained_at_shader_clock"] = round(s_chip / (PEAK_TLANEOPS * shader_mhz / 2400.0), 4)
+    if pmc:
+        roofline["issue"] = {k: pmc[k] for k in ("valu_busy", "valu_instr_per_key", "valu_instr_per_key_all_kernels", "waves_per_simd",
+                                                 "source", "how") if k in pmc}
+
     out = {
         "metric": "Mkeys/sec (keys tried per second)", "value": round(value, 2), "unit": "Mkeys/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -220,30 +385,26 @@ def main():
         "data": "synthetic (sequential scalars from k0 = SHA-256('vgen-mi355x'||seed=42||shard=0) mod n)",
         "config": {"workload": f"{args.format} pattern {args.pattern!r}{' -i' if args.ci else ''}, "
                                f"{N} keys/dispatch, compressed pubkey, sequential-range mode",
-                   "keys_per_dispatch": N, "frames_in_flight": F,
+                   "keys_per_dispatch": N, "frames_in_flight": F, "topology": runner.topology(),
                    "parallelism": f"range-striped x{world}" + (" (REHEARSAL: ranks share a GPU)" if rehearse else ""),
                    "device_filter_kind": pat.device_kind, "candidates_reported": cand},
-        "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1),
-                     "unit": "Tlaneop/s", "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": traffic,
-                     "hbm_gb_per_s": round(traffic * args.steps / elapsed / 1e9, 1) if traffic else None,
-                     "hbm_frac_of_8TBps": round(traffic * args.steps / elapsed / 8e12, 4) if traffic else None,
-                     "kernel": "seq_bwd_kernel", "avg_launch_ms": round(avg_ms, 4), "frames_in_flight": F,
-                     "mean_launches_in_flight": round(concurrency, 2), "achieved_per_launch": round(per_launch, 3),
-                     "work_per_key": w_bwd, "work_per_key_whole_path": w_key,
-                     "chip_achieved": round(value * 1e6 / world * w_key / 1e12, 3),
-                     "chip_frac": round(value * 1e6 / world * w_key / 1e12 / PEAK_TLANEOPS, 4),
-                     "shader_clock_mhz": round(shader_mhz) if shader_mhz else None,
-                     "chip_frac_at_shader_clock": round(value * 1e6 / world * w_key / 1e12 /
-                                                        (PEAK_TLANEOPS * shader_mhz / 2400.0), 4) if shader_mhz else None,
-                     "note": "integer-VALU bound path (no MFMA; HBM traffic is a few % of peak); achieved = "
-                             "algorithmic lane-op-equivalents of one seq_bwd_kernel launch / its average HIP-event "
-                             "duration (achieved_per_launch) x the mean number of its launches in flight (sum of launch "
-                             "durations / wall time): one launch is 1 wave per SIMD and the frames overlap on the device; "
-                             "chip_* is the same ratio for the whole path from wall time; shader_clock_mhz = "
-                             "s_memtime / s_memrealtime sampled by a probe wave during the timed region (the peak "
-                             "assumes the nominal 2400 MHz, which power management does not sustain under this load)"},
+        "sustained": sustained,
+        "roofline": roofline,
     }
     if rank == 0 and world == 1:
+        # the kernel alone: frames = 1, so every launch has the chip to itself (one wave per SIMD), HIP events
+        # recorded on the launch's own stream immediately before and after seq_bwd_kernel
+        r1 = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=1)
+        r1.set_filter(pat if pat.device_kind != 0 else None)
+        p1 = Pipeline(r1, seed_key(42, 0))
+        p1.run_steps(8)
+        _, k1 = p1.run_steps(64, collect=True)
+        r1.close()
+        lone = sum(k1) / len(k1)
+        roofline["lone_launch"] = {"avg_launch_ms": round(lone, 4), "launches": len(k1),
+                                   "achieved": round(N * w_bwd / (lone * 1e-3) / 1e12, 3),
+                                   "frac": round(N * w_bwd / (lone * 1e-3) / 1e12 / PEAK_TLANEOPS, 4),
+                                   "keys_per_s_equivalent": round(N / (lone * 1e-3) / 1e6, 1)}
         # time-to-first-match (the second half of BASELINE.json's metric): a `generate -c 1` style scan
         # through the scanner (vgen_scan), warm = existing context, cold = including context creation
         # (offset-table build + allocations; the HIP runtime itself is already initialised here)
@@ -260,9 +421,22 @@ def main():
         out["time_to_first_match"] = {"warm_s": round(warm, 5), "cold_s": round(cold, 5),
                                       "keys_scanned_warm": res.operations, "keys_scanned_cold": res2.operations,
                                       "found": bool(res.matches) and bool(res2.matches)}
+    runner.close()
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        sec = 1.0
+        oc = [timed_config(vg, "p2wpkh", "dead$", False, args.batch, F, local_rank, sec, "BASELINE config 3: P2WPKH bech32 suffix"),
+              timed_config(vg, "ethereum", "^0xdead", True, args.batch, F, local_rank, sec, "BASELINE config 5 (one GPU): Ethereum, case-insensitive"),
+              timed_config(vg, "p2pkh", "^13zb1hQbWVsc2S7ZTZnP2G4undNNpdh5so$", False, args.batch, F, local_rank, sec,
+                           "BASELINE config 4 (one GPU): puzzle-66 exact address", note="keys from k0(seed=42), not the puzzle range: the rate does not depend on the range"),
+              timed_config(vg, "p2sh-p2wpkh", "^3Cat", False, args.batch, F, local_rank, sec, "P2SH-P2WPKH prefix"),
+              timed_config(vg, "p2pkh-uncompressed", "^1Cat", False, args.batch, F, local_rank, sec, "P2PKH, uncompressed public key"),
+              timed_config(vg, "p2tr", "^bc1pqqq", False, args.batch, F, local_rank, sec, "P2TR (taproot tweak on the device)"),
+              timed_config(vg, "p2pkh", "1[Oo]ri", False, args.batch, F, local_rank, sec, "unanchored pattern: full Base58Check + DFA match on the device"),
+              keys_mode_config(vg, args.batch, min(F, 8), local_rank, sec)]
+        oc += dump_mode_configs(vg, args.batch, local_rank, sec)
+        out["other_configs"] = oc
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.format, args.pattern, args.ci)
-    runner.close()
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -61,7 +61,10 @@ typedef struct vgen_params {
     uint32_t batch_size;   /* keys per dispatch; reference default 524288 (gpu.rs:83); must be a
                               multiple of 8192; 0 selects 1048576 */
     uint32_t format;       /* vgen_format */
-    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 20: beyond ~22 streams per device the hardware queues are oversubscribed and throughput collapses */
+    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 20 (64 with
+                              VGEN_STREAMS=A,B).  One dispatch is one wave per SIMD, so throughput grows with the frames
+                              in flight: 8.9 / 10.6 / 11.8 / 12.0 Gkeys/s at 4 / 8 / 16 / 20 (P2PKH, 2^20 keys each); every
+                              frame's stream owns a hardware queue, independent of GPU_MAX_HW_QUEUES (vgen_get_topology) */
     uint32_t match_cap;    /* match records kept per dispatch in filter mode; 0 -> 4096 */
     uint32_t flags;        /* VGEN_FLAG_* */
 } vgen_params;
@@ -100,6 +103,15 @@ void vgen_destroy(vgen_ctx *ctx);
 const char *vgen_last_error(const vgen_ctx *ctx);
 /* The batch size / frame count actually in use (after defaults). */
 int vgen_get_info(const vgen_ctx *ctx, uint32_t *batch_size, uint32_t *frames, uint32_t *match_cap);
+/* How the context reaches the device (the reference's wgpu queue, src/gpu.rs:116-131, has no counterpart to
+ * tune).  Default layout: one stream per frame (*fwd_streams = 0, *bwd_streams = frames), each owning a
+ * hardware queue.  With VGEN_STREAMS=A,B: the number of streams shared by the first halves of all dispatches
+ * (denominators, product trees, root inversions) and by their second halves (per-key work, result copies).
+ * *hw_queues: the limit the HIP runtime was started with (GPU_MAX_HW_QUEUES, default 4); it binds only
+ * ordinary streams (VGEN_STREAM_KIND=plain), and *oversubscribed == 1 reports that such streams outnumber it —
+ * then streams share queues, their kernels serialise and the throughput drops.  Any pointer may be NULL. */
+int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_streams, uint32_t *hw_queues,
+                      int32_t *oversubscribed);
 
 /* ---- pattern: Pattern::new / Pattern::matches (src/pattern.rs:21-45) -------------------------------- */
 
@@ -158,10 +170,14 @@ int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint
 /* Dump mode only, after vgen_wait: copies the frame's payloads (batch_size * 20 bytes, or * 32 for
  * P2TR; zeroed for invalid keys) — the Vec<[u8;20]> await_result returns (src/gpu.rs:644-650). */
 int vgen_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
+/* The same payloads without the copy: a dump-mode dispatch ends with its own asynchronous transfer into pinned
+ * host memory, and this returns that buffer (valid until the frame is dispatched again) — what the host-side
+ * filter loop of scan_gpu_with_runner reads (src/gpu.rs:1030-1093). */
+int vgen_dump_view(vgen_ctx *ctx, uint32_t frame, const uint8_t **ptr, size_t *len);
 /* Device time of the dominant kernel (seq_bwd_kernel: tree walk-down, point additions, hashes,
  * filter) of the frame's last completed dispatch, from HIP events on the frame's own stream. */
 int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms);
-/* Device time of the whole dispatch (seq_fwd + seq_inv + seq_bwd kernels incl. the gaps between them). */
+/* Device time of the whole dispatch (seq_fwd incl. the root inversions + seq_bwd, incl. the gap between them). */
 int vgen_frame_dispatch_ms(vgen_ctx *ctx, uint32_t frame, float *ms);
 
 /* ---- host-side derivation (what the Rust host obtains from rust-bitcoin) ----------------------------- */

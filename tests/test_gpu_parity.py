@@ -537,3 +537,107 @@ def test_first_dispatch_right_after_create_is_not_raced_by_setup(vg, vo):
             blob, _, _ = r.await_result(f)
             assert hashlib.sha256(blob).digest() == want, (i, f)
         r.close()
+
+
+# ---- stop flag, progress callback, count-limited checkpoints (reference src/scanner.rs:413-440, src/gpu.rs:980-984,1106-1109) ----
+
+
+def test_stop_flag_ends_a_hopeless_scan_promptly_with_whole_batches(vg):
+    import ctypes
+    import threading
+    import time
+    batch = 1 << 18
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=4)
+    stop = ctypes.c_int32(0)
+    seen = []
+
+    def stopper():
+        time.sleep(0.15)
+        stop.value = 1
+
+    t = threading.Thread(target=stopper)
+    t0 = time.perf_counter()
+    t.start()
+    # 12 fixed Base58 characters: 1 in 58^12 keys — never within this test
+    res = vg.scan_gpu_with_runner("^1zzzzzzzzzzzz", vg.ScanConfig(count=1, seed=9), r, progress_cb=seen.append, stop=stop)
+    dt = time.perf_counter() - t0
+    t.join()
+    assert res.matches == [] and not res.complete
+    assert res.operations > 0 and res.operations % batch == 0          # whole batches only (gpu.rs:1106)
+    assert 0.1 < dt < 2.0, f"stopped scan took {dt:.2f} s"
+    assert seen and seen[-1] == res.operations                          # the last callback carries the final count
+    # a flag that is already set: nothing is dispatched at all (gpu.rs:980-984)
+    res = vg.scan_gpu_with_runner("^1zzzzzzzzzzzz", vg.ScanConfig(count=1, seed=9), r, stop=stop)
+    assert res.operations == 0 and res.matches == []
+    r.close()
+
+
+def test_progress_callback_once_per_batch_with_cumulative_operations(vg):
+    batch = 65536
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=3)
+    seen = []
+    res = vg.scan_gpu_with_runner("^1zzzzzzzzzzzz", vg.ScanConfig(count=1, seed=3, max_batches=17), r, progress_cb=seen.append)
+    assert seen == [batch * (i + 1) for i in range(17)] and res.operations == 17 * batch
+    # two contexts, batches striped: one shared cumulative counter, still strictly increasing, one call per batch
+    rs = [r, vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=3)]
+    seen = []
+    res = vg.scan_gpu_with_runner("^1zzzzzzzzzzzz", vg.ScanConfig(count=1, seed=3, max_batches=9), rs, progress_cb=seen.append)
+    assert seen == [batch * (i + 1) for i in range(18)] and res.operations == 18 * batch
+    # dump mode (host-side filtering, the reference's own mode) reports the same way
+    seen = []
+    res = vg.scan_gpu_with_runner("zzzzzzzz", vg.ScanConfig(format=vg.AddressFormat.P2wpkh, count=1, start=1, end=3 * 8192 - 1),
+                                  vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2wpkh), progress_cb=seen.append)
+    assert seen == [8192, 16384, 24576] and res.complete
+    for x in rs:
+        x.close()
+
+
+def test_checkpoint_written_under_a_small_count_resumes_under_a_larger_one(vg, vo, tmp_path):
+    import os
+    import stat
+    batch, lo, hi, pat = 8192, 1, 0x2FFFF, "^1[A-C]"
+    want = [x["hex"] for x in vo.scan_range(0, pat, lo, hi, count=10**9)["matches"]]
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=4)
+    ck = str(tmp_path / "count.ckpt")
+    cfg = lambda n: vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=n, start=lo, end=hi, checkpoint_path=ck)
+    a = vg.scan_gpu_with_runner(pat, cfg(1), r)
+    assert [m.hex for m in a.matches] == want[:1] and not a.complete
+    text = open(ck).read()
+    assert "\ncomplete=0\n" in text                                    # stopping on count is not "range finished"
+    assert stat.S_IMODE(os.stat(ck).st_mode) == 0o600                     # the file holds private keys
+    # the committed batches keep ALL their matches: the ledger is the oracle's list up to the recorded position
+    done = int([l for l in text.splitlines() if l.startswith("done=")][0][5:])
+    ledger = [l[6:] for l in text.splitlines() if l.startswith("match=")]
+    assert done >= 1 and ledger == [h for h in want if int(h, 16) < lo + done * batch]
+    b = vg.scan_gpu_with_runner(pat, cfg(5), r)
+    assert [m.hex for m in b.matches] == want[:5] and not b.complete
+    c = vg.scan_gpu_with_runner(pat, cfg(None), r)
+    assert c.complete and [m.hex for m in c.matches] == want
+    # and across two contexts (shared counter): small count first, then everything
+    ck2 = str(tmp_path / "count2.ckpt")
+    rs = [r, vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=4)]
+    cfg2 = lambda n: vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=n, start=lo, end=hi, checkpoint_path=ck2)
+    a = vg.scan_gpu_with_runner(pat, cfg2(2), rs)
+    assert len(a.matches) == 2 and not a.complete and set(m.hex for m in a.matches) <= set(want)
+    c = vg.scan_gpu_with_runner(pat, cfg2(None), rs)
+    assert c.complete and [m.hex for m in c.matches] == want
+    for x in rs:
+        x.close()
+
+
+def test_frames_own_their_hardware_queues_without_environment_help(vg):
+    import os
+    assert "GPU_MAX_HW_QUEUES" not in os.environ or int(os.environ["GPU_MAX_HW_QUEUES"]) >= 4
+    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=16)
+    t = r.topology()
+    assert t["bwd_streams"] == 16 and t["fwd_streams"] == 0 and not t["oversubscribed"]
+    r.close()
+    # contexts are created and destroyed repeatedly in one process (streams are recycled, never torn down)
+    for frames in (4, 8, 4, 12):
+        r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=frames)
+        r.set_filter(None)
+        for f in range(frames):
+            r.dispatch(1 + f, f)
+        for f in range(frames):
+            r.await_result(f)
+        r.close()

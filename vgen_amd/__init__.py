@@ -5,11 +5,6 @@ include/vgen_hip.h).  This package is the thin Python view of that ABI used by t
 bench.py; names mirror the reference (src/address.rs, src/scanner.rs, src/pattern.rs, src/gpu.rs).
 There is no CPU fallback: importing works anywhere, creating a GpuRunner needs an MI355X.
 """
-import os as _os
-
-# one hardware queue per frame stream; read by the HIP runtime when it initialises
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-
 from .api import (AddressFormat, GeneratedAddress, GpuRunner, Pattern, ScanConfig, ScanResult, VgenError,
                   abi_version, address_from_payload, derive, device_count, device_name, key_add, key_to_wif,
                   library_path, scan_gpu_with_runner, ProviderResult, provider_resolve, build_pattern, build_exact_pattern)

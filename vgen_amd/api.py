@@ -111,6 +111,8 @@ _L.vgen_dispatch_keys.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_cha
 _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match), ctypes.c_uint32,
                          ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
 _L.vgen_read_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+_L.vgen_dump_view.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+_L.vgen_get_topology.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint32)] * 3 + [ctypes.POINTER(ctypes.c_int32)]
 _L.vgen_frame_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
 _L.vgen_frame_dispatch_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
 _L.vgen_address_from_payload.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
@@ -314,6 +316,18 @@ class GpuRunner:
         self.payload_bytes = 32 if self.format == AddressFormat.P2tr else 20
         self._pattern = None
 
+    def topology(self) -> dict:
+        """vgen_get_topology: stage streams of the context, the HIP hardware-queue limit, and whether they fit."""
+        a, b, q, o = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int32()
+        _check(_L.vgen_get_topology(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(q), ctypes.byref(o)), self._h)
+        return {"fwd_streams": a.value, "bwd_streams": b.value, "hw_queues": q.value, "oversubscribed": bool(o.value)}
+
+    def dump_view(self, frame: int) -> bytes:
+        """vgen_dump_view: the frame's payloads from the pinned buffer its dump-mode dispatch copied itself into."""
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(_L.vgen_dump_view(self._h, frame, ctypes.byref(ptr), ctypes.byref(n)), self._h)
+        return ctypes.string_at(ptr.value, n.value)
+
     def close(self):
         if getattr(self, "_h", None):
             _L.vgen_destroy(self._h)
@@ -371,7 +385,7 @@ class GpuRunner:
         return ms.value
 
     def dispatch_ms(self, frame: int) -> float:
-        """HIP-event duration of the whole last dispatch (fwd + inv + bwd kernels)."""
+        """HIP-event duration of the whole last dispatch (seq_fwd incl. the root inversions + seq_bwd)."""
         ms = ctypes.c_float()
         _check(_L.vgen_frame_dispatch_ms(self._h, frame, ctypes.byref(ms)), self._h)
         return ms.value

@@ -16,11 +16,8 @@
 namespace {
 thread_local std::string g_last_error;
 
-// The frames of a context overlap on the device only if every frame's stream has its own hardware queue; the
-// HIP default (4 queues) serialises them (6.0 instead of 10.7 Gkeys/s).  The runtime reads GPU_MAX_HW_QUEUES
-// when it initialises, so the default is planted when this library is loaded — before the first HIP call of a
-// host that has not touched the GPU yet — and never overrides a value the host chose.
-__attribute__((constructor)) void vgen_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// (No load-time side effects: the library neither sets nor needs GPU_MAX_HW_QUEUES.  A context drives its frames
+// through at most four stage streams — runtime.h — which fit the HIP default of four hardware queues.)
 
 int copy_out(const std::string &s, char *out, size_t cap) {
     if (!out || cap < s.size() + 1) return VGEN_E_INVALID;
@@ -184,6 +181,21 @@ int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint
 int vgen_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len) {
     if (!ctx) return VGEN_E_INVALID;
     return vg::rt_read_dump(ctx, frame, out, out_len);
+}
+
+int vgen_dump_view(vgen_ctx *ctx, uint32_t frame, const uint8_t **ptr, size_t *len) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_dump_view(ctx, frame, ptr, len);
+}
+
+int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_streams, uint32_t *hw_queues,
+                      int32_t *oversubscribed) {
+    if (!ctx) return VGEN_E_INVALID;
+    if (fwd_streams) *fwd_streams = ctx->n_fwd;
+    if (bwd_streams) *bwd_streams = ctx->n_bwd;
+    if (hw_queues) *hw_queues = ctx->hw_queues;
+    if (oversubscribed) *oversubscribed = !ctx->own_queues && ctx->n_fwd + ctx->n_bwd > ctx->hw_queues ? 1 : 0;
+    return VGEN_OK;
 }
 
 int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {

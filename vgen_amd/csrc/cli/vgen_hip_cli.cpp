@@ -423,7 +423,7 @@ const char *argv_pattern(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
-    setenv("GPU_MAX_HW_QUEUES", "24", 0);   // one hardware queue per frame stream; before HIP initialises
+
     Opts o = parse(argc, argv);
     signal(SIGINT, on_sigint);
     if (o.cmd == "generate") {

@@ -84,6 +84,8 @@ struct SeqArgs {
     uint32_t *pre;             // scratch: prefix products [S][9][lanes]
     uint32_t *tree;            // scratch: product-tree nodes [groups][9][SEQ_WG]
     uint32_t *root;            // scratch: tree roots / their inverses [9][groups]
+    uint32_t *arrive;          // scratch: [ceil(groups/64)] arrival counters of seq_fwd's inversion tail (zero between
+                               // dispatches); nullptr = the roots are inverted by a seq_inv_kernel launch instead
     uint32_t lanes;            // N / (2*S)
     uint32_t groups;           // lanes / SEQ_WG
     uint32_t n;                // N

@@ -179,7 +179,15 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
 
 // ---- stage 1: denominators, per-lane products, workgroup product tree ---------------------------------
 
-__global__ void __launch_bounds__(WG) seq_fwd_kernel(const SeqArgs args) {
+// INV_TAIL: the root inversions ride in the tail of this kernel instead of a kernel of their own.  Workgroups
+// are counted in as they publish their root (one counter per run of 64 consecutive workgroups); the workgroup
+// that completes a run inverts its 64 roots, ONE ROOT PER LANE of its first wave, while every other workgroup
+// has already retired — nobody waits on anybody, so the grid drains whatever the residency.  A dispatch is then
+// two launches (fwd+inv -> bwd) and the inversion needs neither a launch nor a hardware queue of its own.
+// (Register budget 128 with the tail: a first-half wave then fits into the slot one retiring seq_bwd wave frees.)
+template <bool INV_TAIL>
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(INV_TAIL ? 4 : 1, INV_TAIL ? 4 : 8)))
+seq_fwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
     const int tid = threadIdx.x;
     const u32 S = args.s;
@@ -229,6 +237,28 @@ __global__ void __launch_bounds__(WG) seq_fwd_kernel(const SeqArgs args) {
 #pragma unroll
     for (int i = 0; i < 9; i++) tg[i * WG + tid] = tree[i * WG + tid];
     if (tid < 9) args.root[(size_t)tid * args.groups + blockIdx.x] = tree[tid * WG + 1];
+    if (!INV_TAIL || tid >= 64) return;
+
+    // first wave only: release the root, count this workgroup in, and if it was the last of its run, invert
+    const u32 run = blockIdx.x >> 6;
+    const u32 members = min(64u, args.groups - (run << 6));
+    __threadfence();   // the root stores above are visible device-wide (all XCDs) before the arrival is
+    u32 last = 0;
+    if (tid == 0) last = atomicAdd(&args.arrive[run], 1u) == members - 1 ? 1u : 0u;
+    last = (u32)__builtin_amdgcn_readfirstlane((int)last);
+    if (!last) return;
+    __threadfence();   // acquire: the other workgroups' roots, written on other XCDs, are read from memory
+    const u32 g = (run << 6) + (u32)tid;
+    const u32 gg = g < args.groups ? g : args.groups - 1;
+    fe r, ri;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.n[i] = args.root[(size_t)i * args.groups + gg];
+    fe_inv(ri, r);
+    if (g < args.groups) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) args.root[(size_t)i * args.groups + g] = ri.n[i];
+    }
+    if (tid == 0) args.arrive[run] = 0;   // ready for the frame's next dispatch (ordered by the kernel boundary)
 }
 
 // ---- stage 2: invert every workgroup's root, one root per lane -----------------------------------------
@@ -793,15 +823,22 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream, hipEvent_t before_bwd) {
+
+hipError_t launch_seq_fwd(const SeqArgs &a, hipStream_t stream) {
     if (a.lanes % WG != 0 || a.groups != a.lanes / WG || a.s < 2 || a.s > SEQ_MAX_S) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(seq_fwd_kernel, dim3(a.groups), dim3(WG), 0, stream, a);
+    if (a.arrive) {
+        hipLaunchKernelGGL(seq_fwd_kernel<true>, dim3(a.groups), dim3(WG), 0, stream, a);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(seq_fwd_kernel<false>, dim3(a.groups), dim3(WG), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (before_bwd && (e = hipEventRecord(before_bwd, stream)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_seq_bwd(int fmt, const SeqArgs &a, hipStream_t stream) {
+    if (a.lanes % WG != 0 || a.groups != a.lanes / WG || a.s < 2 || a.s > SEQ_MAX_S) return hipErrorInvalidValue;
     switch (fmt) {
     case VGF_P2PKH:
     case VGF_P2WPKH:

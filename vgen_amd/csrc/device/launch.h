@@ -6,9 +6,13 @@
 
 namespace vg {
 
-// Enqueues the sequential-range scan on `stream`.  a.lanes must be a multiple of 256.
-// `before_bwd` (optional) is recorded between the inversion stage and the backward stage.
-hipError_t launch_seq_scan(int fmt, const SeqArgs &a, hipStream_t stream, hipEvent_t before_bwd);
+// The sequential-range scan in its two halves (a.lanes must be a multiple of 256):
+//   launch_seq_fwd  denominators, prefix products, workgroup product trees and the inverted tree roots
+//                   (in the kernel's tail when a.arrive is set, else by a seq_inv_kernel launch behind it);
+//   launch_seq_bwd  everything per key (tree walk-down, additions, hashes, filter / dump), after the first half
+//                   of the same dispatch has completed (same stream, or an event between two streams).
+hipError_t launch_seq_fwd(const SeqArgs &a, hipStream_t stream);
+hipError_t launch_seq_bwd(int fmt, const SeqArgs &a, hipStream_t stream);
 
 }  // namespace vg
 

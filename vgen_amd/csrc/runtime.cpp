@@ -1,11 +1,14 @@
 // runtime.cpp — see runtime.h.
 #include "runtime.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "device/launch.h"
 #include "host/host_ec.h"
@@ -32,14 +35,137 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
     return x > 0 ? (uint32_t)x : dflt;
 }
 
-// pre [S][9][lanes] | tree [groups][9][WG] | root [9][groups]
+// pre [S][9][lanes] | tree [groups][9][WG] | root [9][groups] | arrive [ceil(groups/64)]
 size_t scratch_words(const vgen_ctx *c) {
-    return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
+    return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups + (c->groups + 63) / 64;
+}
+
+// P2TR: tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
+size_t p2tr_words(const vgen_ctx *c) {
+    if (c->format != VGF_P2TR) return 0;
+    return (size_t)2 * c->S * 27 * c->lanes + (size_t)2 * c->S * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
 }
 
 void fe_canon_neg(fe &r, const fe &a) {
     fe_neg(r, a, 1);
     fe_normalize(r);
+}
+
+size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// Stage stream `i` of `pool`, created on first use (a stream costs ~5 ms: a scan's first dispatches should be
+// running while the later streams are still being set up).
+//
+// The streams are created through hipExtStreamCreateWithCUMask with every CU enabled: such a stream owns a
+// hardware queue of its own, whereas ordinary streams share the runtime's pool of GPU_MAX_HW_QUEUES (default 4)
+// queues — measured on the box with tools/queue_probe.hip (profiles/r02_queue_probe.txt): the 5th, 9th, 13th
+// ordinary stream each add a full serial round, CU-masked streams overlap like ordinary ones under
+// GPU_MAX_HW_QUEUES=16.  So the overlap of the frames depends neither on an environment variable nor on whether
+// the host initialised HIP first.
+//
+// Own-queue streams are never destroyed: a context returns them to a process-wide cache (per device) when it is
+// destroyed and the next context takes them from there.  On this runtime (ROCm 7.2) creating a CU-masked stream
+// after others were destroyed can block forever inside hipExtStreamCreateWithCUMask (seen: the second
+// vgen_create of a process, after "Deleting hardware queue" of the first context's streams); reuse avoids the
+// teardown path altogether and saves the ~5 ms per stream on every later vgen_create.
+struct StreamCache {
+    std::mutex mu;
+    std::map<int, std::vector<hipStream_t>> idle;   // device -> streams not in use by any context
+};
+StreamCache &stream_cache() {
+    static StreamCache *sc = new StreamCache();   // the object itself is never freed (no static-destruction order to get wrong)
+    return *sc;
+}
+
+// Idle cached streams are destroyed when the process exits: registered with atexit() at the first stream
+// creation, i.e. after the HIP runtime registered its own teardown, so this runs before it.  (Nothing is created
+// afterwards, which is the only sequence that was seen to block; leaving the queues to the runtime's teardown
+// made rocprofv3 crash in its exit handlers.)
+void destroy_idle_streams() {
+    StreamCache &sc = stream_cache();
+    std::lock_guard<std::mutex> g(sc.mu);
+    for (auto &kv : sc.idle) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        for (hipStream_t st : kv.second) (void)hipStreamDestroy(st);
+        kv.second.clear();
+    }
+}
+
+int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStream_t *out) {
+    if (!pool[i]) {
+        if (c->own_queues) {
+            {
+                StreamCache &sc = stream_cache();
+                std::lock_guard<std::mutex> g(sc.mu);
+                auto &idle = sc.idle[c->device];
+                if (!idle.empty()) {
+                    pool[i] = idle.back();
+                    idle.pop_back();
+                }
+            }
+            if (!pool[i]) {
+                static std::once_flag once;
+                std::call_once(once, []() { atexit(destroy_idle_streams); });
+                std::vector<uint32_t> mask((c->cu_count + 31) / 32, 0xFFFFFFFFu);
+                HIP_TRY(c, hipExtStreamCreateWithCUMask(&pool[i], (uint32_t)mask.size(), mask.data()));
+            }
+        } else {
+            HIP_TRY(c, hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
+        }
+    }
+    *out = pool[i];
+    return VGEN_OK;
+}
+
+void retire_stream(vgen_ctx *c, hipStream_t st) {
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    if (c->own_queues) {
+        StreamCache &sc = stream_cache();
+        std::lock_guard<std::mutex> g(sc.mu);
+        sc.idle[c->device].push_back(st);
+    } else {
+        (void)hipStreamDestroy(st);
+    }
+}
+
+// Blocking upload that never touches the null stream (whose queue would otherwise be a fifth one next to the
+// four stage streams, and which the non-blocking stage streams do not synchronise with anyway).
+int upload(vgen_ctx *c, void *dst, const void *src, size_t bytes) {
+    hipStream_t st;
+    if (int rc = stage_stream(c, c->bwd_streams, 0, &st)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return VGEN_OK;
+}
+
+// VGEN_STREAMS: "frame" (default: one private stream per frame carries both halves of its dispatches) or "A,B"
+// (A streams shared by the first halves, B by the second halves; A may be 0).  Measured with every stream on a
+// hardware queue of its own (profiles/r02_topology_sweep.txt): per-frame streams win at every frame count; the
+// stage layouts only pay when queues are scarce (VGEN_STREAM_KIND=plain with the default GPU_MAX_HW_QUEUES=4:
+// "2,2" reaches 10.8 Gkeys/s where 16 per-frame streams on 4 shared queues reach 9.7).
+// VGEN_FUSED_INV: root inversions in seq_fwd's tail (1) or as a seq_inv_kernel launch (0); default by frame
+// count — the fused tail shortens a dispatch's chain (+16 % at 4 frames, +7 % at 8), the separate launch keeps
+// seq_fwd at 64 VGPRs, which packs better beside seq_bwd waves once many frames overlap (+3 % at 16-20).
+void parse_topology(vgen_ctx *c) {
+    const char *v = getenv("VGEN_STREAMS");
+    c->per_frame_streams = true;
+    c->n_fwd = 0;
+    c->n_bwd = c->frames;
+    if (v && *v && strcmp(v, "frame") != 0) {
+        unsigned a = 2, b = 2;
+        if (sscanf(v, "%u,%u", &a, &b) == 2 && a <= 16 && b >= 1 && b <= 16) {
+            c->per_frame_streams = false;
+            c->n_fwd = a;
+            c->n_bwd = b;
+        }
+    }
+    const char *k = getenv("VGEN_STREAM_KIND");   // "plain": ordinary streams from the runtime's shared queue pool
+    if (k && !strcmp(k, "plain")) c->own_queues = false;
+    c->fused_inv = c->frames <= 8;
+    const char *fi = getenv("VGEN_FUSED_INV");
+    if (fi && (*fi == '0' || *fi == '1')) c->fused_inv = *fi == '1';
+    c->hw_queues = env_u32("GPU_MAX_HW_QUEUES", 4);
 }
 
 }  // namespace
@@ -76,57 +202,69 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         rt_destroy(c);
         return st;
     };
-    if (c->frames > 20) return bail(VGEN_E_INVALID, "frames must be <= 20 (more streams than hardware queues collapse the throughput)");
+    if (c->frames > 64) return bail(VGEN_E_INVALID, "frames must be <= 64");
+    parse_topology(c);
+    if (c->per_frame_streams && c->frames > 20)
+        return bail(VGEN_E_INVALID, "frames must be <= 20 (one hardware queue per frame: beyond ~22 busy queues per device the throughput "
+                                    "collapses to ~1 Gkeys/s; VGEN_STREAMS=A,B shares A+B queues among up to 64 frames)");
     if (c->S < 2 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two in [2, 16]");
     if (c->batch % 8192 != 0 || c->batch % (2 * SEQ_WG * c->S) != 0 || c->batch < 8192)
         return bail(VGEN_E_INVALID, "batch_size must be a multiple of 8192 (and of 512*S)");
     if (c->match_cap < FIRST_COPY) c->match_cap = FIRST_COPY;
     c->lanes = c->batch / (2 * c->S);
     c->groups = c->lanes / SEQ_WG;
+    c->fwd_streams.assign(c->n_fwd, nullptr);
+    c->bwd_streams.assign(c->n_bwd, nullptr);
 
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return bail(VGEN_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-
-    // offset table R_u = (u*S + S/2) * G, uploaded limb-major ([18][lanes]) for coalesced reads
     {
-        std::vector<ge> tab;
-        host_build_stride_table(c->S / 2, c->S, c->lanes, tab);
-        std::vector<uint32_t> lm((size_t)18 * c->lanes);
-        for (uint32_t u = 0; u < c->lanes; u++)
-            for (int i = 0; i < 9; i++) {
-                lm[(size_t)i * c->lanes + u] = tab[u].x.n[i];
-                lm[(size_t)(9 + i) * c->lanes + u] = tab[u].y.n[i];
-            }
-        e = hipMalloc((void **)&c->d_rtab, lm.size() * sizeof(uint32_t));
-        if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(rtab): ") + hipGetErrorString(e));
-        e = hipMemcpy(c->d_rtab, lm.data(), lm.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return bail(VGEN_E_HIP, std::string("hipMemcpy(rtab): ") + hipGetErrorString(e));
+        int cus = 0;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device)) != hipSuccess || cus <= 0)
+            return bail(VGEN_E_HIP, std::string("hipDeviceGetAttribute: ") + hipGetErrorString(e));
+        c->cu_count = (uint32_t)cus;
     }
-    e = hipMalloc((void **)&c->d_filter, sizeof(DevFilter));
-    if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(filter): ") + hipGetErrorString(e));
 
-    // One device slab and one pinned slab for all frames: sixteen frames as separate allocations cost ~85 ms of
-    // vgen_create (time to first match, cold); slices are 256-byte aligned.
+    // One device slab and one pinned slab for all frames (sixteen frames as separate allocations cost ~85 ms of
+    // vgen_create, i.e. of the time to a cold first match); slices are 256-byte aligned.  Everything a dispatch
+    // of this context's format touches is allocated here, nothing on the dispatch path.
     c->fr.resize(c->frames);
-    auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
     const size_t scratch_b = up256(scratch_words(c) * sizeof(uint32_t)), match_b = up256(match_bytes(c->match_cap));
-    if ((e = hipMalloc((void **)&c->d_slab, (scratch_b + match_b) * c->frames)) != hipSuccess ||
+    const size_t p2tr_b = up256(p2tr_words(c) * sizeof(uint32_t));
+    const size_t frame_b = scratch_b + match_b + p2tr_b;
+    if ((e = hipMalloc((void **)&c->d_slab, frame_b * c->frames)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_slab, match_b * c->frames, hipHostMallocDefault)) != hipSuccess)
         return bail(VGEN_E_NOMEM, std::string("frame allocation: ") + hipGetErrorString(e));
     for (uint32_t i = 0; i < c->frames; i++) {
         vgen_ctx::Frame &f = c->fr[i];
-        f.d_scratch = reinterpret_cast<uint32_t *>(c->d_slab + (scratch_b + match_b) * i);
-        f.d_match = c->d_slab + (scratch_b + match_b) * i + scratch_b;
+        f.d_scratch = reinterpret_cast<uint32_t *>(c->d_slab + frame_b * i);
+        f.d_match = c->d_slab + frame_b * i + scratch_b;
+        if (p2tr_b) f.d_p2tr_scratch = reinterpret_cast<uint32_t *>(c->d_slab + frame_b * i + scratch_b + match_b);
         f.h_match = c->h_slab + match_b * i;
-        // (the frame's stream and events are created on its first dispatch: a stream costs ~5 ms, and a scan's
-        // first frames should be running while the later ones are still being set up)
     }
-    // The match rings start at zero (monotonic counters); the scratch needs no initialisation.  The frames'
-    // streams do not synchronise with the null stream, so the clears must have finished before vgen_create returns.
-    for (uint32_t i = 0; i < c->frames; i++)
-        if ((e = hipMemset(c->fr[i].d_match, 0, match_bytes(c->match_cap))) != hipSuccess)
-            return bail(VGEN_E_NOMEM, std::string("frame setup: ") + hipGetErrorString(e));
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(VGEN_E_HIP, std::string("frame setup: ") + hipGetErrorString(e));
+    e = hipMalloc((void **)&c->d_filter, sizeof(DevFilter));
+    if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(filter): ") + hipGetErrorString(e));
+
+    // offset table R_u = (u*S + S/2) * G, uploaded limb-major ([18][lanes]) for coalesced reads
+    std::vector<ge> tab;
+    host_build_stride_table(c->S / 2, c->S, c->lanes, tab);
+    std::vector<uint32_t> lm((size_t)18 * c->lanes);
+    for (uint32_t u = 0; u < c->lanes; u++)
+        for (int i = 0; i < 9; i++) {
+            lm[(size_t)i * c->lanes + u] = tab[u].x.n[i];
+            lm[(size_t)(9 + i) * c->lanes + u] = tab[u].y.n[i];
+        }
+    e = hipMalloc((void **)&c->d_rtab, lm.size() * sizeof(uint32_t));
+    if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(rtab): ") + hipGetErrorString(e));
+    // The match rings (monotonic counters) and the arrival counters start at zero; the rest of the scratch
+    // needs no initialisation but shares the slab.  Cleared and uploaded on stage stream 0 and waited for: the
+    // other stage streams do not synchronise with it, so nothing may be pending when vgen_create returns.
+    hipStream_t st0 = nullptr;
+    if (stage_stream(c, c->bwd_streams, 0, &st0) != VGEN_OK) return bail(VGEN_E_HIP, c->err);
+    if ((e = hipMemsetAsync(c->d_slab, 0, frame_b * c->frames, st0)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->d_rtab, lm.data(), lm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st0)) != hipSuccess ||
+        (e = hipStreamSynchronize(st0)) != hipSuccess)
+        return bail(VGEN_E_HIP, std::string("frame setup: ") + hipGetErrorString(e));
     *out = c;
     return VGEN_OK;
 }
@@ -134,17 +272,16 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
 void rt_destroy(vgen_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (auto &st : c->fwd_streams)
+        if (st) (void)hipStreamSynchronize(st);
+    for (auto &st : c->bwd_streams)
+        if (st) (void)hipStreamSynchronize(st);
     for (auto &f : c->fr) {
-        if (f.stream) (void)hipStreamSynchronize(f.stream);
-        if (f.d_dump) (void)hipFree(f.d_dump);
-        if (f.d_keys) (void)hipFree(f.d_keys);
-        if (f.d_keys_scratch) (void)hipFree(f.d_keys_scratch);
-        if (f.d_p2tr_scratch) (void)hipFree(f.d_p2tr_scratch);
-        if (f.ev_start) (void)hipEventDestroy(f.ev_start);
-        if (f.ev_mid) (void)hipEventDestroy(f.ev_mid);
-        if (f.ev_stop) (void)hipEventDestroy(f.ev_stop);
-        if (f.stream) (void)hipStreamDestroy(f.stream);
+        for (hipEvent_t ev : {f.ev_fwd, f.ev_done, f.ev_start, f.ev_mid, f.ev_stop})
+            if (ev) (void)hipEventDestroy(ev);
     }
+    for (auto &st : c->fwd_streams) retire_stream(c, st);
+    for (auto &st : c->bwd_streams) retire_stream(c, st);
     if (c->probe_stream) {
         (void)hipStreamSynchronize(c->probe_stream);
         (void)hipStreamDestroy(c->probe_stream);
@@ -152,6 +289,9 @@ void rt_destroy(vgen_ctx *c) {
     if (c->d_probe) (void)hipFree(c->d_probe);
     if (c->d_slab) (void)hipFree(c->d_slab);      // scratch + match rings of all frames
     if (c->h_slab) (void)hipHostFree(c->h_slab);
+    if (c->d_dump_slab) (void)hipFree(c->d_dump_slab);
+    if (c->h_dump_slab) (void)hipHostFree(c->h_dump_slab);
+    if (c->d_keys_slab) (void)hipFree(c->d_keys_slab);
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
@@ -175,14 +315,35 @@ int rt_clock_probe_start(vgen_ctx *c, uint32_t duration_ms) {
 int rt_clock_probe_read(vgen_ctx *c, double *mhz) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->probe_running) return c->fail(VGEN_E_STATE, "no clock probe was started");
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(v, c->d_probe, sizeof v, hipMemcpyDeviceToHost, c->probe_stream));
     HIP_TRY(c, hipStreamSynchronize(c->probe_stream));
     c->probe_running = false;
-    unsigned long long v[2] = {0, 0};
-    HIP_TRY(c, hipMemcpy(v, c->d_probe, sizeof v, hipMemcpyDeviceToHost));
     if (v[1] == 0) return c->fail(VGEN_E_HIP, "clock probe returned no ticks");
     *mhz = (double)v[0] / (double)v[1] * 100.0;
     return VGEN_OK;
 }
+
+namespace {
+
+// Dump mode's buffers for all frames: the payloads on the device and their pinned mirrors, which every dump-mode
+// dispatch fills with its own asynchronous copy (vgen_read_dump / vgen_dump_view then need no device call).
+// Allocated once, when dump mode is first selected — never while a dispatch of this context is in flight.
+int ensure_dump_slab(vgen_ctx *c) {
+    if (c->d_dump_slab) return VGEN_OK;
+    const size_t per = up256((size_t)c->batch * c->payload_words * sizeof(uint32_t));
+    HIP_TRY(c, hipMalloc((void **)&c->d_dump_slab, per * c->frames));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_dump_slab, per * c->frames, hipHostMallocDefault));
+    for (uint32_t i = 0; i < c->frames; i++) {
+        c->fr[i].d_dump = reinterpret_cast<uint32_t *>(c->d_dump_slab + per * i);
+        c->fr[i].h_dump = c->h_dump_slab + per * i;
+    }
+    return VGEN_OK;
+}
+
+bool dump_mode(const vgen_ctx *c) { return !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL; }
+
+}  // namespace
 
 int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
     HIP_TRY(c, hipSetDevice(c->device));
@@ -190,54 +351,93 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
         if (fr.in_flight) return c->fail(VGEN_E_STATE, "vgen_set_filter while a dispatch is in flight");
     if (!f) {
         c->have_filter = false;
-        return VGEN_OK;
+        return ensure_dump_slab(c);
     }
     if (f->format != c->format) return c->fail(VGEN_E_INVALID, "filter was compiled for another address format");
     c->h_filter = f->dev;
     if (f->dev.chk_lut) {   // Bech32 checksum tables: upload and point the device copy at them
         if (!c->d_chk_lut) HIP_TRY(c, hipMalloc((void **)&c->d_chk_lut, 32 * 256 * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemcpy(c->d_chk_lut, f->chk_lut.data(), f->chk_lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (int rc = upload(c, c->d_chk_lut, f->chk_lut.data(), f->chk_lut.size() * sizeof(uint32_t))) return rc;
         c->h_filter.chk_lut = c->d_chk_lut;
     }
     if (f->dev.kind == DEVF_DFA) {   // the pattern's automaton: upload, point the device copy at it
         if (!c->d_dfa) HIP_TRY(c, hipMalloc((void **)&c->d_dfa, 48 * 1024));
-        HIP_TRY(c, hipMemcpy(c->d_dfa, f->dfa_blob.data(), f->dfa_blob.size() * 4, hipMemcpyHostToDevice));
+        if (int rc = upload(c, c->d_dfa, f->dfa_blob.data(), f->dfa_blob.size() * 4)) return rc;
         c->h_filter.dfa_blob = c->d_dfa;
     }
-    HIP_TRY(c, hipMemcpy(c->d_filter, &c->h_filter, sizeof(DevFilter), hipMemcpyHostToDevice));
-    // the uploads ran on the null stream, which the frames' non-blocking streams do not wait for
-    HIP_TRY(c, hipDeviceSynchronize());
+    // (uploads are waited for: the other stage streams do not synchronise with the one that carried them)
+    if (int rc = upload(c, c->d_filter, &c->h_filter, sizeof(DevFilter))) return rc;
     c->have_filter = true;
+    if (dump_mode(c)) return ensure_dump_slab(c);
     return VGEN_OK;
 }
 
 namespace {
 
-// The frame's stream and timing events, created on first use.
-int ensure_stream(vgen_ctx *c, vgen_ctx::Frame &f) {
-    if (f.stream) return VGEN_OK;
-    HIP_TRY(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipEventCreate(&f.ev_start));
-    HIP_TRY(c, hipEventCreate(&f.ev_mid));
-    HIP_TRY(c, hipEventCreate(&f.ev_stop));
+// The frame's stage streams and events, created on first use.
+int ensure_frame(vgen_ctx *c, uint32_t frame) {
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (f.s_bwd) return VGEN_OK;
+    if (int rc = stage_stream(c, c->bwd_streams, frame % c->n_bwd, &f.s_bwd)) return rc;
+    f.s_fwd = f.s_bwd;
+    if (c->n_fwd)
+        if (int rc = stage_stream(c, c->fwd_streams, frame % c->n_fwd, &f.s_fwd)) return rc;
+    HIP_TRY(c, hipEventCreateWithFlags(&f.ev_fwd, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
+    if (c->timing) {
+        HIP_TRY(c, hipEventCreate(&f.ev_start));
+        HIP_TRY(c, hipEventCreate(&f.ev_mid));
+        HIP_TRY(c, hipEventCreate(&f.ev_stop));
+    }
     return VGEN_OK;
 }
 
-// Enqueues the arbitrary-scalar kernel on frame f: explicit keys (keys_dev != nullptr) or base + i.
+// What follows the last kernel of a dispatch on the frame's bwd stream: the copy of the results and the event
+// vgen_wait waits on.
+int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys) {
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.s_bwd));
+    if (dump)
+        HIP_TRY(c, hipMemcpyAsync(f.h_dump, f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t), hipMemcpyDeviceToHost, f.s_bwd));
+    else
+        HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.s_bwd));
+    HIP_TRY(c, hipEventRecord(f.ev_done, f.s_bwd));
+    f.in_flight = true;
+    f.dumped = dump;
+    f.keys_tested = keys;
+    return VGEN_OK;
+}
+
 int ensure_gtab(vgen_ctx *c) {
     if (!c->d_gtab) {
         std::vector<uint32_t> tab;
         host_gen_table8_limbs(tab);   // 8-bit windows, 652 800 B (core/ec.h)
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemcpy(c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipDeviceSynchronize());   // (null-stream upload: see rt_set_filter)
+        if (int rc = upload(c, c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t))) return rc;
     }
     return VGEN_OK;
 }
 
+// Keys and scratch of the arbitrary-scalar path for all frames (keys [batch][32 B] | xyz | tree | root per
+// frame), one allocation when the path is first used: it serves vgen_dispatch_keys and the rare sequential
+// batches that touch the group order, so most contexts never pay its ~155 MB per frame.
+int ensure_keys_slab(vgen_ctx *c) {
+    if (c->d_keys_slab) return VGEN_OK;
+    const uint32_t max_groups = (c->batch + KEYS_WG - 1) / KEYS_WG;
+    const size_t keys_b = up256((size_t)c->batch * 32);
+    const size_t scratch_b = up256(((size_t)27 * max_groups * KEYS_WG + (size_t)max_groups * 9 * KEYS_WG + (size_t)9 * max_groups) * sizeof(uint32_t));
+    HIP_TRY(c, hipMalloc((void **)&c->d_keys_slab, (keys_b + scratch_b) * c->frames));
+    for (uint32_t i = 0; i < c->frames; i++) {
+        c->fr[i].d_keys = c->d_keys_slab + (keys_b + scratch_b) * i;
+        c->fr[i].d_keys_scratch = reinterpret_cast<uint32_t *>(c->d_keys_slab + (keys_b + scratch_b) * i + keys_b);
+    }
+    return VGEN_OK;
+}
+
+// Enqueues the arbitrary-scalar kernels on frame f (its bwd stream carries the whole chain): explicit keys
+// (keys_dev != nullptr) or base + i.
 int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
     if (int rc = ensure_gtab(c)) return rc;
-    if (int rc = ensure_stream(c, f)) return rc;
+    if (int rc = ensure_keys_slab(c)) return rc;
     KeysArgs a;
     memset(&a, 0, sizeof a);
     a.gtab = c->d_gtab;
@@ -247,19 +447,15 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     a.filter = c->d_filter;
     a.n = n;
     a.fmt = c->format;
-    // scratch of the three stages, sized for a full batch on first use: xyz | tree | root
     const uint32_t max_groups = (c->batch + KEYS_WG - 1) / KEYS_WG;
-    if (!f.d_keys_scratch)
-        HIP_TRY(c, hipMalloc((void **)&f.d_keys_scratch,
-                             ((size_t)27 * max_groups * KEYS_WG + (size_t)max_groups * 9 * KEYS_WG + (size_t)9 * max_groups) * sizeof(uint32_t)));
     a.groups = (n + KEYS_WG - 1) / KEYS_WG;
     a.xyz = f.d_keys_scratch;
     a.tree = a.xyz + (size_t)27 * max_groups * KEYS_WG;
     a.root = a.tree + (size_t)max_groups * 9 * KEYS_WG;
-    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
+    const bool dump = dump_mode(c);
     if (dump) {
-        if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
-        if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.stream));
+        if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
+        if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.s_bwd));
         a.dump = f.d_dump;
     } else {
         a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
@@ -271,15 +467,9 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
             a.dfa_bytes = c->h_filter.dfa_bytes;
         }
     }
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
-    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.stream, c->timing ? f.ev_mid : nullptr));
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
-    if (!dump)
-        HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
-    f.in_flight = true;
-    f.dumped = dump;
-    f.keys_tested = n;
-    return VGEN_OK;
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s_bwd));
+    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.s_bwd, c->timing ? f.ev_mid : nullptr));
+    return finish_dispatch(c, f, dump, n);
 }
 
 }  // namespace
@@ -292,7 +482,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     scalar_from_be(k0, start_key_be);
     if (!scalar_is_valid(k0)) return c->fail(VGEN_E_RANGE, "start key is not a valid secp256k1 scalar");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (int rc = ensure_stream(c, f)) return rc;
+    if (int rc = ensure_frame(c, frame)) return rc;
     f.start = k0;
     // The batched affine additions have no exceptional cases as long as every scalar involved stays
     // below n (SURVEY.md §7 "hard parts"): k0 + N + S < n.  The (astronomically rare) batches that touch
@@ -326,13 +516,14 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     a.pre = f.d_scratch;
     a.tree = a.pre + (size_t)S * 9 * c->lanes;
     a.root = a.tree + (size_t)c->groups * 9 * SEQ_WG;
+    a.arrive = c->fused_inv ? a.root + (size_t)9 * c->groups : nullptr;
     a.lanes = c->lanes;
     a.groups = c->groups;
     a.n = c->batch;
     a.s = S;
-    const bool dump = !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL;
+    const bool dump = dump_mode(c);
     if (dump) {
-        if (!f.d_dump) HIP_TRY(c, hipMalloc((void **)&f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t)));
+        if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
         a.dump = f.d_dump;
     } else {
         a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
@@ -351,23 +542,22 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         // ... and the tweaked points of the dispatch wait in scratch for their shared inversion:
         // tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
         const size_t tq_words = (size_t)2 * S * 27 * c->lanes, flag_words = (size_t)2 * S * c->lanes;
-        const size_t tree_words = (size_t)c->groups * 9 * SEQ_WG, root_words = (size_t)9 * c->groups;
-        if (!f.d_p2tr_scratch)
-            HIP_TRY(c, hipMalloc((void **)&f.d_p2tr_scratch, (tq_words + flag_words + tree_words + root_words) * sizeof(uint32_t)));
+        const size_t tree_words = (size_t)c->groups * 9 * SEQ_WG;
         a.tq = f.d_p2tr_scratch;
         a.tq_flag = a.tq + tq_words;
         a.tree2 = a.tq_flag + flag_words;
         a.root2 = a.tree2 + tree_words;
     }
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.stream));
-    HIP_TRY(c, launch_seq_scan((int)c->format, a, f.stream, c->timing ? f.ev_mid : nullptr));
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.stream));
-    if (!dump)
-        HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.stream));
-    f.in_flight = true;
-    f.dumped = dump;
-    f.keys_tested = c->batch;
-    return VGEN_OK;
+    // first half on the frame's fwd stream, second half on its bwd stream behind an event
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s_fwd));
+    HIP_TRY(c, launch_seq_fwd(a, f.s_fwd));
+    if (f.s_fwd != f.s_bwd) {
+        HIP_TRY(c, hipEventRecord(f.ev_fwd, f.s_fwd));
+        HIP_TRY(c, hipStreamWaitEvent(f.s_bwd, f.ev_fwd, 0));
+    }
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_mid, f.s_bwd));
+    HIP_TRY(c, launch_seq_bwd((int)c->format, a, f.s_bwd));
+    return finish_dispatch(c, f, dump, c->batch);
 }
 
 int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32_t n) {
@@ -376,9 +566,9 @@ int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (int rc = ensure_stream(c, f)) return rc;
-    if (!f.d_keys) HIP_TRY(c, hipMalloc((void **)&f.d_keys, (size_t)c->batch * 32));
-    HIP_TRY(c, hipMemcpyAsync(f.d_keys, keys_be, (size_t)n * 32, hipMemcpyHostToDevice, f.stream));
+    if (int rc = ensure_frame(c, frame)) return rc;
+    if (int rc = ensure_keys_slab(c)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(f.d_keys, keys_be, (size_t)n * 32, hipMemcpyHostToDevice, f.s_bwd));
     memset(&f.start, 0, sizeof f.start);
     return enqueue_keys(c, f, f.d_keys, nullptr, n);
 }
@@ -388,7 +578,7 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
     vgen_ctx::Frame &f = c->fr[frame];
     if (!f.in_flight) return c->fail(VGEN_E_STATE, "No pending operation on frame " + std::to_string(frame));
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(f.stream));
+    HIP_TRY(c, hipEventSynchronize(f.ev_done));
     f.in_flight = false;
     f.timing_fresh = false;   // elapsed times are read from the events on demand (rt_frame_times)
     if (keys_tested) *keys_tested = f.keys_tested;
@@ -398,9 +588,12 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
         found = hdr->count - f.match_base;   // mod 2^32
         f.match_base = hdr->count;
         uint32_t stored = std::min(found, c->match_cap);
-        if (stored > FIRST_COPY)
-            HIP_TRY(c, hipMemcpy(f.h_match + match_bytes(FIRST_COPY), f.d_match + match_bytes(FIRST_COPY),
-                                 (size_t)(stored - FIRST_COPY) * sizeof(DevMatch), hipMemcpyDeviceToHost));
+        if (stored > FIRST_COPY) {   // rare: the tail of a busy ring, fetched on the frame's own stream
+            HIP_TRY(c, hipMemcpyAsync(f.h_match + match_bytes(FIRST_COPY), f.d_match + match_bytes(FIRST_COPY),
+                                      (size_t)(stored - FIRST_COPY) * sizeof(DevMatch), hipMemcpyDeviceToHost, f.s_bwd));
+            HIP_TRY(c, hipEventRecord(f.ev_done, f.s_bwd));
+            HIP_TRY(c, hipEventSynchronize(f.ev_done));
+        }
         DevMatch *rec = reinterpret_cast<DevMatch *>(f.h_match + sizeof(DevMatchHeader));
         // ascending index, the order the reference's par_iter().enumerate() collect yields (gpu.rs:1030-1093)
         std::sort(rec, rec + stored, [](const DevMatch &x, const DevMatch &y) { return x.index < y.index; });
@@ -423,7 +616,7 @@ int rt_frame_times(vgen_ctx *c, uint32_t frame, float *kernel_ms, float *total_m
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame still in flight");
     if (!c->timing) return c->fail(VGEN_E_STATE, "the context was created without VGEN_FLAG_TIMING");
-    if (!f.timing_fresh && f.stream) {
+    if (!f.timing_fresh && f.s_bwd) {
         HIP_TRY(c, hipSetDevice(c->device));
         (void)hipEventElapsedTime(&f.last_ms, f.ev_mid, f.ev_stop);
         (void)hipEventElapsedTime(&f.last_total_ms, f.ev_start, f.ev_stop);
@@ -434,15 +627,24 @@ int rt_frame_times(vgen_ctx *c, uint32_t frame, float *kernel_ms, float *total_m
     return VGEN_OK;
 }
 
-int rt_read_dump(vgen_ctx *c, uint32_t frame, uint8_t *out, size_t out_len) {
-    if (frame >= c->frames || !out) return c->fail(VGEN_E_INVALID, "bad frame index / buffer");
+// The pinned mirror of the frame's dump (filled by the dispatch's own copy): valid until the frame is dispatched again.
+int rt_dump_view(vgen_ctx *c, uint32_t frame, const uint8_t **ptr, size_t *len) {
+    if (frame >= c->frames || !ptr) return c->fail(VGEN_E_INVALID, "bad frame index / pointer");
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "vgen_read_dump before vgen_wait");
-    if (!f.dumped || !f.d_dump) return c->fail(VGEN_E_STATE, "frame's last dispatch was not in dump mode");
-    const size_t need = (size_t)c->batch * c->payload_words * sizeof(uint32_t);
+    if (!f.dumped || !f.h_dump) return c->fail(VGEN_E_STATE, "frame's last dispatch was not in dump mode");
+    *ptr = f.h_dump;
+    if (len) *len = (size_t)c->batch * c->payload_words * sizeof(uint32_t);
+    return VGEN_OK;
+}
+
+int rt_read_dump(vgen_ctx *c, uint32_t frame, uint8_t *out, size_t out_len) {
+    if (!out) return c->fail(VGEN_E_INVALID, "bad frame index / buffer");
+    const uint8_t *src = nullptr;
+    size_t need = 0;
+    if (int rc = rt_dump_view(c, frame, &src, &need)) return rc;
     if (out_len < need) return c->fail(VGEN_E_INVALID, "output buffer too small");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpy(out, f.d_dump, need, hipMemcpyDeviceToHost));
+    memcpy(out, src, need);
     return VGEN_OK;
 }
 

@@ -1,8 +1,12 @@
-// runtime.h — the HIP runtime object behind vgen_ctx: device binding, frames (stream + buffers +
-// events), offset table, dispatch and readback.  MI355X-native stand-in for the reference's
-// GpuRunner / Frame pair (src/gpu.rs:101-131): hipMalloc'ed buffers sized once, one stream per frame
-// so that consecutive dispatches overlap on the device, pinned host staging for the small
-// per-dispatch uploads and the rare match records, hipEvents around every launch.
+// runtime.h — the HIP runtime object behind vgen_ctx: device binding, frames (buffers + events), stage
+// streams, offset table, dispatch and readback.  MI355X-native stand-in for the reference's GpuRunner /
+// Frame pair (src/gpu.rs:101-131): hipMalloc'ed buffers sized once, pinned host staging for the rare match
+// records (and the dumps of dump mode).  One launch of the per-key kernel is only one wave per SIMD and a
+// dispatch is a chain of dependent launches, so the device is filled by the frames in flight: by default every
+// frame drives its dispatches through a private stream that OWNS a hardware queue (see stage_stream() in
+// runtime.cpp — no GPU_MAX_HW_QUEUES needed).  Alternatively (VGEN_STREAMS=A,B) the first halves of all
+// dispatches (seq_fwd + root inversions) share A streams and the second halves (seq_bwd, result copies) share
+// B streams, joined by events: the layout for hosts where queues are scarce.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -32,14 +36,17 @@ struct vgen_ctx {
     vg::DevFilter h_filter{};
 
     struct Frame {
-        hipStream_t stream = nullptr;
-        hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;   // before fwd / before bwd / after bwd
-        uint32_t *d_dump = nullptr;
-        uint8_t *d_keys = nullptr;       // explicit keys of vgen_dispatch_keys
-        uint32_t *d_keys_scratch = nullptr;   // arbitrary-scalar path: Jacobian results | tree | roots (first use)
-        uint32_t *d_p2tr_scratch = nullptr;   // P2TR: tweaked points | flags | second tree | second roots (first use)
+        hipStream_t s_fwd = nullptr, s_bwd = nullptr;   // this frame's stage streams (owned by the context)
+        hipEvent_t ev_fwd = nullptr;     // first half done (s_fwd -> s_bwd), no timing
+        hipEvent_t ev_done = nullptr;    // dispatch complete incl. its copies: what vgen_wait waits on, no timing
+        hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;   // VGEN_FLAG_TIMING: before fwd / before bwd / after bwd
+        uint32_t *d_dump = nullptr;      // dump mode: slice of d_dump_slab
+        uint8_t *h_dump = nullptr;       // dump mode: pinned mirror, filled by the dispatch's own async copy
+        uint8_t *d_keys = nullptr;       // explicit keys of vgen_dispatch_keys (slice of d_keys_slab)
+        uint32_t *d_keys_scratch = nullptr;   // arbitrary-scalar path: Jacobian results | tree | roots (slice of d_keys_slab)
+        uint32_t *d_p2tr_scratch = nullptr;   // P2TR: tweaked points | flags | second tree | second roots (slice of d_slab)
         uint64_t keys_tested = 0;
-        uint32_t *d_scratch = nullptr;   // pre | tree | root (device_types.h / kernels.hip)
+        uint32_t *d_scratch = nullptr;   // pre | tree | root | arrive (device_types.h / kernels.hip)
         uint32_t match_base = 0;         // candidate counter value when the last dispatch was enqueued
         uint8_t *d_match = nullptr;      // DevMatchHeader followed by match_cap DevMatch
         uint8_t *h_match = nullptr;      // pinned mirror
@@ -51,8 +58,21 @@ struct vgen_ctx {
         float last_total_ms = 0.f;       // whole dispatch: fwd + inv + bwd
     };
     std::vector<Frame> fr;
-    uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch | match ring, per frame)
+    // stage streams: frame i uses fwd_streams[i % n_fwd] and bwd_streams[i % n_bwd]; n_fwd == 0: the first half
+    // runs on the frame's bwd stream as well (one serial chain per bwd stream); per_frame_streams: the round-1
+    // topology, one private stream per frame for both halves (needs GPU_MAX_HW_QUEUES >= frames to overlap)
+    uint32_t n_fwd = 0, n_bwd = 0;
+    bool per_frame_streams = true;
+    bool fused_inv = true;                       // root inversions in seq_fwd's tail (else a seq_inv_kernel launch)
+    std::vector<hipStream_t> fwd_streams, bwd_streams;
+    bool own_queues = true;                      // streams with a hardware queue each (CU-masked, all CUs), see runtime.cpp
+    uint32_t cu_count = 0;
+    uint32_t hw_queues = 4;                      // GPU_MAX_HW_QUEUES in effect when the context was created
+    uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch | match ring [| P2TR scratch], per frame)
     uint8_t *h_slab = nullptr;                   // pinned mirrors of the match rings
+    uint8_t *d_dump_slab = nullptr;              // dump mode: payload buffers of all frames (first vgen_set_filter(NULL))
+    uint8_t *h_dump_slab = nullptr;              // ... and their pinned mirrors
+    uint8_t *d_keys_slab = nullptr;              // arbitrary-scalar path: keys + scratch of all frames (first use)
     hipStream_t probe_stream = nullptr;          // shader-clock probe (vgen_clock_probe_*)
     unsigned long long *d_probe = nullptr;
     bool probe_running = false;
@@ -74,6 +94,7 @@ int rt_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint
 int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
             uint64_t *keys_tested);
 int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
+int rt_dump_view(vgen_ctx *ctx, uint32_t frame, const uint8_t **ptr, size_t *len);
 int rt_frame_times(vgen_ctx *ctx, uint32_t frame, float *kernel_ms, float *total_ms);
 int rt_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
 int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);

@@ -9,14 +9,20 @@
 // Differences, all on the host side of the boundary: candidates arrive pre-filtered by the device and
 // are confirmed with the exact DFA (the reference encodes and regex-matches all batch_size hashes on
 // rayon); the base key can be seeded; batches can be striped over several contexts (multi-GPU).
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
+#include <memory>
 #include <random>
 #include <thread>
 #include <vector>
@@ -111,7 +117,8 @@ bool generated_from_key(uint32_t format, const uint8_t kb[32], vgen_generated &g
 // counter advanced — under one lock, so every file written is a consistent prefix of the scan.  Shards
 // process their batches in dispatch order, so "batches done" is a single number per shard.
 //
-// File (text, rewritten atomically through <path>.tmp + rename):
+// File (text, mode 0600 — it holds the private keys of the matches; rewritten atomically through <path>.tmp,
+// fsync, rename):
 //   vgen-hip checkpoint v1 / pattern_hex= / case_insensitive= / format= / batch_size= / n_shards= /
 //   first_shard= / base= / end= / operations= / done=<per slot> / complete= / match=<key hex> ...
 struct Checkpoint {
@@ -216,11 +223,18 @@ struct Checkpoint {
         return -1;
     }
 
-    // caller holds mu
+    // caller holds mu.  The file lists private keys (match=...): it is created 0600, never through a symlink,
+    // and reaches the disk (fsync) before it replaces the previous checkpoint.
     bool write_locked() {
         const std::string tmp = path + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "w");
-        if (!f) return false;
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_NOFOLLOW | O_CLOEXEC, 0600);
+        if (fd < 0) return false;
+        (void)fchmod(fd, 0600);   // an older .tmp may have been left with wider permissions
+        FILE *f = fdopen(fd, "w");
+        if (!f) {
+            close(fd);
+            return false;
+        }
         fprintf(f, "vgen-hip checkpoint v1\npattern_hex=%s\ncase_insensitive=%d\nformat=%u\nbatch_size=%u\nn_shards=%u\n"
                    "first_shard=%u\nbase=%s\nend=%s\noperations=%llu\ndone=",
                 hex((const uint8_t *)pattern.data(), pattern.size()).c_str(), ci, format, batch, n_shards, first_shard,
@@ -228,7 +242,7 @@ struct Checkpoint {
         for (size_t i = 0; i < done.size(); i++) fprintf(f, "%s%llu", i ? " " : "", (unsigned long long)done[i]);
         fprintf(f, "\ncomplete=%d\n", complete ? 1 : 0);
         for (auto &g : ledger) fprintf(f, "match=%s\n", hex(g.key, 32).c_str());
-        bool ok = fflush(f) == 0;
+        bool ok = fflush(f) == 0 && fsync(fd) == 0;
         ok = (fclose(f) == 0) && ok;
         ok = ok && rename(tmp.c_str(), path.c_str()) == 0;
         last_write = std::chrono::steady_clock::now();
@@ -244,6 +258,64 @@ struct Checkpoint {
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - last_write).count() >= interval_s)
             (void)write_locked();
     }
+};
+
+// Host-side filtering of full dumps (the reference's rayon par_iter over every hash of a batch,
+// src/gpu.rs:1030-1093): a pool of worker threads that lives as long as the scan, handed one index range per
+// thread and batch.
+class HostFilterPool {
+public:
+    explicit HostFilterPool(unsigned n) : n_(std::max(1u, n)) {
+        for (unsigned t = 0; t < n_; t++) th_.emplace_back([this, t]() { loop(t); });
+    }
+    ~HostFilterPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            quit_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    unsigned size() const { return n_; }
+    // runs fn(t) on every worker t and returns when all are done
+    void run(const std::function<void(unsigned)> &fn) {
+        std::unique_lock<std::mutex> g(mu_);
+        fn_ = &fn;
+        pending_ = n_;
+        gen_++;
+        cv_.notify_all();
+        done_.wait(g, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop(unsigned t) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&]() { return gen_ != seen; });
+                seen = gen_;
+                if (quit_) return;
+                fn = fn_;
+            }
+            (*fn)(t);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    unsigned n_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned pending_ = 0;
+    uint64_t gen_ = 0;
+    bool quit_ = false;
 };
 
 }  // namespace
@@ -307,18 +379,24 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
 
     uint64_t dispatched = 0;
     total_ops = 0;
+    const uint64_t count = cfg->count;
     auto found = [&]() -> uint64_t { return shared_found ? shared_found->load(std::memory_order_relaxed) : matches.size(); };
     std::vector<vgen_generated> batch_matches;   // matches of the batch being processed (checkpoint commit unit)
-    auto push = [&](const vgen_generated &g) {
-        matches.push_back(g);
+    // A confirmed match: into the result while `count` is not reached; with a checkpoint ALWAYS into the batch's
+    // ledger entry, so that a committed batch is recorded with all of its matches and a later run with a larger
+    // count loses none.  Returns false when the match was dropped (no checkpoint, count reached).
+    auto push = [&](const vgen_generated &g) -> bool {
+        const bool take = found() < count;
+        if (take) {
+            matches.push_back(g);
+            if (shared_found) shared_found->fetch_add(1, std::memory_order_relaxed);
+        }
         if (ck) batch_matches.push_back(g);
-        if (shared_found) shared_found->fetch_add(1, std::memory_order_relaxed);
+        return take || ck;
     };
-    const uint64_t count = cfg->count;
     const uint32_t nf = ctx->frames;
     std::vector<Pending> pend(nf);
     std::vector<vgen_match> recs(ctx->match_cap);
-    std::vector<uint8_t> dumpbuf;
     uint32_t in_flight = 0;
     int status = VGEN_OK;
 
@@ -358,6 +436,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     };
     prime();
 
+    std::unique_ptr<HostFilterPool> pool;   // dump mode only, created with the first dumped batch
+    bool cut_any = false;      // (no checkpoint) some batch had matches beyond `count` dropped: the range was not covered
+
     while (status == VGEN_OK && !order.empty()) {
         const uint32_t frame = order.front();
         order.pop_front();
@@ -368,9 +449,27 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         const Scalar batch_start = pend[frame].start;
         pend[frame].valid = false;
         const bool dumped = ctx->fr[frame].dumped;
+        bool cut = false;      // this batch: a confirmed (or unexamined) match was dropped because `count` was reached
+
         if (dumped) {
-            dumpbuf.resize((size_t)N * pbytes);
-            if ((status = vgen_read_dump(ctx, frame, dumpbuf.data(), dumpbuf.size())) != VGEN_OK) break;
+            // Host filtering of the whole batch (the reference's only mode, gpu.rs:1030-1093) straight from the
+            // pinned buffer the dispatch copied itself into — hence BEFORE the frame is dispatched again —, in
+            // parallel index ranges, results kept in ascending index order.  The device is not the bottleneck
+            // here (encoding and matching 2^20 addresses takes the host tens of milliseconds).
+            const uint8_t *dump = nullptr;
+            if ((status = vgen_dump_view(ctx, frame, &dump, nullptr)) != VGEN_OK) break;
+            if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
+            const unsigned nt = pool->size();
+            std::vector<std::vector<vgen_generated>> part(nt);
+            pool->run([&](unsigned t) {
+                const uint32_t lo = (uint32_t)((uint64_t)N * t / nt), hi = (uint32_t)((uint64_t)N * (t + 1) / nt);
+                vgen_generated g;
+                for (uint32_t i = lo; i < hi; i++)
+                    if (make_match(flt, cfg->format, batch_start, i, dump + (size_t)i * pbytes, end, g)) part[t].push_back(g);
+            });
+            for (auto &p : part)
+                for (auto &g : p)
+                    if (!push(g)) cut = true;
         }
 
         bool dispatched_next = false;
@@ -380,25 +479,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             if (active < nf && may_launch() && !launch(active++)) break;   // ramp up: one more frame per batch
         }
 
-        if (dumped) {
-            // host filtering of the whole batch (the reference's only mode, gpu.rs:1030-1093), in
-            // parallel chunks, results kept in ascending index order
-            unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-            std::vector<std::vector<vgen_generated>> part(nt);
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++)
-                th.emplace_back([&, t]() {
-                    uint32_t lo = (uint32_t)((uint64_t)N * t / nt), hi = (uint32_t)((uint64_t)N * (t + 1) / nt);
-                    vgen_generated g;
-                    for (uint32_t i = lo; i < hi; i++)
-                        if (make_match(flt, cfg->format, batch_start, i, &dumpbuf[(size_t)i * pbytes], end, g))
-                            part[t].push_back(g);
-                });
-            for (auto &x : th) x.join();
-            for (auto &p : part)
-                for (auto &g : p)
-                    if (found() < count) push(g);
-        } else {
+        if (!dumped) {
             if (n_found > recs.size()) {
                 // More candidates than the ring holds (a permissive pattern): nothing may be dropped, so
                 // drain what is in flight, switch to host filtering of full dumps (the reference's mode)
@@ -416,22 +497,26 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                 continue;
             }
             vgen_generated g;
-            for (uint32_t i = 0; i < n_found && found() < count; i++)
-                if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) push(g);
+            uint32_t i = 0;
+            for (; i < n_found && (ck || found() < count); i++)
+                if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) (void)push(g);
+            cut = i < n_found;   // candidates left unexamined (conservative: they may not all be matches)
         }
 
         total_ops += N;                              // gpu.rs:1106
-        if (ck) {
-            ck->commit(ck_slot, batch_matches, N);
-            batch_matches.clear();
-        }
-        if (cb) cb(shared_ops ? shared_ops->fetch_add(N) + N : total_ops, user);
+        // With a checkpoint a batch is committed with every match it holds (push above), also those beyond
+        // `count`: the file stays a consistent prefix of the scan whatever count a later run asks for.
+        cut_any = cut_any || cut;
+        if (ck) ck->commit(ck_slot, batch_matches, N);
+        batch_matches.clear();
+        if (cb) cb(shared_ops ? N : total_ops, user);   // multi-device: the wrapper adds N to the shared count under its lock
         if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
+    const bool all_processed = order.empty() && !cut_any;   // no dispatched batch was left unread or cut short
     for (uint32_t f = 0; f < nf; f++)
         if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
-    if (range_done) *range_done = status == VGEN_OK && !in_range();
+    if (range_done) *range_done = status == VGEN_OK && !in_range() && all_processed;
     return status;
 }
 
@@ -506,7 +591,8 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     const uint32_t shards = c.n_shards > 1 ? c.n_shards : 1;
     int rc = open_checkpoint(ctx, ck, pattern, c, ctx->batch, shards, c.n_shards > 1 ? c.shard : 0, 1);
     if (rc != VGEN_OK) return rc;
-    matches = ck.ledger;   // what earlier runs found counts towards `count`
+    matches = ck.ledger;   // what earlier runs found counts towards `count` (committed batches keep all their matches)
+    if (matches.size() > c.count) matches.resize((size_t)c.count);
     if (!ck.complete && matches.size() < c.count)
         rc = scan_shard(ctx, flt, &c, cb, user, stop, nullptr, nullptr, matches, ops, &ck, 0, &range_done);
     {
@@ -553,11 +639,13 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     std::vector<int> rcs(n_ctx, VGEN_OK);
     std::vector<std::thread> th;
     std::mutex cb_mu;
-    struct CbCtx { vgen_progress_cb cb; void *user; std::mutex *mu; } cbc{cb, user, &cb_mu};
-    auto locked_cb = [](uint64_t o, void *u) {
+    // one callback per finished batch of any shard, with the cumulative count of all shards: the increment and
+    // the call share a lock, so the host sees strictly increasing multiples of the batch size (gpu.rs:1106-1109)
+    struct CbCtx { vgen_progress_cb cb; void *user; std::mutex *mu; std::atomic<uint64_t> *ops; } cbc{cb, user, &cb_mu, &ops_shared};
+    auto locked_cb = [](uint64_t delta, void *u) {
         CbCtx *c = (CbCtx *)u;
         std::lock_guard<std::mutex> g(*c->mu);
-        c->cb(o, c->user);
+        c->cb(c->ops->fetch_add(delta) + delta, c->user);
     };
     for (uint32_t i = 0; i < n_ctx && !skip_all; i++)
         th.emplace_back([&, i]() {
