@@ -48,50 +48,116 @@ def test_host_side_helpers_match_oracle():
     assert vg.key_add(2**256 - 1, 1) is None
 
 
-WORKER = r'''
+WORKER = r"""
 import json, os, sys
 sys.path.insert(0, sys.argv[1])
 import torch, torch.distributed as dist
-from oracle import pyoracle as vo
+import bench                                   # the product's own striping: bench.batch_key / bench.seed_key
+import vgen_amd as vg                          # the product's host side of the boundary (no device needed for these calls)
+from oracle import pyoracle as vo              # stands in for the device: payloads of each batch
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-N, BATCHES = 2048, 6                       # keys per batch, global batches
-k0 = vo.seed_key(42, 0)
-pat = vo.Regex("^1[A-F]")
-mine, ops = [], 0
-for b in range(rank, BATCHES, world):      # batch striping: rank g takes b = g (mod world)
-    blob = vo.payload_seq(0, k0 + b * N, N, threads=1)
+N, STEPS = 2048, 3                             # keys per batch, steps per rank  (global batches = STEPS * world)
+k0 = bench.seed_key(42, 0)
+assert k0 == vo.seed_key(42, 0)
+pat = vg.Pattern("^1[A-F]", False, vg.AddressFormat.P2pkh)
+mine, ops, starts = [], 0, []
+for step in range(STEPS):
+    start = bench.batch_key(k0, step, world, rank, N)          # what bench.py dispatches on this rank at this step
+    starts.append(start)
+    blob = vo.payload_seq(0, start, N, threads=1)
     for i in range(N):
-        a = vo.address_from_hash160(0, blob[20 * i:20 * i + 20])
-        if pat.matches(a):
-            mine.append(k0 + b * N + i)
+        if pat.matches(vg.address_from_payload(0, blob[20 * i:20 * i + 20])):   # host confirm, as scan_shard does
+            mine.append(vg.key_add(start, i))
     ops += N
 dist.barrier()
 gathered = [None] * world
-dist.all_gather_object(gathered, (mine, ops))   # host-side aggregation of match records and counters
+dist.all_gather_object(gathered, (mine, ops, starts))   # host-side aggregation of match records and counters
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                # the max-over-ranks bench.py takes of the elapsed time
 if rank == 0:
-    merged = sorted(k for m, _ in gathered for k in m)
-    print(json.dumps({"keys": [hex(k) for k in merged], "ops": sum(o for _, o in gathered)}))
+    merged = sorted(k for m, _, _ in gathered for k in m)
+    print(json.dumps({"keys": [hex(k) for k in merged], "ops": sum(o for _, o, _ in gathered),
+                      "starts": sorted(s for _, _, st in gathered for s in st), "max": t.item()}))
 dist.destroy_process_group()
-'''
+"""
+
+
+def _torchrun(script, args, port, timeout=600, env_extra=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(env_extra or {}))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)] + args,
+                          capture_output=True, text=True, env=env, timeout=timeout)
 
 
 def test_two_rank_batch_striping_equals_single_range_scan(tmp_path):
+    """Two gloo ranks walk the batches bench.py's own batch_key() assigns them, confirm candidates with the
+    product's host filter, and the merged result must be the oracle's scan of the whole range: the striping is
+    disjoint, complete and in the order SURVEY.md 8(e) states."""
+    import json
     from oracle import pyoracle as vo
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script), ROOT],
-                         capture_output=True, text=True, env=env, timeout=600)
+    out = _torchrun(script, [ROOT], 29517)
     assert out.returncode == 0, out.stderr[-2000:]
-    import json
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    got = json.loads(line)
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     k0 = vo.seed_key(42, 0)
+    assert got["starts"] == [k0 + b * 2048 for b in range(6)]          # contiguous, disjoint, nothing skipped
     ref = vo.scan_range(0, "^1[A-F]", k0, k0 + 6 * 2048 - 1, count=10**9, threads=2)
-    assert got["ops"] == 6 * 2048 == ref["operations"]
+    assert got["ops"] == 6 * 2048 == ref["operations"] and got["max"] == 2.0
     assert got["keys"] == [hex(m["key"]) for m in ref["matches"]]
+
+
+GPU_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import vgen_amd as vg
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, device=0, frames=3)
+cfg = vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=1, end=0x2FFFF, shard=rank, n_shards=world)
+res = vg.scan_gpu_with_runner("^1[A-C]", cfg, r)          # the product's own striping: scan_shard(shard, n_shards)
+r.close()
+gathered = [None] * world
+dist.all_gather_object(gathered, ([m.hex for m in res.matches], res.operations, res.complete))
+if rank == 0:
+    print(json.dumps({"keys": sorted(k for m, _, _ in gathered for k in m), "ops": [o for _, o, _ in gathered],
+                      "complete": [c for _, _, c in gathered]}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_striping_one_scan_through_vgen_scan_shards(tmp_path):
+    """The N>1 shape of the product itself: two processes (ranks), each driving its own context through
+    vgen_scan with shard = rank, n_shards = 2 (here both on GPU 0), merged on the host over gloo."""
+    import json
+    from oracle import pyoracle as vo
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(GPU_WORKER)
+    out = _torchrun(script, [ROOT], 29519)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    ref = vo.scan_range(0, "^1[A-C]", 1, 0x2FFFF, count=10**9)
+    assert got["keys"] == [m["hex"] for m in ref["matches"]]
+    assert got["ops"] == [12 * 8192, 12 * 8192] and got["complete"] == [True, True]   # 24 batches of 8192 cover 1..0x2FFFF
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_prints_one_contract_line():
+    """bench.py's N>1 path (torchrun, gloo barrier / max over ranks, batch striping) run for real: two ranks
+    sharing the one GPU of the test box (VGEN_BENCH_REHEARSE=1), rank 0 prints the single JSON line."""
+    import json
+    out = _torchrun(os.path.join(ROOT, "bench.py"), ["--gpus", "2", "--steps", "64", "--warmup", "8", "--sustained-seconds", "0.3"],
+                    29521, env_extra={"VGEN_BENCH_REHEARSE": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 64 and d["scaling"] == "weak" and d["value"] > 1000
+    assert d["config"]["parallelism"].startswith("range-striped x2") and d["sustained"]["value"] > 1000
+    assert "cpu_baseline" not in d and "other_configs" not in d
 
 
 def test_cli_warns_about_impossible_patterns_before_touching_the_device():

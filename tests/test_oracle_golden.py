@@ -218,7 +218,9 @@ def test_regex_agrees_with_python_re_on_ascii_subset():
 
 
 def test_regex_unsupported_syntax_is_an_error_not_a_guess():
-    for pat in ["\\bfoo", "\\p{L}", "[a-z&&[^b]]", "(?m)^a", "a{,3}", "*a", "(a", "a)"]:
+    # what remains unsupported: the CRLF flag and Unicode class names outside the oracle's table; the rest of the
+    # list is invalid in the regex crate as well (tests/test_regex_syntax.py covers the supported syntax)
+    for pat in ["(?R)^a", "\\p{NoSuchClass}", "(?=a)", "a{,3}", "*a", "(a", "a)"]:
         with pytest.raises(ValueError):
             vo.Regex(pat)
 

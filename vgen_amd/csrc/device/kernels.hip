@@ -44,6 +44,9 @@ namespace vg {
 
 constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 
+#ifndef VG_FWD_TAIL_WAVES
+#define VG_FWD_TAIL_WAVES 4
+#endif
 #ifndef VG_SEQ_WAVES_P2TR
 #define VG_SEQ_WAVES_P2TR 2
 #endif
@@ -186,7 +189,7 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
 // two launches (fwd+inv -> bwd) and the inversion needs neither a launch nor a hardware queue of its own.
 // (Register budget 128 with the tail: a first-half wave then fits into the slot one retiring seq_bwd wave frees.)
 template <bool INV_TAIL>
-__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(INV_TAIL ? 4 : 1, INV_TAIL ? 4 : 8)))
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(INV_TAIL ? VG_FWD_TAIL_WAVES : 1, INV_TAIL ? VG_FWD_TAIL_WAVES : 8)))
 seq_fwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
     const int tid = threadIdx.x;

@@ -1,6 +1,8 @@
 // regex_dfa.cpp — see regex_dfa.h.
 #include "regex_dfa.h"
 
+#include <string.h>
+
 #include <algorithm>
 #include <map>
 #include <memory>
@@ -10,21 +12,42 @@ namespace vg {
 
 namespace {
 
+// A set of haystack symbols: the 128 ASCII codes + one bit for "any byte >= 128" (address strings are ASCII; the
+// bit only keeps negated classes and '.' well defined on arbitrary bytes).
 struct CharSet {
-    uint64_t bits[2] = {0, 0};   // ASCII 0..127
-    bool other = false;          // bytes >= 128
+    uint64_t bits[2] = {0, 0};
+    bool other = false;
     void add(int c) { bits[c >> 6] |= 1ull << (c & 63); }
+    void add_range(int lo, int hi) {
+        for (int c = lo; c <= hi; c++) add(c);
+    }
     bool has(int c) const { return c < 128 ? (bits[c >> 6] >> (c & 63)) & 1 : other; }
     void merge(const CharSet &o) {
         bits[0] |= o.bits[0];
         bits[1] |= o.bits[1];
         other = other || o.other;
     }
+    void intersect(const CharSet &o) {
+        bits[0] &= o.bits[0];
+        bits[1] &= o.bits[1];
+        other = other && o.other;
+    }
+    void subtract(const CharSet &o) {
+        bits[0] &= ~o.bits[0];
+        bits[1] &= ~o.bits[1];
+        other = other && !o.other;
+    }
+    void symdiff(const CharSet &o) {
+        bits[0] ^= o.bits[0];
+        bits[1] ^= o.bits[1];
+        other = other != o.other;
+    }
     void negate() {
         bits[0] = ~bits[0];
         bits[1] = ~bits[1];
         other = !other;
     }
+    // simple case folding restricted to what can matter on ASCII text
     void fold_case() {
         for (int c = 'a'; c <= 'z'; c++) {
             int u = c - 'a' + 'A';
@@ -36,11 +59,39 @@ struct CharSet {
     }
 };
 
+// Zero-width assertions.  prev / next are the symbol kinds either side of the position.
+enum Assert { A_TEXT_START, A_TEXT_END, A_LINE_START, A_LINE_END, A_WORD, A_NOT_WORD, A_WORD_START, A_WORD_END,
+              A_WORD_START_HALF, A_WORD_END_HALF };
+enum Kind { K_EDGE = 0, K_NEWLINE = 1, K_WORD = 2, K_OTHER = 3, K_UNKNOWN = 4 };   // K_EDGE: start / end of the haystack
+
+bool is_word_byte(int c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
+Kind kind_of(int c) { return c == '\n' ? K_NEWLINE : (c < 128 && is_word_byte(c)) ? K_WORD : K_OTHER; }
+
+bool needs_next(Assert a) { return !(a == A_TEXT_START || a == A_LINE_START || a == A_WORD_START_HALF); }
+
+bool assert_holds(Assert a, Kind prev, Kind next) {
+    const bool pw = prev == K_WORD, nw = next == K_WORD;
+    switch (a) {
+    case A_TEXT_START: return prev == K_EDGE;
+    case A_TEXT_END: return next == K_EDGE;
+    case A_LINE_START: return prev == K_EDGE || prev == K_NEWLINE;
+    case A_LINE_END: return next == K_EDGE || next == K_NEWLINE;
+    case A_WORD: return pw != nw;
+    case A_NOT_WORD: return pw == nw;
+    case A_WORD_START: return !pw && nw;
+    case A_WORD_END: return pw && !nw;
+    case A_WORD_START_HALF: return !pw;
+    case A_WORD_END_HALF: return !nw;
+    }
+    return false;
+}
+
 struct Node;
 using NodeP = std::shared_ptr<Node>;
 struct Node {
-    enum Type { EMPTY, SET, CAT, ALT, STAR, PLUS, QUEST, BOL, EOL, REPEAT } type = EMPTY;
+    enum Type { EMPTY, SET, CAT, ALT, STAR, PLUS, QUEST, ASSERT, REPEAT } type = EMPTY;
     CharSet set;
+    Assert as = A_TEXT_START;
     NodeP a, b;
     int lo = 0, hi = 0;   // REPEAT; hi < 0 = unbounded
 };
@@ -57,12 +108,73 @@ struct ParseError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
+// ---- parser: the syntax of the regex crate (regex-syntax 0.8) as far as it can matter on ASCII haystacks ------
+//
+// flags i m s x U u (inline, scoped and negated), groups (capturing, named, non-capturing), alternation,
+// repetition (* + ? {n} {n,} {n,m}, lazy forms: laziness cannot change is_match), '.', anchors ^ $ \A \z,
+// word boundaries \b \B \< \> \b{start} \b{end} \b{start-half} \b{end-half}, escapes (\n \t ... \xHH \x{..}
+// \uHHHH \u{..} \U........), Perl classes \d \s \w, Unicode classes \pX \p{Name} \P{..} \p{^..} \p{gc=..}
+// restricted to their ASCII members, bracket classes with ranges, negation, nesting, POSIX names [[:alpha:]] and
+// the set operators && -- ~~.  Non-ASCII literals are accepted: they match no ASCII symbol.
+// Not supported (an error, never a guess): the CRLF flag R, Unicode class names outside the table below,
+// \p{..} value forms other than gc= / sc= / scx=.
+struct Flags {
+    bool i = false, m = false, s = false, x = false, U = false;
+};
+
+struct PropName {
+    const char *name;
+    const char *members;   // ASCII members as ranges "az" pairs; "" = no ASCII member
+};
+
+// Unicode general categories, scripts and binary properties -> their ASCII members (UCD 15; names compared
+// loosely: case, '_', '-' and spaces ignored, as UAX44-LM3 / the regex crate do).
+const PropName PROPS[] = {
+    {"any", "\x01\x7f\x00\x00"}, {"ascii", "\x01\x7f\x00\x00"}, {"assigned", "\x01\x7f\x00\x00"},
+    {"l", "AZaz"}, {"letter", "AZaz"}, {"lc", "AZaz"}, {"casedletter", "AZaz"}, {"alphabetic", "AZaz"}, {"alpha", "AZaz"},
+    {"lu", "AZ"}, {"uppercaseletter", "AZ"}, {"uppercase", "AZ"}, {"upper", "AZ"},
+    {"ll", "az"}, {"lowercaseletter", "az"}, {"lowercase", "az"}, {"lower", "az"},
+    {"cased", "AZaz"}, {"caseignorable", "''..::^^``"},
+    {"lt", ""}, {"titlecaseletter", ""}, {"lm", ""}, {"modifierletter", ""}, {"lo", ""}, {"otherletter", ""},
+    {"m", ""}, {"mark", ""}, {"mn", ""}, {"nonspacingmark", ""}, {"mc", ""}, {"spacingmark", ""}, {"me", ""}, {"enclosingmark", ""},
+    {"n", "09"}, {"number", "09"}, {"nd", "09"}, {"decimalnumber", "09"}, {"digit", "09"},
+    {"nl", ""}, {"letternumber", ""}, {"no", ""}, {"othernumber", ""},
+    {"p", "!#%*,/:;?@[]__{{}}"}, {"punctuation", "!#%*,/:;?@[]__{{}}"}, {"punct", "!#%*,/:;?@[]__{{}}"},
+    {"pc", "__"}, {"connectorpunctuation", "__"}, {"pd", "--"}, {"dashpunctuation", "--"},
+    {"ps", "(([[{{"}, {"openpunctuation", "(([[{{"}, {"pe", "))]]}}"}, {"closepunctuation", "))]]}}"},
+    {"pi", ""}, {"initialpunctuation", ""}, {"pf", ""}, {"finalpunctuation", ""},
+    {"po", "!#%'**,,./:;?@\\\\"}, {"otherpunctuation", "!#%'**,,./:;?@\\\\"},
+    {"s", "$$++<>^^``||~~"}, {"symbol", "$$++<>^^``||~~"}, {"sm", "++<>||~~"}, {"mathsymbol", "++<>||~~"},
+    {"sc", "$$"}, {"currencysymbol", "$$"}, {"sk", "^^``"}, {"modifiersymbol", "^^``"}, {"so", ""}, {"othersymbol", ""},
+    {"z", "  "}, {"separator", "  "}, {"zs", "  "}, {"spaceseparator", "  "}, {"zl", ""}, {"lineseparator", ""},
+    {"zp", ""}, {"paragraphseparator", ""},
+    {"c", "\x01\x1f\x7f\x7f"}, {"other", "\x01\x1f\x7f\x7f"}, {"cc", "\x01\x1f\x7f\x7f"}, {"control", "\x01\x1f\x7f\x7f"}, {"cntrl", "\x01\x1f\x7f\x7f"},
+    {"cf", ""}, {"format", ""}, {"cs", ""}, {"surrogate", ""}, {"co", ""}, {"privateuse", ""}, {"cn", ""}, {"unassigned", ""},
+    {"whitespace", "\x09\x0d  "}, {"space", "\x09\x0d  "}, {"wspace", "\x09\x0d  "},
+    {"hexdigit", "09AFaf"}, {"hex", "09AFaf"}, {"asciihexdigit", "09AFaf"}, {"ahex", "09AFaf"},
+    {"latin", "AZaz"}, {"latn", "AZaz"},
+    {"common", "\x01@[`{\x7f"}, {"zyyy", "\x01@[`{\x7f"},
+    {"greek", ""}, {"grek", ""}, {"cyrillic", ""}, {"cyrl", ""}, {"han", ""}, {"hani", ""}, {"arabic", ""}, {"arab", ""},
+    {"hebrew", ""}, {"hebr", ""}, {"hiragana", ""}, {"hira", ""}, {"katakana", ""}, {"kana", ""}, {"hangul", ""}, {"hang", ""},
+    {"thai", ""}, {"devanagari", ""}, {"deva", ""}, {"armenian", ""}, {"armn", ""}, {"georgian", ""}, {"geor", ""},
+    {"inherited", ""}, {"zinh", ""}, {"unknown", ""}, {"zzzz", ""}, {"emoji", "##**09"}, {"idstart", "AZaz"}, {"idcontinue", "09AZ__az"},
+    {"xidstart", "AZaz"}, {"xidcontinue", "09AZ__az"}, {"math", "++<>^^||~~"}, {"dash", "--"}, {"quotationmark", "\"\"''"},
+    {"patternwhitespace", "\x09\x0d  "}, {"patternsyntax", "!/:@[^``{~"}, {"terminalpunctuation", "!!,,..:;??"},
+};
+
+// NUL cannot be written in the member strings above: U+0000 is added for the classes that contain it.
+bool prop_has_nul(const std::string &n) {
+    return n == "any" || n == "ascii" || n == "assigned" || n == "c" || n == "other" || n == "cc" || n == "control" || n == "cntrl" ||
+           n == "common" || n == "zyyy";
+}
+
 class Parser {
   public:
-    Parser(const std::string &p, bool ci) : s_(p), ci_(ci) {}
+    Parser(const std::string &p, bool ci) : s_(p) { top_.i = ci; }
 
     NodeP parse() {
-        NodeP n = alternation();
+        Flags f = top_;
+        NodeP n = alternation(f);
         if (pos_ < s_.size()) throw ParseError(s_[pos_] == ')' ? "unopened group" : "unexpected character");
         return n;
     }
@@ -70,29 +182,125 @@ class Parser {
   private:
     const std::string &s_;
     size_t pos_ = 0;
-    bool ci_;
+    Flags top_;
+    int depth_ = 0;
 
     bool more() const { return pos_ < s_.size(); }
     int peek(size_t k = 0) const { return pos_ + k < s_.size() ? (unsigned char)s_[pos_ + k] : -1; }
     int take() { return (unsigned char)s_[pos_++]; }
+    bool looking_at(const char *lit) const { return s_.compare(pos_, strlen(lit), lit) == 0; }
+
+    // verbose mode: whitespace and # comments are not part of the pattern
+    void skip_space(const Flags &f) {
+        if (!f.x) return;
+        while (more()) {
+            int c = peek();
+            if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v') {
+                pos_++;
+            } else if (c == '#') {
+                while (more() && peek() != '\n') pos_++;
+            } else {
+                break;
+            }
+        }
+    }
+
+    // one scalar value of the UTF-8 pattern text
+    int take_scalar() {
+        int c = take();
+        if (c < 0x80) return c;
+        int n = c >= 0xF0 ? 3 : c >= 0xE0 ? 2 : c >= 0xC0 ? 1 : -1;
+        if (n < 0) throw ParseError("pattern is not valid UTF-8");
+        int cp = c & (0x3F >> n);
+        for (int k = 0; k < n; k++) {
+            if ((peek() & 0xC0) != 0x80) throw ParseError("pattern is not valid UTF-8");
+            cp = (cp << 6) | (take() & 0x3F);
+        }
+        return cp;
+    }
+
+    // adds scalar value cp (and, case-insensitively, what folds to it) to cs
+    static void add_scalar(CharSet &cs, int cp, bool ci) {
+        if (cp < 128) {
+            cs.add(cp);
+        } else {
+            cs.other = true;
+            if (ci && cp == 0x17F) cs.add('s');   // LATIN SMALL LETTER LONG S folds to s
+            if (ci && cp == 0x212A) cs.add('k');  // KELVIN SIGN folds to k
+        }
+        if (ci) cs.fold_case();
+    }
 
     static void perl_class(CharSet &out, int kind) {
         CharSet t;
         switch (kind | 0x20) {
-        case 'd':
-            for (int c = '0'; c <= '9'; c++) t.add(c);
-            break;
+        case 'd': t.add_range('0', '9'); break;
         case 'w':
-            for (int c = '0'; c <= '9'; c++) t.add(c);
-            for (int c = 'a'; c <= 'z'; c++) t.add(c);
-            for (int c = 'A'; c <= 'Z'; c++) t.add(c);
+            t.add_range('0', '9');
+            t.add_range('a', 'z');
+            t.add_range('A', 'Z');
             t.add('_');
             break;
-        default:   // 's'
-            for (int c : {' ', '\t', '\n', '\r', '\f', '\v'}) t.add(c);
+        default:   // 's' (White_Space)
+            t.add_range('\t', '\r');
+            t.add(' ');
             break;
         }
-        if (kind >= 'A' && kind <= 'Z') t.negate();
+        if (kind >= 'A' && kind <= 'Z') {
+            t.negate();
+            t.other = true;
+        }
+        out.merge(t);
+    }
+
+    static std::string loose(const std::string &n) {
+        std::string o;
+        for (char ch : n)
+            if (ch != '_' && ch != '-' && ch != ' ') o += (char)(ch >= 'A' && ch <= 'Z' ? ch + 32 : ch);
+        return o;
+    }
+
+    static bool lookup_prop(const std::string &name, CharSet &t) {
+        const std::string n = loose(name);
+        for (const PropName &p : PROPS)
+            if (n == p.name) {
+                for (const char *m = p.members; m[0]; m += 2) t.add_range((unsigned char)m[0], (unsigned char)m[1]);
+                if (prop_has_nul(n)) t.add(0);
+                // every Unicode class except ASCII also has (or, for empty ASCII parts, only has) members beyond ASCII
+                t.other = n != "ascii" && n != "asciihexdigit" && n != "ahex";
+                return true;
+            }
+        return false;
+    }
+
+    // after "\p" or "\P"
+    void unicode_class(CharSet &out, bool negated) {
+        std::string name;
+        if (peek() == '{') {
+            pos_++;
+            while (more() && peek() != '}') name += (char)take();
+            if (!more()) throw ParseError("unclosed Unicode class");
+            pos_++;
+        } else {
+            if (!more()) throw ParseError("incomplete Unicode class");
+            name = std::string(1, (char)take());
+        }
+        if (!name.empty() && name[0] == '^') {
+            negated = !negated;
+            name.erase(0, 1);
+        }
+        size_t eq = name.find_first_of("=:");
+        if (eq != std::string::npos) {
+            bool ne = eq > 0 && name[eq - 1] == '!';
+            std::string key = loose(name.substr(0, ne ? eq - 1 : eq));
+            if (key != "gc" && key != "generalcategory" && key != "sc" && key != "script" && key != "scx" && key != "scriptextensions")
+                throw ParseError("unsupported Unicode property");
+            if (ne) negated = !negated;
+            name = name.substr(eq + 1);
+        }
+        CharSet t;
+        if (!lookup_prop(name, t)) throw ParseError("unsupported Unicode class name");
+        if (negated) t.negate();
         out.merge(t);
     }
 
@@ -103,182 +311,331 @@ class Parser {
         return -1;
     }
 
-    // after the backslash; returns a literal byte, or -2 after merging a perl class into cls
-    int escape(CharSet &cls) {
+    int hex_escape(int digits) {
+        int v = 0;
+        if (peek() == '{') {
+            pos_++;
+            int n = 0;
+            while (more() && peek() != '}') {
+                int h = hexval(take());
+                if (h < 0 || ++n > 8) throw ParseError("bad hexadecimal escape");
+                v = v * 16 + h;
+            }
+            if (!more() || n == 0) throw ParseError("bad hexadecimal escape");
+            pos_++;
+        } else {
+            for (int k = 0; k < digits; k++) {
+                int h = hexval(peek());
+                if (h < 0) throw ParseError("bad hexadecimal escape");
+                pos_++;
+                v = v * 16 + h;
+            }
+        }
+        if (v > 0x10FFFF || (v >= 0xD800 && v <= 0xDFFF)) throw ParseError("escape is not a Unicode scalar value");
+        return v;
+    }
+
+    // After the backslash.  Returns a scalar value, or -2 after merging a class (\d \pL ...) into cls.
+    int escape(CharSet &cls, const Flags &f) {
         if (!more()) throw ParseError("trailing backslash");
-        int c = take();
+        int c = take_scalar();
         switch (c) {
         case 'd': case 'D': case 'w': case 'W': case 's': case 'S':
             perl_class(cls, c);
+            return -2;
+        case 'p': case 'P':
+            unicode_class(cls, c == 'P');
             return -2;
         case 'n': return '\n';
         case 't': return '\t';
         case 'r': return '\r';
         case 'f': return '\f';
         case 'v': return '\v';
-        case 'x': {
-            int h1 = hexval(peek(0)), h2 = h1 >= 0 ? hexval(peek(1)) : -1;
-            if (h1 < 0 || h2 < 0) throw ParseError("bad \\x escape");
-            pos_ += 2;
-            if (h1 * 16 + h2 > 127) throw ParseError("non-ASCII escape unsupported");
-            return h1 * 16 + h2;
-        }
+        case 'a': return 7;
+        case 'x': return hex_escape(2);
+        case 'u': return hex_escape(4);
+        case 'U': return hex_escape(8);
+        case ' ':
+            if (f.x) return ' ';
+            throw ParseError("unrecognized escape sequence");
         default:
-            if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9'))
-                throw ParseError("unsupported escape sequence");
-            if (c > 127) throw ParseError("non-ASCII pattern unsupported");
-            return c;
+            if (c >= 128 || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9'))
+                throw ParseError("unrecognized escape sequence");
+            return c;   // escaped punctuation
         }
     }
 
-    NodeP char_class() {
-        CharSet cs;
+    // "[:name:]" / "[:^name:]" at pos_ (just after the '[' of the item)?  Merges it and returns true.
+    bool posix_class(CharSet &cs) {
+        if (peek() != ':') return false;
+        size_t end = s_.find(":]", pos_ + 1);
+        if (end == std::string::npos) return false;
+        std::string name = s_.substr(pos_ + 1, end - pos_ - 1);
+        bool neg = !name.empty() && name[0] == '^';
+        if (neg) name.erase(0, 1);
+        CharSet t;
+        if (name == "alnum") { t.add_range('0', '9'); t.add_range('A', 'Z'); t.add_range('a', 'z'); }
+        else if (name == "alpha") { t.add_range('A', 'Z'); t.add_range('a', 'z'); }
+        else if (name == "ascii") t.add_range(0, 127);
+        else if (name == "blank") { t.add(' '); t.add('\t'); }
+        else if (name == "cntrl") { t.add_range(0, 31); t.add(127); }
+        else if (name == "digit") t.add_range('0', '9');
+        else if (name == "graph") t.add_range('!', '~');
+        else if (name == "lower") t.add_range('a', 'z');
+        else if (name == "print") t.add_range(' ', '~');
+        else if (name == "punct") { t.add_range('!', '/'); t.add_range(':', '@'); t.add_range('[', '`'); t.add_range('{', '~'); }
+        else if (name == "space") { t.add_range('\t', '\r'); t.add(' '); }
+        else if (name == "upper") t.add_range('A', 'Z');
+        else if (name == "word") { t.add_range('0', '9'); t.add_range('A', 'Z'); t.add_range('a', 'z'); t.add('_'); }
+        else if (name == "xdigit") { t.add_range('0', '9'); t.add_range('A', 'F'); t.add_range('a', 'f'); }
+        else return false;   // not a POSIX class: an ordinary nested class starting with ':'
+        if (neg) {
+            t.negate();
+            t.other = true;
+        }
+        cs.merge(t);
+        pos_ = end + 2;
+        return true;
+    }
+
+    // Bracketed class; pos_ is just after '['.  Precedence (regex-syntax): ranges, then union, then && -- ~~ left to
+    // right, then negation.  Case folding applies to both operands of a set operator and to every bracketed
+    // class before its negation, as the crate's translator does.
+    CharSet char_class(const Flags &f) {
+        if (++depth_ > 64) throw ParseError("class nesting too deep");
         bool neg = false;
+        skip_space(f);
         if (peek() == '^') {
             neg = true;
             pos_++;
         }
-        bool first = true;
+        CharSet acc, cur;
+        int pending = 0;   // 0 none, '&' '-' '~'
+        bool have_acc = false, first = true;
+        auto combine = [&]() {
+            if (f.i) cur.fold_case();
+            if (!have_acc) {
+                acc = cur;
+                have_acc = true;
+            } else {
+                if (f.i) acc.fold_case();
+                if (pending == '&') acc.intersect(cur);
+                else if (pending == '-') acc.subtract(cur);
+                else acc.symdiff(cur);
+            }
+            cur = CharSet();
+        };
         for (;;) {
+            skip_space(f);
             if (!more()) throw ParseError("unclosed character class");
             int c = peek();
             if (c == ']' && !first) {
                 pos_++;
                 break;
             }
+            if (!first && (looking_at("&&") || looking_at("--") || looking_at("~~"))) {
+                combine();
+                pending = c;
+                pos_ += 2;
+                continue;
+            }
             first = false;
-            if (c == '[') throw ParseError("nested/POSIX character classes unsupported");
-            if (c == '&' && peek(1) == '&') throw ParseError("class set operations unsupported");
-            pos_++;
+            if (c == '[') {
+                pos_++;
+                if (posix_class(cur)) continue;
+                cur.merge(char_class(f));
+                continue;
+            }
             int lo;
             if (c == '\\') {
-                lo = escape(cs);
+                pos_++;
+                lo = escape(cur, f);
                 if (lo == -2) continue;
             } else {
-                if (c > 127) throw ParseError("non-ASCII pattern unsupported");
-                lo = c;
+                lo = take_scalar();
             }
             int hi = lo;
-            if (peek() == '-' && peek(1) != -1 && peek(1) != ']') {
+            skip_space(f);
+            if (peek() == '-' && peek(1) != -1 && peek(1) != ']' && !looking_at("--")) {
                 pos_++;
-                int d = take();
-                if (d == '\\') {
+                skip_space(f);
+                if (peek() == '\\') {
+                    pos_++;
                     CharSet dummy;
-                    hi = escape(dummy);
-                    if (hi < 0) throw ParseError("bad class range");
+                    hi = escape(dummy, f);
+                    if (hi < 0) throw ParseError("invalid class range");
+                } else if (peek() == '[') {
+                    throw ParseError("invalid class range");
                 } else {
-                    if (d > 127) throw ParseError("non-ASCII pattern unsupported");
-                    hi = d;
+                    hi = take_scalar();
                 }
                 if (hi < lo) throw ParseError("invalid class range");
             }
-            for (int k = lo; k <= hi; k++) cs.add(k);
+            if (lo < 128) cur.add_range(lo, std::min(hi, 127));
+            if (hi >= 128) {
+                cur.other = true;
+                if (f.i && lo <= 0x17F && hi >= 0x17F) cur.add('s');
+                if (f.i && lo <= 0x212A && hi >= 0x212A) cur.add('k');
+            }
         }
-        if (ci_) cs.fold_case();
-        if (neg) cs.negate();
-        NodeP n = mk(Node::SET);
-        n->set = cs;
-        return n;
+        combine();
+        if (f.i) acc.fold_case();
+        if (neg) acc.negate();
+        depth_--;
+        return acc;
     }
 
-    int integer() {
+    int integer(const Flags &f) {
+        skip_space(f);
         if (peek() < '0' || peek() > '9') return -1;
         long v = 0;
         while (peek() >= '0' && peek() <= '9') {
             v = v * 10 + (take() - '0');
             if (v > 1000) throw ParseError("repetition count too large");
         }
+        skip_space(f);
         return (int)v;
     }
 
-    NodeP atom() {
+    static NodeP set_node(const CharSet &cs) {
+        NodeP n = mk(Node::SET);
+        n->set = cs;
+        return n;
+    }
+    static NodeP assert_node(Assert a) {
+        NodeP n = mk(Node::ASSERT);
+        n->as = a;
+        return n;
+    }
+
+    // "(?flags)" / "(?flags:" — pos_ is after "(?"; applies the flags to f.  Returns true for the directive form,
+    // false after consuming the ':' of a scoped group.
+    bool flag_group(Flags &f) {
+        bool on = true, any = false, any_neg = false;
+        Flags nf = f;
+        while (more() && peek() != ':' && peek() != ')') {
+            int c = take();
+            switch (c) {
+            case '-':
+                if (!on) throw ParseError("repeated negation in flag group");
+                on = false;
+                continue;
+            case 'i': nf.i = on; break;
+            case 'm': nf.m = on; break;
+            case 's': nf.s = on; break;
+            case 'x': nf.x = on; break;
+            case 'U': nf.U = on; break;
+            case 'u': break;   // Unicode mode: no difference on ASCII haystacks
+            case 'R': throw ParseError("CRLF mode (flag R) unsupported");
+            default: throw ParseError("unrecognized flag");
+            }
+            any = true;
+            if (!on) any_neg = true;
+        }
+        if (!more()) throw ParseError("unclosed group");
+        if (!on && !any_neg) throw ParseError("dangling flag negation");
+        if (peek() == ')') {
+            if (!any) throw ParseError("empty flag group");
+            pos_++;
+            f = nf;
+            return true;
+        }
+        pos_++;   // ':'
+        f = nf;
+        return false;
+    }
+
+    NodeP atom(Flags &f) {
         int c = peek();
         if (c == '(') {
             pos_++;
-            bool saved = ci_;
+            if (++depth_ > 250) throw ParseError("group nesting too deep");
+            Flags inner = f;
             if (peek() == '?') {
                 pos_++;
-                if ((peek() == 'P' && peek(1) == '<') || peek() == '<') {
-                    while (more() && peek() != '>') pos_++;
-                    if (!more()) throw ParseError("unclosed group name");
+                if ((peek() == 'P' && peek(1) == '<') || (peek() == '<' && peek(1) != '=' && peek(1) != '!')) {
+                    if (peek() == 'P') pos_++;
                     pos_++;
+                    size_t start = pos_;
+                    while (more() && peek() != '>') pos_++;
+                    if (!more() || pos_ == start) throw ParseError("bad group name");
+                    pos_++;
+                } else if (peek() == '=' || peek() == '!' || peek() == '<') {
+                    throw ParseError("look-around is not supported");   // nor by the regex crate
                 } else {
-                    bool on = true, newci = ci_, any = false;
-                    while (more() && peek() != ':' && peek() != ')') {
-                        int f = take();
-                        if (f == '-') on = false;
-                        else if (f == 'i') newci = on;
-                        else throw ParseError("unsupported inline flag");
-                        any = true;
-                    }
-                    if (peek() == ')') {
-                        if (!any) throw ParseError("empty flag group");
-                        pos_++;
-                        ci_ = newci;   // until the end of the enclosing group
+                    Flags nf = f;
+                    if (flag_group(nf)) {   // "(?flags)": changes the enclosing group's flags from here on
+                        f = nf;
+                        depth_--;
                         return mk(Node::EMPTY);
                     }
-                    if (peek() != ':') throw ParseError("unclosed group");
-                    pos_++;
-                    ci_ = newci;
+                    inner = nf;             // "(?flags:...)": for this group only
                 }
             }
-            NodeP inner = alternation();
+            NodeP n = alternation(inner);
             if (peek() != ')') throw ParseError("unclosed group");
             pos_++;
-            ci_ = saved;
-            return inner;
+            depth_--;
+            return n;
         }
         if (c == '[') {
             pos_++;
-            return char_class();
+            return set_node(char_class(f));
         }
         if (c == '.') {
             pos_++;
-            NodeP n = mk(Node::SET);
-            n->set.negate();   // everything ...
-            n->set.bits[0] &= ~(1ull << '\n');   // ... except newline
-            return n;
+            CharSet cs;
+            cs.negate();
+            if (!f.s) cs.bits[0] &= ~(1ull << '\n');
+            return set_node(cs);
         }
         if (c == '^') {
             pos_++;
-            return mk(Node::BOL);
+            return assert_node(f.m ? A_LINE_START : A_TEXT_START);
         }
         if (c == '$') {
             pos_++;
-            return mk(Node::EOL);
+            return assert_node(f.m ? A_LINE_END : A_TEXT_END);
         }
         if (c == '\\') {
             pos_++;
             int e = peek();
-            if (e == 'A') {
+            if (e == 'A') { pos_++; return assert_node(A_TEXT_START); }
+            if (e == 'z') { pos_++; return assert_node(A_TEXT_END); }
+            if (e == 'B') { pos_++; return assert_node(A_NOT_WORD); }
+            if (e == '<') { pos_++; return assert_node(A_WORD_START); }
+            if (e == '>') { pos_++; return assert_node(A_WORD_END); }
+            if (e == 'b') {
                 pos_++;
-                return mk(Node::BOL);
+                if (peek() == '{') {
+                    // \b{start} etc.; anything else after \b is an ordinary (invalid here) repetition of \b
+                    static const struct { const char *lit; Assert a; } forms[] = {
+                        {"{start}", A_WORD_START}, {"{end}", A_WORD_END}, {"{start-half}", A_WORD_START_HALF}, {"{end-half}", A_WORD_END_HALF}};
+                    for (auto &fm : forms)
+                        if (looking_at(fm.lit)) {
+                            pos_ += strlen(fm.lit);
+                            return assert_node(fm.a);
+                        }
+                }
+                return assert_node(A_WORD);
             }
-            if (e == 'z') {
-                pos_++;
-                return mk(Node::EOL);
-            }
-            if (e == 'b' || e == 'B' || e == 'p' || e == 'P') throw ParseError("unsupported escape (\\b, \\B, \\p)");
             CharSet cs;
-            int lit = escape(cs);
-            if (lit >= 0) cs.add(lit);
-            if (ci_) cs.fold_case();
-            NodeP n = mk(Node::SET);
-            n->set = cs;
-            return n;
+            int lit = escape(cs, f);
+            if (lit >= 0) add_scalar(cs, lit, f.i);
+            else if (f.i) cs.fold_case();
+            return set_node(cs);
         }
         if (c == '*' || c == '+' || c == '?') throw ParseError("repetition operator missing expression");
-        if (c > 127) throw ParseError("non-ASCII pattern unsupported");
-        pos_++;
-        NodeP n = mk(Node::SET);
-        n->set.add(c);
-        if (ci_) n->set.fold_case();
-        return n;
+        if (c == '{') throw ParseError("repetition operator missing expression");
+        CharSet cs;
+        add_scalar(cs, take_scalar(), f.i);
+        return set_node(cs);
     }
 
-    NodeP repeat() {
-        NodeP a = atom();
+    NodeP repeat(Flags &f) {
+        NodeP a = atom(f);
         for (;;) {
+            skip_space(f);
             int c = peek();
             if (c == '*' || c == '+' || c == '?') {
                 pos_++;
@@ -286,14 +643,15 @@ class Parser {
                 if (peek() == '?') pos_++;   // lazy marker: irrelevant for is_match
             } else if (c == '{') {
                 pos_++;
-                int lo = integer();
+                int lo = integer(f);
                 if (lo < 0) throw ParseError("invalid repetition");
                 int hi = lo;
                 if (peek() == ',') {
                     pos_++;
+                    skip_space(f);
                     if (peek() == '}') hi = -1;
                     else {
-                        hi = integer();
+                        hi = integer(f);
                         if (hi < 0) throw ParseError("invalid repetition");
                     }
                 }
@@ -311,17 +669,23 @@ class Parser {
         return a;
     }
 
-    NodeP concat() {
+    NodeP concat(Flags &f) {
         NodeP res = mk(Node::EMPTY);
-        while (more() && peek() != '|' && peek() != ')') res = mk(Node::CAT, res, repeat());
+        for (;;) {
+            skip_space(f);
+            if (!more() || peek() == '|' || peek() == ')') break;
+            res = mk(Node::CAT, res, repeat(f));
+        }
         return res;
     }
 
-    NodeP alternation() {
-        NodeP left = concat();
+    // `f` is the flag state of the enclosing group: a "(?i)" directive changes it for everything that follows in
+    // that group, across '|' as well (regex-syntax keeps one flag state per group).
+    NodeP alternation(Flags &f) {
+        NodeP left = concat(f);
         while (peek() == '|') {
             pos_++;
-            left = mk(Node::ALT, left, concat());
+            left = mk(Node::ALT, left, concat(f));
         }
         return left;
     }
@@ -330,8 +694,9 @@ class Parser {
 // ---- NFA -------------------------------------------------------------------------------------------------
 
 struct NState {
-    enum Type { CHAR, SPLIT, BOL, EOL, MATCH } type;
+    enum Type { CHAR, SPLIT, ASSERT, MATCH } type;
     CharSet set;
+    Assert as = A_TEXT_START;
     int a = -1, b = -1;
 };
 
@@ -378,10 +743,11 @@ struct Nfa {
             int body = emit(n->a, next);
             return add(NState::SPLIT, body, next);
         }
-        case Node::BOL:
-            return add(NState::BOL, next);
-        case Node::EOL:
-            return add(NState::EOL, next);
+        case Node::ASSERT: {
+            int s = add(NState::ASSERT, next);
+            st[s].as = n->as;
+            return s;
+        }
         case Node::REPEAT: {
             int cur = next;
             if (n->hi < 0) {
@@ -401,9 +767,10 @@ struct Nfa {
     }
 };
 
-// epsilon closure of `seeds`; BOL edges are followed only when at_start, EOL edges only when at_end.
-// Result: sorted list of CHAR / MATCH / (pending) EOL states.
-void closure(const Nfa &nfa, const std::vector<int> &seeds, bool at_start, bool at_end, std::vector<int> &out,
+// Epsilon closure of `seeds` at a position whose previous symbol has kind `prev` and whose next symbol has kind
+// `next` (K_UNKNOWN: not looked at yet — assertions that need it stay in the result as pending states).
+// Result: sorted list of CHAR / MATCH / pending ASSERT states.
+void closure(const Nfa &nfa, const std::vector<int> &seeds, Kind prev, Kind next, std::vector<int> &out,
              std::vector<uint32_t> &mark, uint32_t &epoch) {
     epoch++;
     out.clear();
@@ -419,12 +786,9 @@ void closure(const Nfa &nfa, const std::vector<int> &seeds, bool at_start, bool 
             stack.push_back(n.b);
             stack.push_back(n.a);
             break;
-        case NState::BOL:
-            if (at_start) stack.push_back(n.a);
-            break;
-        case NState::EOL:
-            if (at_end) stack.push_back(n.a);
-            else out.push_back(s);
+        case NState::ASSERT:
+            if (next == K_UNKNOWN && needs_next(n.as)) out.push_back(s);
+            else if (assert_holds(n.as, prev, next)) stack.push_back(n.a);
             break;
         default:
             out.push_back(s);
@@ -456,19 +820,26 @@ bool regex_compile(const std::string &pattern, bool case_insensitive, Dfa &out, 
         Nfa nfa;
         int match = nfa.add(NState::MATCH);
         int start = nfa.emit(ast, match);
+        bool any_assert = false;
+        for (auto &s : nfa.st) any_assert = any_assert || s.type == NState::ASSERT;
 
-        // symbol classes: bytes with identical membership in every CHAR set
+        // symbol classes: bytes with identical membership in every CHAR set and of the same kind (newline / word /
+        // other — the kinds only matter when the pattern has assertions)
         std::vector<const CharSet *> sets;
         for (auto &s : nfa.st)
             if (s.type == NState::CHAR) sets.push_back(&s.set);
         std::map<std::vector<bool>, uint8_t> sig2cls;
         std::vector<int> cls_rep;   // representative byte per class
         for (int c = 0; c <= 128; c++) {
-            std::vector<bool> sig(sets.size());
+            std::vector<bool> sig(sets.size() + 2);
             for (size_t i = 0; i < sets.size(); i++) sig[i] = sets[i]->has(c);
+            const Kind k = kind_of(c);
+            sig[sets.size()] = any_assert && k == K_NEWLINE;
+            sig[sets.size() + 1] = any_assert && k == K_WORD;
             auto it = sig2cls.find(sig);
             uint8_t id;
             if (it == sig2cls.end()) {
+                if (sig2cls.size() >= 255) throw ParseError("pattern needs too many symbol classes");
                 id = (uint8_t)sig2cls.size();
                 sig2cls[sig] = id;
                 cls_rep.push_back(c);
@@ -479,56 +850,106 @@ bool regex_compile(const std::string &pattern, bool case_insensitive, Dfa &out, 
             else
                 for (int b = 128; b < 256; b++) out.cls[b] = id;
         }
-        out.n_cls = (uint32_t)cls_rep.size();
+        const uint32_t n_cls = (uint32_t)cls_rep.size();
 
+        // Subset construction.  A DFA state is (NFA states with their look-behind assertions already resolved and the
+        // look-ahead ones pending, kind of the previous symbol); the kind is dropped (K_OTHER) when the pattern has no
+        // assertion at all.  State 0 is the start of the haystack.
         std::vector<uint32_t> mark(nfa.st.size(), 0);
         uint32_t epoch = 0;
-        std::map<std::vector<int>, uint32_t> ids;
-        std::vector<std::vector<int>> states;
-        std::vector<int> tmp, tmp2;
+        std::map<std::pair<std::vector<int>, int>, uint32_t> ids;
+        std::vector<std::pair<std::vector<int>, int>> states;
+        std::vector<int> tmp, resolved;
 
-        auto intern = [&](const std::vector<int> &set) -> uint32_t {
-            auto it = ids.find(set);
+        auto intern = [&](const std::vector<int> &set, Kind prev) -> uint32_t {
+            auto key = std::make_pair(set, any_assert ? (int)prev : (int)K_OTHER);
+            auto it = ids.find(key);
             if (it != ids.end()) return it->second;
             if (states.size() >= 20000) throw ParseError("pattern needs too many DFA states");
             uint32_t id = (uint32_t)states.size();
-            ids[set] = id;
-            states.push_back(set);
+            ids[key] = id;
+            states.push_back(key);
             return id;
         };
 
-        // state 0 is the start-of-haystack state; the -1 sentinel keeps it distinct from a later state
-        // with the same NFA set (which differs in that '^' can no longer hold)
-        closure(nfa, {start}, true, false, tmp, mark, epoch);
-        tmp.insert(tmp.begin(), -1);
-        intern(tmp);
-        out.trans.clear();
-        out.match_now.clear();
-        out.match_at_end.clear();
+        closure(nfa, {start}, K_EDGE, K_UNKNOWN, tmp, mark, epoch);
+        {
+            // the start state keeps K_EDGE even without assertions in the pattern: nothing depends on it then
+            auto key = std::make_pair(tmp, (int)K_EDGE);
+            ids[key] = 0;
+            states.push_back(key);
+        }
+        std::vector<uint32_t> trans;
+        std::vector<uint8_t> match_now, match_at_end;
         for (uint32_t si = 0; si < states.size(); si++) {
-            const std::vector<int> cur = states[si];
-            bool now = std::binary_search(cur.begin(), cur.end(), match);
-            // end-of-haystack acceptance: follow pending EOL edges (and BOL when nothing was consumed,
-            // i.e. only from the start state)
-            closure(nfa, cur, si == 0, true, tmp2, mark, epoch);
-            bool at_end = std::binary_search(tmp2.begin(), tmp2.end(), match);
-            out.match_now.push_back(now);
-            out.match_at_end.push_back(at_end);
-            out.trans.resize((size_t)(si + 1) * out.n_cls);
-            for (uint32_t c = 0; c < out.n_cls; c++) {
+            const std::vector<int> cur = states[si].first;
+            const Kind prev = si == 0 ? K_EDGE : (Kind)states[si].second;
+            const bool now = std::binary_search(cur.begin(), cur.end(), match);
+            // end of the haystack: the pending assertions see K_EDGE as the next symbol
+            closure(nfa, cur, prev, K_EDGE, resolved, mark, epoch);
+            match_now.push_back(now);
+            match_at_end.push_back(std::binary_search(resolved.begin(), resolved.end(), match));
+            trans.resize((size_t)(si + 1) * n_cls);
+            for (uint32_t c = 0; c < n_cls; c++) {
+                if (now) {
+                    trans[(size_t)si * n_cls + c] = si;   // absorbing
+                    continue;
+                }
+                const int rep = cls_rep[c];
+                const Kind nk = kind_of(rep);
+                // resolve what was waiting for this symbol, then step over it
+                closure(nfa, cur, prev, nk, resolved, mark, epoch);
+                if (std::binary_search(resolved.begin(), resolved.end(), match)) {
+                    // matched just before this symbol: go to an absorbing match state
+                    std::vector<int> m{match};
+                    trans[(size_t)si * n_cls + c] = intern(m, K_OTHER);
+                    continue;
+                }
                 std::vector<int> seeds;
-                int rep = cls_rep[c];
-                for (int s : cur) {
-                    if (s < 0) continue;
+                for (int s : resolved) {
                     const NState &n = nfa.st[s];
                     if (n.type == NState::CHAR && n.set.has(rep)) seeds.push_back(n.a);
                 }
                 seeds.push_back(start);   // unanchored search: a new attempt may begin at every offset
-                closure(nfa, seeds, false, false, tmp, mark, epoch);
-                out.trans[(size_t)si * out.n_cls + c] = now ? si : intern(tmp);
+                closure(nfa, seeds, nk, K_UNKNOWN, tmp, mark, epoch);
+                trans[(size_t)si * n_cls + c] = intern(tmp, nk);
             }
         }
-        out.n_states = (uint32_t)states.size();
+        uint32_t n_states = (uint32_t)states.size();
+
+        // Minimisation (Moore): states that accept the same continuations merge — among them the copies that differ
+        // only in a previous-symbol kind no pending assertion looks at.  Block of state 0 stays number 0.
+        std::vector<uint32_t> block(n_states);
+        for (uint32_t s = 0; s < n_states; s++) block[s] = (match_now[s] ? 1u : 0u) | (match_at_end[s] ? 2u : 0u);
+        uint32_t n_blocks = 0;
+        for (;;) {
+            std::map<std::vector<uint32_t>, uint32_t> sig_ids;
+            std::vector<uint32_t> nb(n_states);
+            std::vector<uint32_t> sig(n_cls + 1);
+            for (uint32_t s = 0; s < n_states; s++) {
+                sig[0] = block[s];
+                for (uint32_t c = 0; c < n_cls; c++) sig[c + 1] = block[trans[(size_t)s * n_cls + c]];
+                auto it = sig_ids.find(sig);
+                if (it == sig_ids.end()) it = sig_ids.emplace(sig, (uint32_t)sig_ids.size()).first;
+                nb[s] = it->second;
+            }
+            const bool stable = sig_ids.size() == n_blocks;
+            n_blocks = (uint32_t)sig_ids.size();
+            block = nb;
+            if (stable) break;
+        }
+        // state 0 was the first to get a signature id in every round, so block[0] == 0
+        out.n_cls = n_cls;
+        out.n_states = n_blocks;
+        out.trans.assign((size_t)n_blocks * n_cls, 0);
+        out.match_now.assign(n_blocks, 0);
+        out.match_at_end.assign(n_blocks, 0);
+        for (uint32_t s = 0; s < n_states; s++) {
+            const uint32_t b = block[s];
+            out.match_now[b] = match_now[s];
+            out.match_at_end[b] = match_at_end[s];
+            for (uint32_t c = 0; c < n_cls; c++) out.trans[(size_t)b * n_cls + c] = block[trans[(size_t)s * n_cls + c]];
+        }
 
         // dead states: cannot reach a state with match_now or match_at_end (reverse reachability)
         std::vector<uint8_t> live(out.n_states, 0);

@@ -77,10 +77,14 @@ StreamCache &stream_cache() {
     return *sc;
 }
 
-// Idle cached streams are destroyed when the process exits: registered with atexit() at the first stream
-// creation, i.e. after the HIP runtime registered its own teardown, so this runs before it.  (Nothing is created
-// afterwards, which is the only sequence that was seen to block; leaving the queues to the runtime's teardown
-// made rocprofv3 crash in its exit handlers.)
+// The cached streams are normally left to the HIP runtime's own teardown when the process exits.  Destroying
+// them ourselves is not safe on this runtime (ROCm 7.2): hipStreamDestroy of a CU-masked stream deletes its
+// hardware queue, and that was seen to block forever ("Deleting hardware queue ...") when another process held
+// queues on the same device (tools/cli_hang_probe.py), as creating a stream after such a deletion was
+// (tools/topo_sweep.py, second context of a process).  The one case where leaving them is worse is a run under
+// rocprofv3, whose exit handlers crash on queues that outlive it (after it has written its output): with
+// VGEN_DESTROY_STREAMS_AT_EXIT=1 the idle streams are destroyed by an atexit() handler registered at the first
+// stream creation — i.e. after the HIP runtime registered its own teardown, so it runs before it.
 void destroy_idle_streams() {
     StreamCache &sc = stream_cache();
     std::lock_guard<std::mutex> g(sc.mu);
@@ -105,7 +109,10 @@ int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStr
             }
             if (!pool[i]) {
                 static std::once_flag once;
-                std::call_once(once, []() { atexit(destroy_idle_streams); });
+                std::call_once(once, []() {
+                    const char *v = getenv("VGEN_DESTROY_STREAMS_AT_EXIT");
+                    if (v && *v == '1') atexit(destroy_idle_streams);
+                });
                 std::vector<uint32_t> mask((c->cu_count + 31) / 32, 0xFFFFFFFFu);
                 HIP_TRY(c, hipExtStreamCreateWithCUMask(&pool[i], (uint32_t)mask.size(), mask.data()));
             }
@@ -144,9 +151,11 @@ int upload(vgen_ctx *c, void *dst, const void *src, size_t bytes) {
 // hardware queue of its own (profiles/r02_topology_sweep.txt): per-frame streams win at every frame count; the
 // stage layouts only pay when queues are scarce (VGEN_STREAM_KIND=plain with the default GPU_MAX_HW_QUEUES=4:
 // "2,2" reaches 10.8 Gkeys/s where 16 per-frame streams on 4 shared queues reach 9.7).
-// VGEN_FUSED_INV: root inversions in seq_fwd's tail (1) or as a seq_inv_kernel launch (0); default by frame
-// count — the fused tail shortens a dispatch's chain (+16 % at 4 frames, +7 % at 8), the separate launch keeps
-// seq_fwd at 64 VGPRs, which packs better beside seq_bwd waves once many frames overlap (+3 % at 16-20).
+// VGEN_FUSED_INV=1: the root inversions ride in seq_fwd's tail (last-arriver pattern, kernels.hip) instead of a
+// seq_inv_kernel launch.  Off by default: it saves a launch, but the tail needs ~128 VGPRs where seq_fwd alone
+// needs 64, which packs worse beside seq_bwd waves once many frames overlap (11.4 vs 11.8 Gkeys/s at 16 frames,
+// 11.5 vs 12.0 at 20), and at 1-8 frames the two forms measure within run-to-run noise of each other
+// (profiles/r02_topology_sweep.txt, profiles/r02_fused_inv_ab.txt).
 void parse_topology(vgen_ctx *c) {
     const char *v = getenv("VGEN_STREAMS");
     c->per_frame_streams = true;
@@ -162,7 +171,7 @@ void parse_topology(vgen_ctx *c) {
     }
     const char *k = getenv("VGEN_STREAM_KIND");   // "plain": ordinary streams from the runtime's shared queue pool
     if (k && !strcmp(k, "plain")) c->own_queues = false;
-    c->fused_inv = c->frames <= 8;
+    c->fused_inv = false;
     const char *fi = getenv("VGEN_FUSED_INV");
     if (fi && (*fi == '0' || *fi == '1')) c->fused_inv = *fi == '1';
     c->hw_queues = env_u32("GPU_MAX_HW_QUEUES", 4);

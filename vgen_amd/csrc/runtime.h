@@ -63,7 +63,7 @@ struct vgen_ctx {
     // topology, one private stream per frame for both halves (needs GPU_MAX_HW_QUEUES >= frames to overlap)
     uint32_t n_fwd = 0, n_bwd = 0;
     bool per_frame_streams = true;
-    bool fused_inv = true;                       // root inversions in seq_fwd's tail (else a seq_inv_kernel launch)
+    bool fused_inv = false;                      // root inversions in seq_fwd's tail instead of a seq_inv_kernel launch
     std::vector<hipStream_t> fwd_streams, bwd_streams;
     bool own_queues = true;                      // streams with a hardware queue each (CU-masked, all CUs), see runtime.cpp
     uint32_t cu_count = 0;
