@@ -5,9 +5,9 @@ Metric (BASELINE.json): Mkeys/s = keys tested per second, whole job over all GPU
 Workload at N=1 (BASELINE configs[1]): P2PKH, pattern "^1Cat", 2^20 keys per dispatch, compressed public keys,
 sequential scalars k0(seed=42) + i, inputs resident on the device (the only per-dispatch upload is the 1-2 KB of
 base points in the kernel arguments).  A "step" is one dispatch of the hot path over 2^20 keys; `frames`
-dispatches are kept in flight the way the reference's scan loop keeps 2 (src/gpu.rs:399) — 20 here, every frame on
-a stream that owns a hardware queue (no GPU_MAX_HW_QUEUES involved), because one launch of the per-key kernel is
-only one wave per SIMD and a dispatch is a chain of dependent launches.
+dispatches are kept in flight the way the reference's scan loop keeps 2 (src/gpu.rs:399) — 12 here, every frame on
+a stream with a hardware queue of its own (three priority pools of four queues: no GPU_MAX_HW_QUEUES involved),
+because one launch of the per-key kernel is only one wave per SIMD and a dispatch is a chain of dependent launches.
 For N>1 (python -m torch.distributed.run ... bench.py --gpus N) every rank drives its own GPU over batch-striped
 disjoint scalar ranges — no data-path collective; torch.distributed only provides the barriers and the
 max-over-ranks of the elapsed time.
@@ -131,8 +131,9 @@ class Pipeline:
         self.next_step = first + n_steps
         return cand, kms
 
-    def run_seconds(self, seconds, min_steps=0):
+    def run_seconds(self, seconds, min_steps=0, clock=False):
         """Dispatches until `seconds` of wall time have passed (checked every `frames` completions), then drains.
+        clock: also sum the shader-clock samples of the dispatches (vgen_frame_clock) into self.clk_cycles / clk_ticks.
         -> (dispatches, elapsed seconds incl. fill and drain)"""
         r, F = self.r, self.f
         first = self.next_step
@@ -143,8 +144,13 @@ class Pipeline:
             issued += 1
         fw = 0
         stop = False
+        self.clk_cycles = self.clk_ticks = 0
         while done < issued:
             r.wait(fw)
+            if clock:
+                c, t = r.frame_clock(fw)
+                self.clk_cycles += c
+                self.clk_ticks += t
             done += 1
             if not stop and fw == F - 1:
                 stop = time.perf_counter() - t0 >= seconds and issued >= min_steps
@@ -241,7 +247,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1 << 20, help="keys per dispatch (BASELINE config: 2^20)")
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "20")),
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("VGEN_BENCH_FRAMES", "12")),
                     help="dispatches in flight per GPU")
     ap.add_argument("--format", default="p2pkh", choices=sorted(FORMATS))
     ap.add_argument("--pattern", default="^1Cat")
@@ -313,18 +319,13 @@ def main():
     keys = world * args.steps * N
     value = keys / elapsed / 1e6
 
-    # ---- the same loop for >= 3 s of wall time, with the shader-clock probe beside it ----
+    # ---- the same loop for >= 3 s of wall time ----
     sustained = None
     shader_mhz = None
     if args.sustained_seconds > 0:
-        probe_ms = int(min(2000.0, 0.5 * args.sustained_seconds * 1e3))
-        if os.environ.get("VGEN_BENCH_PROBE") == "0":
-            probe_ms = 0
         barrier()
-        if probe_ms >= 2:
-            runner.clock_probe_start(probe_ms)
         ts = time.perf_counter()
-        n_s, _ = pipe.run_seconds(args.sustained_seconds)
+        n_s, _ = pipe.run_seconds(args.sustained_seconds, clock=True)
         barrier()
         dt_s = max_over_ranks(time.perf_counter() - ts)
         if world > 1:   # every rank stops on its own clock: sum the dispatches
@@ -333,8 +334,8 @@ def main():
             n_total = int(t.item())
         else:
             n_total = n_s
-        if probe_ms >= 2:
-            shader_mhz = runner.clock_probe_read()
+        if pipe.clk_ticks:   # MHz the CUs ran at, sampled by the seq_bwd launches of this leg themselves
+            shader_mhz = pipe.clk_cycles / pipe.clk_ticks * 100.0
         sustained = {"value": round(n_total * N / dt_s / 1e6, 2), "unit": "Mkeys/sec", "seconds": round(dt_s, 3),
                      "dispatches": n_total, "frames_in_flight": F}
 

@@ -63,8 +63,9 @@ typedef struct vgen_params {
     uint32_t format;       /* vgen_format */
     uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 20 (64 with
                               VGEN_STREAMS=A,B).  One dispatch is one wave per SIMD, so throughput grows with the frames
-                              in flight: 8.9 / 10.6 / 11.8 / 12.0 Gkeys/s at 4 / 8 / 16 / 20 (P2PKH, 2^20 keys each); every
-                              frame's stream owns a hardware queue, independent of GPU_MAX_HW_QUEUES (vgen_get_topology) */
+                              in flight: 7.4 / 11.4 / 12.0 / 12.1 Gkeys/s at 2 / 4 / 8 / 12 (P2PKH, 2^20 keys each).  The
+                              first twelve frames get a hardware queue each (vgen_get_topology), whatever
+                              GPU_MAX_HW_QUEUES is; multiples of 4 balance the queue pools */
     uint32_t match_cap;    /* match records kept per dispatch in filter mode; 0 -> 4096 */
     uint32_t flags;        /* VGEN_FLAG_* */
 } vgen_params;
@@ -104,12 +105,13 @@ const char *vgen_last_error(const vgen_ctx *ctx);
 /* The batch size / frame count actually in use (after defaults). */
 int vgen_get_info(const vgen_ctx *ctx, uint32_t *batch_size, uint32_t *frames, uint32_t *match_cap);
 /* How the context reaches the device (the reference's wgpu queue, src/gpu.rs:116-131, has no counterpart to
- * tune).  Default layout: one stream per frame (*fwd_streams = 0, *bwd_streams = frames), each owning a
- * hardware queue.  With VGEN_STREAMS=A,B: the number of streams shared by the first halves of all dispatches
- * (denominators, product trees, root inversions) and by their second halves (per-key work, result copies).
- * *hw_queues: the limit the HIP runtime was started with (GPU_MAX_HW_QUEUES, default 4); it binds only
- * ordinary streams (VGEN_STREAM_KIND=plain), and *oversubscribed == 1 reports that such streams outnumber it —
- * then streams share queues, their kernels serialise and the throughput drops.  Any pointer may be NULL. */
+ * tune).  Default layout: one stream per frame (*fwd_streams = 0, *bwd_streams = frames).  The HIP runtime keeps
+ * one pool of GPU_MAX_HW_QUEUES (default 4, reported in *hw_queues) hardware queues per stream priority level, and
+ * the context spreads its streams over the three levels: up to 3 x *hw_queues streams own a queue each.
+ * *oversubscribed == 1 reports that the context has more streams than that (frames > 12 by default): the surplus
+ * streams share queues, which costs little (11.6 Gkeys/s on 4 queues against 12.1 on 12) but buys nothing.
+ * With VGEN_STREAMS=A,B the first halves of all dispatches (denominators, product trees, root inversions) share A
+ * streams and their second halves (per-key work, result copies) B streams.  Any pointer may be NULL. */
 int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_streams, uint32_t *hw_queues,
                       int32_t *oversubscribed);
 
@@ -146,8 +148,9 @@ int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 
 /* Starts a one-wave probe on its own stream that, for duration_ms, compares the shader-clock counter with
  * the constant 100 MHz counter; vgen_clock_probe_read waits for it and returns the clock (MHz) the CUs ran at
- * meanwhile — i.e. under whatever the frames were executing (bench.py reports it beside the roofline:
- * power management keeps the MI355X below its nominal 2400 MHz under this integer load). */
+ * meanwhile — i.e. under whatever the frames were executing.  The probe's stream takes a hardware queue from the
+ * normal-priority pool, which it may share with a frame and then holds up that frame's kernels: for measurements
+ * beside a saturated scan prefer vgen_frame_clock, which costs no queue. */
 int vgen_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
 int vgen_clock_probe_read(vgen_ctx *ctx, double *mhz);
 
@@ -179,6 +182,12 @@ int vgen_dump_view(vgen_ctx *ctx, uint32_t frame, const uint8_t **ptr, size_t *l
 int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms);
 /* Device time of the whole dispatch (seq_fwd incl. the root inversions + seq_bwd, incl. the gap between them). */
 int vgen_frame_dispatch_ms(vgen_ctx *ctx, uint32_t frame, float *ms);
+
+/* Shader-clock sample of the frame's last completed filter-mode dispatch: the first wave of its seq_bwd_kernel
+ * launch read the shader-clock counter and the constant 100 MHz counter when it started and when it ended;
+ * *cycles / *ticks_100mhz x 100 = the MHz the CUs ran at while that kernel executed (0 / 0 after a dump-mode or
+ * P2TR dispatch).  No extra launch, no extra queue: bench.py sums the samples of its sustained leg. */
+int vgen_frame_clock(vgen_ctx *ctx, uint32_t frame, uint32_t *cycles, uint32_t *ticks_100mhz);
 
 /* ---- host-side derivation (what the Rust host obtains from rust-bitcoin) ----------------------------- */
 

@@ -114,6 +114,7 @@ _L.vgen_read_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
 _L.vgen_dump_view.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
 _L.vgen_get_topology.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint32)] * 3 + [ctypes.POINTER(ctypes.c_int32)]
 _L.vgen_frame_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
+_L.vgen_frame_clock.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
 _L.vgen_frame_dispatch_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
 _L.vgen_address_from_payload.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_key_to_wif.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
@@ -383,6 +384,12 @@ class GpuRunner:
         ms = ctypes.c_float()
         _check(_L.vgen_frame_kernel_ms(self._h, frame, ctypes.byref(ms)), self._h)
         return ms.value
+
+    def frame_clock(self, frame: int):
+        """vgen_frame_clock: (shader-clock cycles, 100 MHz ticks) sampled by the frame's last seq_bwd launch."""
+        c, t = ctypes.c_uint32(), ctypes.c_uint32()
+        _check(_L.vgen_frame_clock(self._h, frame, ctypes.byref(c), ctypes.byref(t)), self._h)
+        return c.value, t.value
 
     def dispatch_ms(self, frame: int) -> float:
         """HIP-event duration of the whole last dispatch (seq_fwd incl. the root inversions + seq_bwd)."""

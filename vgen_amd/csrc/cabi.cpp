@@ -194,13 +194,21 @@ int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_
     if (fwd_streams) *fwd_streams = ctx->n_fwd;
     if (bwd_streams) *bwd_streams = ctx->n_bwd;
     if (hw_queues) *hw_queues = ctx->hw_queues;
-    if (oversubscribed) *oversubscribed = !ctx->own_queues && ctx->n_fwd + ctx->n_bwd > ctx->hw_queues ? 1 : 0;
+    if (oversubscribed) {
+        const uint32_t own = ctx->stream_kind == vg::STREAMS_CUMASK ? 1u << 30 : ctx->stream_kind == vg::STREAMS_PRIORITY ? 3 * ctx->hw_queues : ctx->hw_queues;
+        *oversubscribed = ctx->n_fwd + ctx->n_bwd > own ? 1 : 0;
+    }
     return VGEN_OK;
 }
 
 int vgen_frame_kernel_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {
     if (!ctx || !ms) return VGEN_E_INVALID;
     return vg::rt_frame_times(ctx, frame, ms, nullptr);
+}
+
+int vgen_frame_clock(vgen_ctx *ctx, uint32_t frame, uint32_t *cycles, uint32_t *ticks_100mhz) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_frame_clock(ctx, frame, cycles, ticks_100mhz);
 }
 
 int vgen_frame_dispatch_ms(vgen_ctx *ctx, uint32_t frame, float *ms) {

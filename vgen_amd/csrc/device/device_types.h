@@ -63,7 +63,8 @@ struct DevMatch {
 struct DevMatchHeader {
     uint32_t count;
     uint32_t cap;
-    uint32_t pad[2];
+    uint32_t clk_cycles;   // running sums (mod 2^32) over the frame's seq_bwd launches, first wave of each launch:
+    uint32_t clk_ticks;    // shader-clock cycles and 100 MHz ticks it ran for (kernels.hip: "shader-clock sample")
 };
 
 // Per-dispatch uniform points of the sequential kernel: Q_j = (k0 + N/2 - S/2 + j)*G and the
@@ -96,6 +97,7 @@ struct SeqArgs {
     const uint32_t *gtab;      // P2TR: 8-bit fixed-window generator table (global memory) for the tweak multiplication
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
+    uint32_t prio;             // seq_fwd: raise the waves' issue priority (set by launch_seq_fwd)
     // P2TR only: the tweaked points Q = P + t*G of a dispatch wait for a second shared inversion.
     uint32_t *tq;              // [2S key steps][27][lanes]: X(Q), Z(Q), running product of the lane's Z's
     uint32_t *tq_flag;         // [2S][lanes]: 1 = the key has an address (valid tweak, Q finite)

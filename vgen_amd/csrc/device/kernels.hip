@@ -40,9 +40,32 @@
 #include "device_types.h"
 #include "launch.h"
 
+#include <stdlib.h>
+
 namespace vg {
 
 constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
+
+// Scheduling knobs of the dispatch chain (host side, read once):
+//   VGEN_CHAIN_PRIO (default 1): the waves of the short, latency-bound first half of a dispatch (seq_fwd_kernel,
+//     seq_inv_kernel) raise their issue priority (s_setprio 3) over the seq_bwd waves of other frames they share
+//     a SIMD with — same instruction count, but the chain of the NEXT dispatch is not slowed to a quarter of its
+//     speed by the arbiter's round robin.
+//   VGEN_BWD_LDS_PAD (bytes, default 0): extra dynamic LDS per seq_bwd workgroup; 40960 caps the kernel at three
+//     workgroups per CU (3 waves per SIMD, 384 of 512 VGPRs), leaving register room for first-half waves of
+//     other frames to start without waiting for a seq_bwd wave to retire.
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+static int chain_prio() {
+    static const int v = env_int("VGEN_CHAIN_PRIO", 1);
+    return v;
+}
+static unsigned bwd_lds_pad() {
+    static const int v = env_int("VGEN_BWD_LDS_PAD", 0);
+    return v > 0 && v <= 48 * 1024 ? (unsigned)v & ~255u : 0u;
+}
 
 #ifndef VG_FWD_TAIL_WAVES
 #define VG_FWD_TAIL_WAVES 4
@@ -191,6 +214,7 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
 template <bool INV_TAIL>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(INV_TAIL ? VG_FWD_TAIL_WAVES : 1, INV_TAIL ? VG_FWD_TAIL_WAVES : 8)))
 seq_fwd_kernel(const SeqArgs args) {
+    if (args.prio) __builtin_amdgcn_s_setprio(3);
     __shared__ u32 tree[9 * WG];
     const int tid = threadIdx.x;
     const u32 S = args.s;
@@ -266,7 +290,8 @@ seq_fwd_kernel(const SeqArgs args) {
 
 // ---- stage 2: invert every workgroup's root, one root per lane -----------------------------------------
 
-__global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
+__global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups, u32 prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const u32 g = blockIdx.x * 64 + threadIdx.x;
     const u32 gg = g < groups ? g : groups - 1;
     fe r, ri;
@@ -308,6 +333,11 @@ seq_bwd_kernel(const SeqArgs args) {
     const u32 S = args.s;
     const u32 lanes = args.lanes;
     const u32 u = blockIdx.x * WG + tid;
+    // shader-clock sample: the first wave of the launch reads the shader-clock counter (s_memtime) and the constant
+    // 100 MHz counter (s_memrealtime) when it starts and when it ends, and adds both spans to the frame's match
+    // header — the clock the CUs really ran at while this very kernel executed, at the cost of four scalar reads
+    const bool stamp = FMT != VGF_P2TR && blockIdx.x == 0 && args.mhdr != nullptr;
+    const unsigned long long stamp_c0 = stamp ? clock64() : 0ull, stamp_w0 = stamp ? wall_clock64() : 0ull;
 
     const u32 *tg = args.tree + (size_t)blockIdx.x * 9 * WG;
 #pragma unroll
@@ -443,6 +473,10 @@ seq_bwd_kernel(const SeqArgs args) {
                 }
             }
         }
+    }
+    if (stamp && tid == 0) {   // (launches of one frame are ordered on their stream: plain accumulation, mod 2^32)
+        args.mhdr->clk_cycles += (u32)(clock64() - stamp_c0);
+        args.mhdr->clk_ticks += (u32)(wall_clock64() - stamp_w0);
     }
     if (FMT == VGF_P2TR) {
         // product tree of the lanes' final products (as seq_fwd_kernel does for the denominators)
@@ -744,7 +778,7 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEven
     hipLaunchKernelGGL(keys_fwd_kernel, dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
+    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups, (u32)chain_prio());
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (before_bwd && (e = hipEventRecord(before_bwd, stream)) != hipSuccess) return e;
@@ -814,7 +848,7 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
         hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root2, a.groups);
+        hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root2, a.groups, (u32)chain_prio());
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (full) hipLaunchKernelGGL((p2tr_finish_kernel<true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
@@ -822,13 +856,15 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
         return hipGetLastError();
     }
     if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
-    else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
+    else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), bwd_lds_pad(), stream, a);
     return hipGetLastError();
 }
 
 
-hipError_t launch_seq_fwd(const SeqArgs &a, hipStream_t stream) {
-    if (a.lanes % WG != 0 || a.groups != a.lanes / WG || a.s < 2 || a.s > SEQ_MAX_S) return hipErrorInvalidValue;
+hipError_t launch_seq_fwd(const SeqArgs &a_in, hipStream_t stream) {
+    if (a_in.lanes % WG != 0 || a_in.groups != a_in.lanes / WG || a_in.s < 2 || a_in.s > SEQ_MAX_S) return hipErrorInvalidValue;
+    SeqArgs a = a_in;
+    a.prio = (u32)chain_prio();
     if (a.arrive) {
         hipLaunchKernelGGL(seq_fwd_kernel<true>, dim3(a.groups), dim3(WG), 0, stream, a);
         return hipGetLastError();
@@ -836,7 +872,7 @@ hipError_t launch_seq_fwd(const SeqArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(seq_fwd_kernel<false>, dim3(a.groups), dim3(WG), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
+    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups, (u32)chain_prio());
     return hipGetLastError();
 }
 

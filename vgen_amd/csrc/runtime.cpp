@@ -56,18 +56,17 @@ size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 // Stage stream `i` of `pool`, created on first use (a stream costs ~5 ms: a scan's first dispatches should be
 // running while the later streams are still being set up).
 //
-// The streams are created through hipExtStreamCreateWithCUMask with every CU enabled: such a stream owns a
-// hardware queue of its own, whereas ordinary streams share the runtime's pool of GPU_MAX_HW_QUEUES (default 4)
-// queues — measured on the box with tools/queue_probe.hip (profiles/r02_queue_probe.txt): the 5th, 9th, 13th
-// ordinary stream each add a full serial round, CU-masked streams overlap like ordinary ones under
-// GPU_MAX_HW_QUEUES=16.  So the overlap of the frames depends neither on an environment variable nor on whether
-// the host initialised HIP first.
-//
-// Own-queue streams are never destroyed: a context returns them to a process-wide cache (per device) when it is
-// destroyed and the next context takes them from there.  On this runtime (ROCm 7.2) creating a CU-masked stream
-// after others were destroyed can block forever inside hipExtStreamCreateWithCUMask (seen: the second
-// vgen_create of a process, after "Deleting hardware queue" of the first context's streams); reuse avoids the
-// teardown path altogether and saves the ~5 ms per stream on every later vgen_create.
+// Which streams own a hardware queue (measured with tools/queue_probe.hip, profiles/r02_queue_probe.txt): ordinary
+// streams share the runtime's pool of GPU_MAX_HW_QUEUES (default 4) queues — the 5th, 9th, 13th stream each add a
+// full serial round —, but the runtime keeps one such pool PER PRIORITY LEVEL, and CU-masked streams
+// (hipExtStreamCreateWithCUMask, all CUs enabled) get a queue each without limit.  Default: priority pools, i.e.
+// twelve queues with no environment variable and whether or not the host initialised HIP first.  CU-masked
+// streams (VGEN_STREAM_KIND=cumask) measure 3 % faster at 20 frames (12.4 vs 12.1 Gkeys/s at 12) but their
+// teardown is broken on this runtime (ROCm 7.2): hipStreamDestroy deletes the hardware queue, and that was seen
+// to block forever when another process held queues on the device (tools/cli_hang_probe.py), as was creating a
+// stream after such a deletion (second vgen_create of a process); never destroying them instead crashes the
+// runtime's own exit handlers once several contexts have come and gone.  CU-masked streams are therefore cached
+// per process and device and handed from context to context, and left for measurements only.
 struct StreamCache {
     std::mutex mu;
     std::map<int, std::vector<hipStream_t>> idle;   // device -> streams not in use by any context
@@ -77,14 +76,9 @@ StreamCache &stream_cache() {
     return *sc;
 }
 
-// The cached streams are normally left to the HIP runtime's own teardown when the process exits.  Destroying
-// them ourselves is not safe on this runtime (ROCm 7.2): hipStreamDestroy of a CU-masked stream deletes its
-// hardware queue, and that was seen to block forever ("Deleting hardware queue ...") when another process held
-// queues on the same device (tools/cli_hang_probe.py), as creating a stream after such a deletion was
-// (tools/topo_sweep.py, second context of a process).  The one case where leaving them is worse is a run under
-// rocprofv3, whose exit handlers crash on queues that outlive it (after it has written its output): with
-// VGEN_DESTROY_STREAMS_AT_EXIT=1 the idle streams are destroyed by an atexit() handler registered at the first
-// stream creation — i.e. after the HIP runtime registered its own teardown, so it runs before it.
+// VGEN_DESTROY_STREAMS_AT_EXIT=1: the idle CU-masked streams are destroyed by an atexit() handler registered at the
+// first stream creation — i.e. after the HIP runtime registered its own teardown, so it runs before it (rocprofv3's
+// exit handlers crash on queues that outlive it).
 void destroy_idle_streams() {
     StreamCache &sc = stream_cache();
     std::lock_guard<std::mutex> g(sc.mu);
@@ -97,7 +91,7 @@ void destroy_idle_streams() {
 
 int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStream_t *out) {
     if (!pool[i]) {
-        if (c->own_queues) {
+        if (c->stream_kind == STREAMS_CUMASK) {
             {
                 StreamCache &sc = stream_cache();
                 std::lock_guard<std::mutex> g(sc.mu);
@@ -116,6 +110,20 @@ int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStr
                 std::vector<uint32_t> mask((c->cu_count + 31) / 32, 0xFFFFFFFFu);
                 HIP_TRY(c, hipExtStreamCreateWithCUMask(&pool[i], (uint32_t)mask.size(), mask.data()));
             }
+        } else if (c->stream_kind == STREAMS_PRIORITY) {
+            // the runtime keeps one pool of GPU_MAX_HW_QUEUES hardware queues PER PRIORITY LEVEL: streams 0-3 take
+            // the normal level, 4-7 the next, 8-11 the third, so that twelve streams own twelve queues
+            int least = 0, greatest = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int levels = least - greatest + 1;   // 3 on this runtime: -1 (greatest), 0, 1 (least)
+            const uint32_t n = c->streams_created++;
+            int prio = 0;
+            if (levels >= 3) {
+                static const int order[3] = {0, -1, 1};
+                prio = order[(n / c->hw_queues) % 3];
+                if (prio < greatest || prio > least) prio = 0;
+            }
+            HIP_TRY(c, hipStreamCreateWithPriority(&pool[i], hipStreamNonBlocking, prio));
         } else {
             HIP_TRY(c, hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
         }
@@ -127,7 +135,7 @@ int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStr
 void retire_stream(vgen_ctx *c, hipStream_t st) {
     if (!st) return;
     (void)hipStreamSynchronize(st);
-    if (c->own_queues) {
+    if (c->stream_kind == STREAMS_CUMASK) {
         StreamCache &sc = stream_cache();
         std::lock_guard<std::mutex> g(sc.mu);
         sc.idle[c->device].push_back(st);
@@ -169,8 +177,11 @@ void parse_topology(vgen_ctx *c) {
             c->n_bwd = b;
         }
     }
-    const char *k = getenv("VGEN_STREAM_KIND");   // "plain": ordinary streams from the runtime's shared queue pool
-    if (k && !strcmp(k, "plain")) c->own_queues = false;
+    // VGEN_STREAM_KIND: "priority" (default) | "plain" (one priority level: GPU_MAX_HW_QUEUES queues in all) |
+    // "cumask" (CU-masked streams, a hardware queue each without limit — see stage_stream for why not by default)
+    const char *k = getenv("VGEN_STREAM_KIND");
+    if (k && !strcmp(k, "plain")) c->stream_kind = STREAMS_PLAIN;
+    else if (k && !strcmp(k, "cumask")) c->stream_kind = STREAMS_CUMASK;
     c->fused_inv = false;
     const char *fi = getenv("VGEN_FUSED_INV");
     if (fi && (*fi == '0' || *fi == '1')) c->fused_inv = *fi == '1';
@@ -596,6 +607,10 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
         const DevMatchHeader *hdr = reinterpret_cast<const DevMatchHeader *>(f.h_match);
         found = hdr->count - f.match_base;   // mod 2^32
         f.match_base = hdr->count;
+        f.last_clk_cycles = hdr->clk_cycles - f.clk_cycles_seen;
+        f.last_clk_ticks = hdr->clk_ticks - f.clk_ticks_seen;
+        f.clk_cycles_seen = hdr->clk_cycles;
+        f.clk_ticks_seen = hdr->clk_ticks;
         uint32_t stored = std::min(found, c->match_cap);
         if (stored > FIRST_COPY) {   // rare: the tail of a busy ring, fetched on the frame's own stream
             HIP_TRY(c, hipMemcpyAsync(f.h_match + match_bytes(FIRST_COPY), f.d_match + match_bytes(FIRST_COPY),
@@ -633,6 +648,16 @@ int rt_frame_times(vgen_ctx *c, uint32_t frame, float *kernel_ms, float *total_m
     }
     if (kernel_ms) *kernel_ms = f.last_ms;
     if (total_ms) *total_ms = f.last_total_ms;
+    return VGEN_OK;
+}
+
+// Shader-clock sample of the frame's last completed filter-mode dispatch (kernels.hip): cycles / ticks * 100 = MHz.
+int rt_frame_clock(vgen_ctx *c, uint32_t frame, uint32_t *cycles, uint32_t *ticks) {
+    if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (f.in_flight) return c->fail(VGEN_E_STATE, "frame still in flight");
+    if (cycles) *cycles = f.dumped ? 0 : f.last_clk_cycles;
+    if (ticks) *ticks = f.dumped ? 0 : f.last_clk_ticks;
     return VGEN_OK;
 }
 

@@ -56,6 +56,8 @@ struct vgen_ctx {
         bool timing_fresh = true;        // last_ms / last_total_ms already read from the events
         float last_ms = 0.f;             // dominant kernel (seq_bwd) of the last completed dispatch
         float last_total_ms = 0.f;       // whole dispatch: fwd + inv + bwd
+        uint32_t clk_cycles_seen = 0, clk_ticks_seen = 0;   // match-header clock sums at the last vgen_wait
+        uint32_t last_clk_cycles = 0, last_clk_ticks = 0;   // ... and what the last dispatch added to them
     };
     std::vector<Frame> fr;
     // stage streams: frame i uses fwd_streams[i % n_fwd] and bwd_streams[i % n_bwd]; n_fwd == 0: the first half
@@ -65,7 +67,8 @@ struct vgen_ctx {
     bool per_frame_streams = true;
     bool fused_inv = false;                      // root inversions in seq_fwd's tail instead of a seq_inv_kernel launch
     std::vector<hipStream_t> fwd_streams, bwd_streams;
-    bool own_queues = true;                      // streams with a hardware queue each (CU-masked, all CUs), see runtime.cpp
+    int stream_kind = 1;                         // vg::STREAMS_* (runtime.cpp: stage_stream)
+    uint32_t streams_created = 0;
     uint32_t cu_count = 0;
     uint32_t hw_queues = 4;                      // GPU_MAX_HW_QUEUES in effect when the context was created
     uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch | match ring [| P2TR scratch], per frame)
@@ -86,6 +89,8 @@ struct vgen_ctx {
 
 namespace vg {
 
+enum { STREAMS_PLAIN = 0, STREAMS_PRIORITY = 1, STREAMS_CUMASK = 2 };
+
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
 void rt_destroy(vgen_ctx *ctx);
 int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
@@ -96,6 +101,7 @@ int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32
 int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
 int rt_dump_view(vgen_ctx *ctx, uint32_t frame, const uint8_t **ptr, size_t *len);
 int rt_frame_times(vgen_ctx *ctx, uint32_t frame, float *kernel_ms, float *total_ms);
+int rt_frame_clock(vgen_ctx *ctx, uint32_t frame, uint32_t *cycles, uint32_t *ticks);
 int rt_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
 int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);
 
