@@ -30,8 +30,11 @@ def test_puzzle_66_and_unknown_names():
     assert vg.provider_resolve("other:thing") is None                             # unknown provider = regex (provider.rs:19)
     assert vg.provider_resolve("a:b|c") is None
     with pytest.raises(vg.VgenError) as e:
-        vg.provider_resolve("boha:b1000:67")
-    assert "not in the built-in table" in str(e.value)
+        vg.provider_resolve("boha:b1000:161")
+    assert "puzzles 1..160" in str(e.value)
+    with pytest.raises(vg.VgenError) as e:
+        vg.provider_resolve("boha:gsmg:1")
+    assert "not in the built-in b1000 table" in str(e.value)
     # escaping of metacharacters (regex::escape)
     assert vg.build_exact_pattern(vg.ProviderResult("a.b+c", vg.AddressFormat.P2pkh)) == "^a\\.b\\+c$"
 
@@ -77,3 +80,31 @@ def test_cli_messages(tmp_path):
     t.write_text("nokeys/1,1BgGZ9tcN4rm9KBzDn7KprQz87SZ26SAMH,p2pkh\n")
     out = run("range", "-p", "boha:nokeys:1", "--provider-table", str(t))
     assert out.returncode == 1 and "has no key range. Use --range or --puzzle" in out.stderr               # lib.rs:625-630
+
+
+def test_b1000_table_is_complete_and_every_solved_puzzle_rederives():
+    """All 160 puzzles resolve (the reference reads them from the boha crate, src/provider.rs:23-53).  For the 79
+    solved ones the address must be what the public key hashes to — checked with the oracle AND the product's
+    host-side derivation; the other 81 addresses must at least be well-formed Base58Check P2PKH strings."""
+    import hashlib
+    import json
+    from oracle import pyoracle as vo
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "b1000_puzzles.json")))["puzzles"]
+    assert [p["n"] for p in data] == list(range(1, 161))
+    b58 = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"
+    derived = 0
+    for p in data:
+        n = p["n"]
+        r = vg.provider_resolve("boha:b1000:%d" % n)
+        assert r.address == p["address"] and r.format == vg.AddressFormat.P2pkh and r.key_range == (2 ** (n - 1), 2 ** n - 1)
+        v = 0
+        for ch in p["address"]:
+            v = v * 58 + b58.index(ch)
+        raw = v.to_bytes(25, "big")
+        assert raw[0] == 0 and hashlib.sha256(hashlib.sha256(raw[:21]).digest()).digest()[:4] == raw[21:], n
+        if p["key_hex"]:
+            k = int(p["key_hex"], 16)
+            assert 2 ** (n - 1) <= k < 2 ** n
+            assert vo.generate(0, k)["address"] == p["address"] == vg.derive(0, k).address, n
+            derived += 1
+    assert derived == 79
