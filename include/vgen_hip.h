@@ -119,7 +119,10 @@ int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_
 
 /* Compiles `pattern` (prefixed with "(?i)" when case_insensitive, pattern.rs:26-30) into (a) a DFA
  * that decides Pattern::matches exactly for ASCII address strings and (b) a device prefilter for
- * `format`.  Empty or invalid patterns fail with VGEN_E_PATTERN (pattern.rs:22-24,32-33). */
+ * `format`.  Syntax: the regex crate's, as far as it can matter on ASCII haystacks (flags i m s x U u, word
+ * boundaries, Unicode / POSIX classes by their ASCII members, nested classes with && -- ~~); the CRLF flag R
+ * and Unicode class names outside the built-in table are VGEN_E_PATTERN, as are empty or invalid patterns
+ * (pattern.rs:22-24,32-33). */
 int vgen_filter_compile(const char *pattern, int case_insensitive, uint32_t format, vgen_filter **out);
 void vgen_filter_free(vgen_filter *f);
 /* Pattern::matches (pattern.rs:43-45): unanchored regex search over the address string. 1 / 0. */

@@ -2,10 +2,13 @@
 //
 // Stands in for regex::Regex as the reference uses it (src/pattern.rs:21-45): Pattern::new compiles
 // "(?i)"+pattern when case-insensitive, Pattern::matches is an UNANCHORED is_match over the address
-// string.  Address strings are ASCII, so the DFA works on bytes; syntax the subset does not cover
-// (\b, \p{..}, class set operations, flags other than i) is rejected with an error instead of being
-// approximated.  The DFA is used (a) on the host to confirm every device candidate exactly and
-// (b) by filter.cpp to derive the device prefilter (accepted prefixes / fixed suffixes).
+// string.  Address strings are ASCII, so the DFA works on bytes.  The parser covers the regex crate's syntax as
+// far as it can matter on ASCII (flags i m s x U u, word boundaries, Unicode / POSIX classes by their ASCII
+// members, nested classes and set operators — see regex_dfa.cpp); what it does not cover (the CRLF flag, Unicode
+// class names outside its table) is rejected with an error instead of being approximated.  Zero-width assertions
+// are part of the DFA (states carry the kind of the previous symbol), so is_match stays a table walk.
+// The DFA is used (a) on the host to confirm every device candidate exactly, (b) by filter.cpp to derive the
+// device prefilter (accepted prefixes / fixed suffixes) and (c) on the device itself (core/dfa_eval.h).
 #pragma once
 #include <stdint.h>
 
