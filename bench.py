@@ -229,12 +229,23 @@ def dump_mode_configs(vg, batch, device, seconds):
             "seconds": round(dt, 2), "dispatches": n,
             "pcie_gb_per_s": round(n * batch * 20 / dt / 1e9, 1),
             "note": "bound by the 20 B/key device-to-host copy, not by the kernels"}]
+    # a pattern too permissive for the default match ring (1 key in ~64 matches): the scan grows the ring and stays on
+    # the device filter; the host only encodes and confirms the candidates
     t0 = time.perf_counter()
-    res = vg.scan_gpu_with_runner("^1C", vg.ScanConfig(format=fmt, count=None, seed=42, max_batches=8), r)
-    dt = time.perf_counter() - t0
+    res = vg.scan_gpu_with_runner("^1C", vg.ScanConfig(format=fmt, count=None, seed=42, max_batches=64), r)
+    dt = res.elapsed_secs   # vgen_scan's own clock (the ctypes view then spends seconds turning 3 M matches into Python objects)
+    out.append({"config": "permissive prefix (1 key in ~64 matches): match ring grown by the scan, candidates confirmed on the host",
+                "format": "p2pkh", "pattern": "^1C", "value": round(res.operations / dt / 1e6, 1), "unit": "Mkeys/sec",
+                "seconds": round(dt, 2), "dispatches": res.operations // batch, "matches": len(res.matches),
+                "host_threads": usable_cores(),
+                "note": "bound by building the match records (address, WIF, hex) on the host cores"})
+    # a pattern nearly every address matches: full dumps, every key encoded and matched on the host (the reference's mode)
+    t0 = time.perf_counter()
+    res = vg.scan_gpu_with_runner("^1[1-9A-Za-z]", vg.ScanConfig(format=fmt, count=200000, seed=42, max_batches=8), r)
+    dt = res.elapsed_secs
     r.close()
-    out.append({"config": "host-filter scan (pattern too permissive for the match ring: every key encoded and matched on the host)",
-                "format": "p2pkh", "pattern": "^1C", "value": round(res.operations / dt / 1e6, 2), "unit": "Mkeys/sec",
+    out.append({"config": "host-filter scan (nearly every key matches: full dumps, every key encoded and matched on the host)",
+                "format": "p2pkh", "pattern": "^1[1-9A-Za-z]", "value": round(res.operations / dt / 1e6, 2), "unit": "Mkeys/sec",
                 "seconds": round(dt, 2), "dispatches": res.operations // batch, "matches": len(res.matches),
                 "host_threads": usable_cores(),
                 "note": "the reference's only mode; bound by Base58Check encoding + regex on the host cores"})

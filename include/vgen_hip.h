@@ -147,6 +147,11 @@ const char *vgen_format_charset_name(uint32_t format);
  * index order — the reference kernel's behaviour, src/shaders/search.wgsl:2-31). */
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 
+/* Resizes the match rings of all frames to match_cap records per dispatch (clamped to [256, batch_size]); only while
+ * no dispatch is in flight.  vgen_scan uses it to keep permissive patterns on the device filter: the reference hands
+ * EVERY hash to the host (src/gpu.rs:602-658); here the ring grows to hold the expected candidates instead. */
+int vgen_set_match_cap(vgen_ctx *ctx, uint32_t match_cap);
+
 /* ---- measurement aid -------------------------------------------------------------------------------------- */
 
 /* Starts a one-wave probe on its own stream that, for duration_ms, compares the shader-clock counter with

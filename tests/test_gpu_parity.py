@@ -644,3 +644,18 @@ def test_frames_own_their_hardware_queues_without_environment_help(vg):
         for f in range(frames):
             r.await_result(f)
         r.close()
+
+
+def test_permissive_pattern_grows_the_match_ring_instead_of_dumping(vg, vo):
+    """A prefix 1 key in ~23 matches: far more candidates per batch than the default ring of 4096 holds.  The scan
+    grows the ring (vgen_set_match_cap) and stays on the device filter; results equal the oracle's range scan, in
+    order, and a pattern that overflows a ring sized from a wrong guess still loses nothing."""
+    batch, lo, hi = 65536, 1, 6 * 65536
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=3, match_cap=256)
+    for pat in ("^1[A-F]", "^1[2-9A-Za-z]", "1[A-D][a-z]"):
+        want = vo.scan_range(0, pat, lo, hi, count=10**9)["matches"]
+        assert len(want) > 2000
+        res = vg.scan_gpu_with_runner(pat, vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=lo, end=hi), r)
+        assert [(m.address, m.wif) for m in res.matches] == [(x["address"], x["wif"]) for x in want], pat
+        assert res.operations == 6 * batch and res.complete
+    r.close()

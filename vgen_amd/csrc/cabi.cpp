@@ -157,6 +157,11 @@ int vgen_clock_probe_read(vgen_ctx *ctx, double *mhz) {
     return vg::rt_clock_probe_read(ctx, mhz);
 }
 
+int vgen_set_match_cap(vgen_ctx *ctx, uint32_t match_cap) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_set_match_cap(ctx, match_cap);
+}
+
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f) {
     if (!ctx) return VGEN_E_INVALID;
     return vg::rt_set_filter(ctx, f);

@@ -249,18 +249,15 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     // vgen_create, i.e. of the time to a cold first match); slices are 256-byte aligned.  Everything a dispatch
     // of this context's format touches is allocated here, nothing on the dispatch path.
     c->fr.resize(c->frames);
-    const size_t scratch_b = up256(scratch_words(c) * sizeof(uint32_t)), match_b = up256(match_bytes(c->match_cap));
+    const size_t scratch_b = up256(scratch_words(c) * sizeof(uint32_t));
     const size_t p2tr_b = up256(p2tr_words(c) * sizeof(uint32_t));
-    const size_t frame_b = scratch_b + match_b + p2tr_b;
-    if ((e = hipMalloc((void **)&c->d_slab, frame_b * c->frames)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&c->h_slab, match_b * c->frames, hipHostMallocDefault)) != hipSuccess)
+    const size_t frame_b = scratch_b + p2tr_b;
+    if ((e = hipMalloc((void **)&c->d_slab, frame_b * c->frames)) != hipSuccess)
         return bail(VGEN_E_NOMEM, std::string("frame allocation: ") + hipGetErrorString(e));
     for (uint32_t i = 0; i < c->frames; i++) {
         vgen_ctx::Frame &f = c->fr[i];
         f.d_scratch = reinterpret_cast<uint32_t *>(c->d_slab + frame_b * i);
-        f.d_match = c->d_slab + frame_b * i + scratch_b;
-        if (p2tr_b) f.d_p2tr_scratch = reinterpret_cast<uint32_t *>(c->d_slab + frame_b * i + scratch_b + match_b);
-        f.h_match = c->h_slab + match_b * i;
+        if (p2tr_b) f.d_p2tr_scratch = reinterpret_cast<uint32_t *>(c->d_slab + frame_b * i + scratch_b);
     }
     e = hipMalloc((void **)&c->d_filter, sizeof(DevFilter));
     if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(filter): ") + hipGetErrorString(e));
@@ -285,7 +282,44 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         (e = hipMemcpyAsync(c->d_rtab, lm.data(), lm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st0)) != hipSuccess ||
         (e = hipStreamSynchronize(st0)) != hipSuccess)
         return bail(VGEN_E_HIP, std::string("frame setup: ") + hipGetErrorString(e));
+    if (int rc = rt_set_match_cap(c, c->match_cap)) return bail(rc, c->err);
     *out = c;
+    return VGEN_OK;
+}
+
+// (Re)allocates the match rings of all frames for `cap` records each: at vgen_create, and when a scan meets a pattern
+// too permissive for the current rings (scanner.cpp grows them instead of falling back to filtering every key on the
+// host).  Only between dispatches.  The rings' monotonic counters restart at zero.
+int rt_set_match_cap(vgen_ctx *c, uint32_t cap) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (auto &f : c->fr)
+        if (f.in_flight) return c->fail(VGEN_E_STATE, "vgen_set_match_cap while a dispatch is in flight");
+    if (cap < FIRST_COPY) cap = FIRST_COPY;
+    if (cap > c->batch) cap = c->batch;   // a dispatch cannot report more candidates than keys
+    if (c->d_match_slab && cap == c->match_cap) return VGEN_OK;
+    const size_t match_b = up256(match_bytes(cap));
+    uint8_t *d = nullptr, *h = nullptr;
+    if (hipMalloc((void **)&d, match_b * c->frames) != hipSuccess) return c->fail(VGEN_E_NOMEM, "match ring allocation failed");
+    if (hipHostMalloc((void **)&h, match_b * c->frames, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(d);
+        return c->fail(VGEN_E_NOMEM, "match ring allocation failed (pinned host memory)");
+    }
+    hipStream_t st0 = nullptr;
+    if (int rc = stage_stream(c, c->bwd_streams, 0, &st0)) return rc;
+    HIP_TRY(c, hipMemsetAsync(d, 0, match_b * c->frames, st0));
+    HIP_TRY(c, hipStreamSynchronize(st0));
+    if (c->d_match_slab) (void)hipFree(c->d_match_slab);
+    if (c->h_slab) (void)hipHostFree(c->h_slab);
+    c->d_match_slab = d;
+    c->h_slab = h;
+    c->match_cap = cap;
+    for (uint32_t i = 0; i < c->frames; i++) {
+        vgen_ctx::Frame &f = c->fr[i];
+        f.d_match = d + match_b * i;
+        f.h_match = h + match_b * i;
+        f.match_base = 0;
+        f.clk_cycles_seen = f.clk_ticks_seen = 0;
+    }
     return VGEN_OK;
 }
 
@@ -308,6 +342,7 @@ void rt_destroy(vgen_ctx *c) {
     }
     if (c->d_probe) (void)hipFree(c->d_probe);
     if (c->d_slab) (void)hipFree(c->d_slab);      // scratch + match rings of all frames
+    if (c->d_match_slab) (void)hipFree(c->d_match_slab);
     if (c->h_slab) (void)hipHostFree(c->h_slab);
     if (c->d_dump_slab) (void)hipFree(c->d_dump_slab);
     if (c->h_dump_slab) (void)hipHostFree(c->h_dump_slab);

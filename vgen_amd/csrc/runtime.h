@@ -71,7 +71,8 @@ struct vgen_ctx {
     uint32_t streams_created = 0;
     uint32_t cu_count = 0;
     uint32_t hw_queues = 4;                      // GPU_MAX_HW_QUEUES in effect when the context was created
-    uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch | match ring [| P2TR scratch], per frame)
+    uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch [| P2TR scratch], per frame)
+    uint8_t *d_match_slab = nullptr;             // match rings of all frames (rt_set_match_cap)
     uint8_t *h_slab = nullptr;                   // pinned mirrors of the match rings
     uint8_t *d_dump_slab = nullptr;              // dump mode: payload buffers of all frames (first vgen_set_filter(NULL))
     uint8_t *h_dump_slab = nullptr;              // ... and their pinned mirrors
@@ -94,6 +95,7 @@ enum { STREAMS_PLAIN = 0, STREAMS_PRIORITY = 1, STREAMS_CUMASK = 2 };
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
 void rt_destroy(vgen_ctx *ctx);
 int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
+int rt_set_match_cap(vgen_ctx *ctx, uint32_t cap);
 int rt_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]);
 int rt_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n);
 int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,

@@ -341,11 +341,26 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     const uint32_t shard = cfg->n_shards > 1 ? cfg->shard : 0;
     if (shard >= shards) return ctx->fail(VGEN_E_INVALID, "shard >= n_shards");
 
-    // device prefilter or host filtering of full dumps: too permissive a prefilter would overflow the
-    // match ring, so it is only used when a batch is expected to produce few candidates
-    // (a DEVF_DFA filter has no selectivity estimate: it starts on the device and falls back on overflow)
-    bool host_all = flt.dev.kind == DEVF_HOST_ALL ||
-                    (flt.dev.kind != DEVF_HOST_ALL && flt.selectivity * (double)N > (double)ctx->match_cap / 8);
+    // Device filter or host filtering of full dumps.  A prefilter whose expected candidates per batch do not fit the
+    // match ring does not fall back to the reference's mode (every hash to the host): the ring GROWS to four times
+    // the expectation, as long as that stays below half a record per key (beyond that nearly every key is a match
+    // and the 20 B/key dump is the cheaper transfer).  A DEVF_DFA filter has no selectivity estimate: it starts on
+    // the device with the ring it finds and adapts on overflow (below).
+    auto next_pow2 = [](uint64_t v) {
+        uint64_t p = 256;
+        while (p < v) p <<= 1;
+        return p;
+    };
+    bool host_all = flt.dev.kind == DEVF_HOST_ALL;
+    if (!host_all && flt.selectivity >= 0 && flt.selectivity * (double)N * 4 > (double)ctx->match_cap) {
+        const uint64_t want = next_pow2((uint64_t)(flt.selectivity * (double)N * 4));
+        if (want <= N / 2) {
+            int rc = vgen_set_match_cap(ctx, (uint32_t)want);
+            if (rc != VGEN_OK) return rc;
+        } else {
+            host_all = true;
+        }
+    }
     int rc = vgen_set_filter(ctx, host_all ? nullptr : &flt);
     if (rc != VGEN_OK) return rc;
 
@@ -396,7 +411,6 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     };
     const uint32_t nf = ctx->frames;
     std::vector<Pending> pend(nf);
-    std::vector<vgen_match> recs(ctx->match_cap);
     uint32_t in_flight = 0;
     int status = VGEN_OK;
 
@@ -436,7 +450,8 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     };
     prime();
 
-    std::unique_ptr<HostFilterPool> pool;   // dump mode only, created with the first dumped batch
+    std::vector<vgen_match> recs(ctx->match_cap);   // (after the ring has its size for this scan)
+    std::unique_ptr<HostFilterPool> pool;   // created with the first dumped batch / the first batch with thousands of candidates
     bool cut_any = false;      // (no checkpoint) some batch had matches beyond `count` dropped: the range was not covered
 
     while (status == VGEN_OK && !order.empty()) {
@@ -481,12 +496,19 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
 
         if (!dumped) {
             if (n_found > recs.size()) {
-                // More candidates than the ring holds (a permissive pattern): nothing may be dropped, so
-                // drain what is in flight, switch to host filtering of full dumps (the reference's mode)
-                // and redo from this batch.
+                // More candidates than the ring holds (a permissive pattern): nothing may be dropped, so drain
+                // what is in flight, grow the ring (x4, at least twice what this batch produced) — or, once a ring
+                // would need more than half a record per key, switch to host filtering of full dumps, the
+                // reference's mode — and redo from this batch.
                 for (uint32_t f = 0; f < nf; f++)
                     if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
-                if ((status = vgen_set_filter(ctx, nullptr)) != VGEN_OK) break;
+                const uint64_t want = next_pow2(std::max<uint64_t>((uint64_t)recs.size() * 4, (uint64_t)n_found * 2));
+                if (want <= N / 2) {
+                    if ((status = vgen_set_match_cap(ctx, (uint32_t)want)) != VGEN_OK) break;
+                    recs.resize(ctx->match_cap);
+                } else if ((status = vgen_set_filter(ctx, nullptr)) != VGEN_OK) {
+                    break;
+                }
                 dispatched -= 1 + in_flight;
                 in_flight = 0;
                 order.clear();
@@ -498,9 +520,25 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             }
             vgen_generated g;
             uint32_t i = 0;
-            for (; i < n_found && (ck || found() < count); i++)
-                if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) (void)push(g);
-            cut = i < n_found;   // candidates left unexamined (conservative: they may not all be matches)
+            if (n_found >= 2048) {
+                // many candidates (a permissive pattern on a grown ring): confirm them on the worker pool, in index order
+                if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
+                const unsigned nt = pool->size();
+                std::vector<std::vector<vgen_generated>> part(nt);
+                pool->run([&](unsigned t) {
+                    const uint32_t lo = (uint32_t)((uint64_t)n_found * t / nt), hi = (uint32_t)((uint64_t)n_found * (t + 1) / nt);
+                    vgen_generated gg;
+                    for (uint32_t k = lo; k < hi; k++)
+                        if (make_match(flt, cfg->format, batch_start, recs[k].index, recs[k].payload, end, gg)) part[t].push_back(gg);
+                });
+                for (auto &p : part)
+                    for (auto &gg : p)
+                        if (!push(gg)) cut = true;
+            } else {
+                for (; i < n_found && (ck || found() < count); i++)
+                    if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) (void)push(g);
+                cut = i < n_found;   // candidates left unexamined (conservative: they may not all be matches)
+            }
         }
 
         total_ops += N;                              // gpu.rs:1106
