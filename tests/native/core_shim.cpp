@@ -308,3 +308,37 @@ int core_taproot_from_key(const unsigned char *key_be, unsigned char *out32) {
     return 1;
 }
 }
+
+extern "C" {
+// ec_mul_gen_w16 (core/ec.h, the device algorithm of the KEYS / P2TR paths) on the host: the 67 MB table is
+// allocated untouched and only the sixteen entries this key walks are filled in (d * 2^(16 w) * G by the generic host
+// multiplication); result x||y big-endian.  Returns 0 for k == 0.
+int core_mul_w16(const unsigned char *key_be, unsigned char *xy) {
+    static uint32_t *tab = (uint32_t *)calloc(EC_TABLE16_WORDS, sizeof(uint32_t));
+    Scalar k;
+    scalar_from_be(k, key_be);
+    if (!scalar_is_valid(k)) return 0;
+    for (int w = 0; w < 16; w++) {
+        const uint32_t d = (k.w[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu;
+        if (!d) continue;
+        Scalar e;
+        for (int i = 0; i < 8; i++) e.w[i] = 0;
+        e.w[w >> 1] = d << ((w & 1) * 16);
+        ge p;
+        if (!host_ec_mul_gen(e, p)) return 0;
+        uint32_t *o = tab + ((size_t)w * 65535u + (d - 1)) * 16;
+        fe_to_words(p.x, o);
+        fe_to_words(p.y, o + 8);
+    }
+    gej acc;
+    ec_mul_gen_w16(acc, k.w, tab);
+    ge r;
+    if (!ge_from_gej(r, acc)) return 0;
+    u32 wv[8];
+    fe_to_words(r.x, wv);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[4 * (7 - i) + j] = (unsigned char)(wv[i] >> (24 - 8 * j));
+    fe_to_words(r.y, wv);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[32 + 4 * (7 - i) + j] = (unsigned char)(wv[i] >> (24 - 8 * j));
+    return 1;
+}
+}

@@ -96,3 +96,16 @@ def test_seq_base_points_cache_walks_jumps_and_rewinds(core):
     for c, kb in enumerate(walk):
         for j in (0, 1, S - 1):
             assert out.raw[64 * (c * S + j):64 * (c * S + j) + 64] == vo.pubkey(kb + j)[1:], (c, j)
+
+
+def test_sixteen_bit_window_multiplication_used_by_keys_and_taproot_kernels(core):
+    """ec_mul_gen_w16 (15 branch-free mixed additions over the 16-bit table the device builds itself): random keys,
+    keys with zero digits (skipped windows, late first non-zero digit), single-digit keys, n - 1."""
+    rng = random.Random(77)
+    keys = [1, 2, 0xFFFF, 0x10000, 0x10001, 2**16 * 0xABCD, 2**240, 2**255 + 1, N - 1, N - 2, 0xFFFF << 112, (1 << 200) + (1 << 16)]
+    keys += [rng.randrange(1, N) for _ in range(60)]
+    keys += [rng.randrange(1, 2**64) << (16 * rng.randrange(0, 12)) for _ in range(20)]
+    for k in keys:
+        out = ctypes.create_string_buffer(64)
+        assert core.core_mul_w16((k % N).to_bytes(32, "big"), out) == 1, hex(k)
+        assert out.raw == vo.pubkey(k % N)[1:], hex(k)

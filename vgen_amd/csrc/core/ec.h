@@ -218,6 +218,25 @@ struct alignas(16) ec_u4 {
     u32 v[4];
 };
 
+// One window's step: acc += t (the table point of a non-zero digit d); a zero digit leaves acc alone, the first
+// non-zero digit replaces the point at infinity — all by selects, no branches.
+VG_HD void ec_fixed_accumulate(gej &acc, const ge &t, u32 d) {
+    gej sum;
+    gej_add_ge_nz(sum, acc, t);      // garbage while acc is at infinity; replaced below
+    const bool take_table = acc.inf != 0;
+    const bool skip = d == 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u32 nx = take_table ? t.x.n[i] : sum.x.n[i];
+        const u32 ny = take_table ? t.y.n[i] : sum.y.n[i];
+        const u32 nzl = take_table ? (i == 0 ? 1u : 0u) : sum.z.n[i];
+        acc.x.n[i] = skip ? acc.x.n[i] : nx;
+        acc.y.n[i] = skip ? acc.y.n[i] : ny;
+        acc.z.n[i] = skip ? acc.z.n[i] : nzl;
+    }
+    acc.inf = skip ? acc.inf : 0u;
+}
+
 template <int WB, int ES>
 VG_HD void ec_mul_gen_fixed(gej &acc, const u32 k[8], const u32 *tab) {
     static_assert(32 % WB == 0 && ES >= 18, "window geometry");
@@ -249,20 +268,7 @@ VG_HD void ec_mul_gen_fixed(gej &acc, const u32 k[8], const u32 *tab) {
             t.x.n[i] = raw[i];
             t.y.n[i] = raw[9 + i];
         }
-        gej sum;
-        gej_add_ge_nz(sum, acc, t);      // garbage while acc is at infinity; replaced below
-        const bool take_table = acc.inf != 0;
-        const bool skip = d == 0;
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const u32 nx = take_table ? t.x.n[i] : sum.x.n[i];
-            const u32 ny = take_table ? t.y.n[i] : sum.y.n[i];
-            const u32 nzl = take_table ? (i == 0 ? 1u : 0u) : sum.z.n[i];
-            acc.x.n[i] = skip ? acc.x.n[i] : nx;
-            acc.y.n[i] = skip ? acc.y.n[i] : ny;
-            acc.z.n[i] = skip ? acc.z.n[i] : nzl;
-        }
-        acc.inf = skip ? acc.inf : 0u;
+        ec_fixed_accumulate(acc, t, d);
     }
 }
 
@@ -273,5 +279,44 @@ VG_HD void ec_mul_gen_windows(gej &acc, const u32 k[8], const u32 *tab) { ec_mul
 // L2-resident, one entry = five 16-byte loads).  Half the additions of the 4-bit form.
 constexpr u32 EC_TABLE8_WORDS = 32u * 255u * 20u;
 VG_HD void ec_mul_gen_w8(gej &acc, const u32 k[8], const u32 *tab8) { ec_mul_gen_fixed<8, 20>(acc, k, tab8); }
+
+// 16-bit windows: 16 windows x 65 535 entries x 64 bytes (x then y as eight little-endian 32-bit words each: one
+// 64-byte sector per entry, four 16-byte loads) = 67 MB, built on the device (kernels.hip: gen_table16_kernel) and
+// gathered through the L2 / Infinity Cache.  15 additions instead of the 31 of the 8-bit form; the limb conversion
+// of a table point (two fe_from_words) is 4 % of an addition.
+constexpr u32 EC_TABLE16_ENTRIES = 16u * 65535u;
+constexpr u32 EC_TABLE16_WORDS = EC_TABLE16_ENTRIES * 16u;
+VG_HD void ec_mul_gen_w16(gej &acc, const u32 k[8], const u32 *tab16) {
+    gej_set_infinity(acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int w = 0; w < 16; w++) {
+        const u32 d = (k[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu;
+        const u32 e = (d ? d : 1u) - 1u;
+        const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(tab16 + ((u32)w * 65535u + e) * 16u);
+        u32 raw[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const ec_u4 t4 = e4[q];
+#pragma unroll
+            for (int i = 0; i < 4; i++) raw[4 * q + i] = t4.v[i];
+        }
+        ge t;
+        fe_from_words(t.x, raw);
+        fe_from_words(t.y, raw + 8);
+        ec_fixed_accumulate(acc, t, d);
+    }
+}
+
+// The generator tables a kernel may use: the 8-bit one always, the 16-bit one when it has been built.
+struct GenTables {
+    const u32 *w8;
+    const u32 *w16;
+};
+VG_HD void ec_mul_gen_tables(gej &acc, const u32 k[8], const GenTables &g) {
+    if (g.w16) ec_mul_gen_w16(acc, k, g.w16);
+    else ec_mul_gen_w8(acc, k, g.w8);
+}
 
 }  // namespace vg

@@ -14,11 +14,11 @@ namespace vg {
 constexpr u32 TAP_ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                                 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
-// x, y: canonical affine internal key; tab8: host_gen_table8_limbs.  q = lift_x(x) + TapTweak(x)*G in Jacobian
+// x, y: canonical affine internal key; tabs: the generator tables (ec.h).  q = lift_x(x) + TapTweak(x)*G in Jacobian
 // coordinates.  Returns false when the tweak is not a valid scalar (t == 0 or t >= n: probability ~2^-128;
 // q is then some other valid point) — such keys yield no address (Address::p2tr would fail there).
 // q.z == 0 (t*G == -P) is the caller's to check.
-VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const u32 *tab8, gej &q) {
+VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const GenTables &tabs, gej &q) {
     u32 xw[8], tb[8], k[8];
     fe_to_words(x, xw);
     sha256_taptweak(xw, tb);
@@ -39,7 +39,7 @@ VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const u32 *tab8, gej &q
         k[0] = 1;
     }
     gej tg;
-    ec_mul_gen_w8(tg, k, tab8);
+    ec_mul_gen_tables(tg, k, tabs);
     // P with even Y
     ge p;
     p.x = x;
@@ -71,8 +71,9 @@ VG_HD void taproot_affine_x(const gej &q, const fe &zi, u32 out_xw[8]) {
 
 // Single-key form (host: vgen_derive, match confirmation, tests): its own inversion.
 VG_HD bool taproot_output_x(const fe &x, const fe &y, const u32 *tab8, u32 out_xw[8]) {
+    const GenTables tabs{tab8, nullptr};
     gej q;
-    const bool ok = taproot_tweak_point(x, y, tab8, q);
+    const bool ok = taproot_tweak_point(x, y, tabs, q);
     const bool inf = taproot_z_is_zero(q.z);
     fe zi;
     fe_inv(zi, q.z);

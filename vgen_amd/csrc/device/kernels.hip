@@ -153,17 +153,17 @@ struct PayloadWords {
 };
 
 // x, y: canonical affine public key.  out: the payload words in memory order (PayloadWords<FMT>).
-// tab8: the 8-bit fixed-window generator table in global memory, tree: 9*WG words of LDS (both P2TR only: the
+// tabs: the fixed-window generator tables in global memory, tree: 9*WG words of LDS (both P2TR only: the
 // arbitrary-scalar path's taproot keys; the sequential path parks its tweaked points instead, see seq_bwd_kernel).
 // Returns false when the key yields no address (P2TR tweak not a valid scalar — probability ~2^-128).
 template <int FMT>
-__device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, const u32 *tab8, u32 *tree, u32 *out) {
+__device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, const GenTables &tabs, u32 *tree, u32 *out) {
     u32 xw[8];
     if (FMT == VGF_P2TR) {
         // Q = lift_x(x) + t*G per lane (8-bit fixed windows over the global table), then ONE inversion for the
         // whole workgroup: every lane of the workgroup must be here (the callers' loops are uniform).
         gej q;
-        bool ok = taproot_tweak_point(x, y_canon, tab8, q);
+        bool ok = taproot_tweak_point(x, y_canon, tabs, q);
         const bool zero = taproot_z_is_zero(q.z);     // t*G == -P: no address; keep the shared product invertible
         if (zero) fe_set_one(q.z);
         fe zi;
@@ -324,7 +324,7 @@ seq_bwd_kernel(const SeqArgs args) {
     extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
-    const u32 *gtab = args.gtab;       // P2TR: 8-bit fixed-window generator table, read from global memory (L2)
+    const GenTables gtab{args.gtab, args.gtab16};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache)
     u32 *dfa_lds = dyn_lds;
     if (FULL) {
         for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_fwd_kernel(const KeysArgs args) 
     (void)keys_load_scalar(args, idx, k);
 
     gej acc;
-    ec_mul_gen_w8(acc, k, args.gtab);
+    ec_mul_gen_tables(acc, k, GenTables{args.gtab, args.gtab16});
 
     u32 *o = args.xyz + idx;
 #pragma unroll
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
     u32 k[8];
     const bool valid = keys_load_scalar(args, idx, k);
     u32 pl[NW];
-    const bool ok = payload_from_point<FMT>(x, y, args.gtab, tree, pl) && valid;   // P2TR: workgroup-wide
+    const bool ok = payload_from_point<FMT>(x, y, GenTables{args.gtab, args.gtab16}, tree, pl) && valid;   // P2TR: workgroup-wide
 
     if (idx >= args.n) return;
     if (args.dump) {
@@ -784,6 +784,43 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEven
     if (before_bwd && (e = hipEventRecord(before_bwd, stream)) != hipSuccess) return e;
     if (full) hipLaunchKernelGGL((keys_bwd_kernel<FMT, true>), dim3(a.groups), dim3(KEYS_WG), a.dfa_bytes, stream, a);
     else hipLaunchKernelGGL((keys_bwd_kernel<FMT, false>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---- 16-bit fixed-window generator table, built on the device ---------------------------------------------------
+// Entry (w, d) = d * 2^(16 w) * G for d = 1 .. 65535: one lane per entry multiplies through the 8-bit table and
+// normalises with its own inversion (1 M entries x ~610 field multiplications: ~3 ms of the chip, once per context).
+// Output: eight little-endian words of x, eight of y per entry (core/ec.h: ec_mul_gen_w16).
+__global__ void __launch_bounds__(256) gen_table16_kernel(const u32 *tab8, u32 *tab16) {
+    const u32 idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= EC_TABLE16_ENTRIES) return;
+    const u32 w = idx / 65535u, d = idx % 65535u + 1u;
+    u32 k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = 0;
+    k[w >> 1] = d << ((w & 1u) * 16u);
+    gej p;
+    ec_mul_gen_w8(p, k, tab8);
+    fe zi, zi2, zi3, x, y;
+    fe_inv(zi, p.z);
+    fe_sqr(zi2, zi);
+    fe_mul(zi3, zi2, zi);
+    fe_mul(x, p.x, zi2);
+    fe_mul(y, p.y, zi3);
+    fe_canonicalize_product(x);
+    fe_canonicalize_product(y);
+    u32 xw[8], yw[8];
+    fe_to_words(x, xw);
+    fe_to_words(y, yw);
+    ec_u4 *o = reinterpret_cast<ec_u4 *>(tab16 + (size_t)idx * 16);
+    o[0] = ec_u4{{xw[0], xw[1], xw[2], xw[3]}};
+    o[1] = ec_u4{{xw[4], xw[5], xw[6], xw[7]}};
+    o[2] = ec_u4{{yw[0], yw[1], yw[2], yw[3]}};
+    o[3] = ec_u4{{yw[4], yw[5], yw[6], yw[7]}};
+}
+
+hipError_t launch_gen_table16(const u32 *tab8, u32 *tab16, hipStream_t stream) {
+    hipLaunchKernelGGL(gen_table16_kernel, dim3((EC_TABLE16_ENTRIES + 255) / 256), dim3(256), 0, stream, tab8, tab16);
     return hipGetLastError();
 }
 

@@ -349,6 +349,7 @@ void rt_destroy(vgen_ctx *c) {
     if (c->d_keys_slab) (void)hipFree(c->d_keys_slab);
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
+    if (c->d_gtab16) (void)hipFree(c->d_gtab16);
     if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
     if (c->d_dfa) (void)hipFree(c->d_dfa);
     if (c->d_filter) (void)hipFree(c->d_filter);
@@ -469,6 +470,15 @@ int ensure_gtab(vgen_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
         if (int rc = upload(c, c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t))) return rc;
     }
+    // the 16-bit table (half the additions per multiplication), built on the device from the 8-bit one: 67 MB,
+    // ~3 ms, once per context.  VGEN_GTAB_BITS=8 keeps the paths on the 8-bit table.
+    if (!c->d_gtab16 && env_u32("VGEN_GTAB_BITS", 16) == 16) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_gtab16, (size_t)EC_TABLE16_WORDS * sizeof(uint32_t)));
+        hipStream_t st0 = nullptr;
+        if (int rc = stage_stream(c, c->bwd_streams, 0, &st0)) return rc;
+        HIP_TRY(c, launch_gen_table16(c->d_gtab, c->d_gtab16, st0));
+        HIP_TRY(c, hipStreamSynchronize(st0));
+    }
     return VGEN_OK;
 }
 
@@ -496,6 +506,7 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     KeysArgs a;
     memset(&a, 0, sizeof a);
     a.gtab = c->d_gtab;
+    a.gtab16 = c->d_gtab16;
     a.keys_be = keys_dev;
     if (base)
         for (int i = 0; i < 8; i++) a.base[i] = base->w[i];
@@ -594,6 +605,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
         if (int rc = ensure_gtab(c)) return rc;
         a.gtab = c->d_gtab;
+        a.gtab16 = c->d_gtab16;
         // ... and the tweaked points of the dispatch wait in scratch for their shared inversion:
         // tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
         const size_t tq_words = (size_t)2 * S * 27 * c->lanes, flag_words = (size_t)2 * S * c->lanes;
