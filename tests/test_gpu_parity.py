@@ -659,3 +659,27 @@ def test_permissive_pattern_grows_the_match_ring_instead_of_dumping(vg, vo):
         assert [(m.address, m.wif) for m in res.matches] == [(x["address"], x["wif"]) for x in want], pat
         assert res.operations == 6 * batch and res.complete
     r.close()
+
+
+@pytest.mark.parametrize("bits", [8, 16, 20, 22])
+def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypatch):
+    """The arbitrary-scalar and taproot paths multiply through a fixed-window table of VGEN_GTAB_BITS-bit windows
+    (8: the host-built 653 KB table; 16 / 20 / 22: built on the device from it).  Every width must reproduce the
+    oracle: explicit scalars incl. the extremes, and the P2TR tweak multiplication."""
+    monkeypatch.setenv("VGEN_GTAB_BITS", str(bits))
+    import random
+    rng = random.Random(bits)
+    keys = [1, 2, N - 1, N - 2, 2**255, 0xFFFF, 0x10000, (1 << 200) + 5, (2**22 - 1) << 220, 2**256 - 1, 0, N] + [rng.randrange(1, N) for _ in range(500)]
+    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh)
+    r.set_filter(None)
+    r.dispatch_keys(keys, 0)
+    blob, _, tested = r.await_result(0)
+    assert tested == len(keys)
+    for i, k in enumerate(keys):
+        want = vo.payload(0, k) if 0 < k < N else bytes(20)
+        assert blob[20 * i:20 * i + 20] == want, (bits, hex(k))
+    r.close()
+    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2tr)
+    start = vo.seed_key(bits, 3)
+    assert dump(r, start) == vo.payload_seq(3, start, 8192)
+    r.close()

@@ -280,21 +280,35 @@ VG_HD void ec_mul_gen_windows(gej &acc, const u32 k[8], const u32 *tab) { ec_mul
 constexpr u32 EC_TABLE8_WORDS = 32u * 255u * 20u;
 VG_HD void ec_mul_gen_w8(gej &acc, const u32 k[8], const u32 *tab8) { ec_mul_gen_fixed<8, 20>(acc, k, tab8); }
 
-// 16-bit windows: 16 windows x 65 535 entries x 64 bytes (x then y as eight little-endian 32-bit words each: one
-// 64-byte sector per entry, four 16-byte loads) = 67 MB, built on the device (kernels.hip: gen_table16_kernel) and
-// gathered through the L2 / Infinity Cache.  15 additions instead of the 31 of the 8-bit form; the limb conversion
-// of a table point (two fe_from_words) is 4 % of an addition.
-constexpr u32 EC_TABLE16_ENTRIES = 16u * 65535u;
-constexpr u32 EC_TABLE16_WORDS = EC_TABLE16_ENTRIES * 16u;
-VG_HD void ec_mul_gen_w16(gej &acc, const u32 k[8], const u32 *tab16) {
+// Wide windows: WB = 16 .. 24 bits, NW = ceil(256 / WB) windows x (2^WB - 1) entries x 64 bytes (x then y as eight
+// little-endian 32-bit words each: one 64-byte sector per entry, four 16-byte loads), built on the device
+// (kernels.hip: gen_table_wide_kernel) and gathered through the L2 / Infinity Cache / HBM.  NW - 1 additions instead
+// of the 31 of the 8-bit form (16 bits: 15 additions, 67 MB; 20 bits: 12 additions, 872 MB; 22 bits: 11, 3.2 GB);
+// the limb conversion of a table point (two fe_from_words) is 4 % of an addition.
+VG_HD constexpr u32 ec_wide_windows(u32 wb) { return (256u + wb - 1u) / wb; }
+VG_HD constexpr u64 ec_wide_entries(u32 wb) { return (u64)ec_wide_windows(wb) * ((1ull << wb) - 1ull); }
+VG_HD constexpr u64 ec_wide_words(u32 wb) { return ec_wide_entries(wb) * 16ull; }
+
+// digit `w` (WB bits, least significant first) of the 256-bit little-endian scalar k
+VG_HD u32 ec_wide_digit(const u32 k[8], u32 w, u32 wb) {
+    const u32 bit = w * wb, i = bit >> 5, sh = bit & 31u;
+    const u64 lo = k[i], hi = i + 1 < 8 ? k[i + 1] : 0u;
+    return (u32)(((lo | (hi << 32)) >> sh) & ((1ull << wb) - 1ull));
+}
+
+template <int WB>
+VG_HD void ec_mul_gen_wide(gej &acc, const u32 k[8], const u32 *tab) {
+    static_assert(WB >= 9 && WB <= 24, "window width");
+    constexpr u32 NW = ec_wide_windows(WB);
+    constexpr u64 NE = (1ull << WB) - 1ull;
     gej_set_infinity(acc);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int w = 0; w < 16; w++) {
-        const u32 d = (k[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu;
+    for (u32 w = 0; w < NW; w++) {
+        const u32 d = ec_wide_digit(k, w, WB);
         const u32 e = (d ? d : 1u) - 1u;
-        const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(tab16 + ((u32)w * 65535u + e) * 16u);
+        const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(tab + ((u64)w * NE + e) * 16ull);
         u32 raw[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -309,13 +323,20 @@ VG_HD void ec_mul_gen_w16(gej &acc, const u32 k[8], const u32 *tab16) {
     }
 }
 
-// The generator tables a kernel may use: the 8-bit one always, the 16-bit one when it has been built.
+constexpr u32 EC_TABLE16_ENTRIES = 16u * 65535u;
+constexpr u32 EC_TABLE16_WORDS = EC_TABLE16_ENTRIES * 16u;
+VG_HD void ec_mul_gen_w16(gej &acc, const u32 k[8], const u32 *tab16) { ec_mul_gen_wide<16>(acc, k, tab16); }
+
+// The generator tables a kernel may use: the 8-bit one always, a wide one (of `wide_bits` bits) when it has been built.
 struct GenTables {
     const u32 *w8;
-    const u32 *w16;
+    const u32 *wide;
+    u32 wide_bits;
 };
 VG_HD void ec_mul_gen_tables(gej &acc, const u32 k[8], const GenTables &g) {
-    if (g.w16) ec_mul_gen_w16(acc, k, g.w16);
+    if (g.wide && g.wide_bits == 16) ec_mul_gen_wide<16>(acc, k, g.wide);
+    else if (g.wide && g.wide_bits == 20) ec_mul_gen_wide<20>(acc, k, g.wide);
+    else if (g.wide && g.wide_bits == 22) ec_mul_gen_wide<22>(acc, k, g.wide);
     else ec_mul_gen_w8(acc, k, g.w8);
 }
 

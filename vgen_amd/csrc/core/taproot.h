@@ -71,7 +71,7 @@ VG_HD void taproot_affine_x(const gej &q, const fe &zi, u32 out_xw[8]) {
 
 // Single-key form (host: vgen_derive, match confirmation, tests): its own inversion.
 VG_HD bool taproot_output_x(const fe &x, const fe &y, const u32 *tab8, u32 out_xw[8]) {
-    const GenTables tabs{tab8, nullptr};
+    const GenTables tabs{tab8, nullptr, 0};
     gej q;
     const bool ok = taproot_tweak_point(x, y, tabs, q);
     const bool inf = taproot_z_is_zero(q.z);

@@ -95,7 +95,8 @@ struct SeqArgs {
     uint32_t match_cap;
     const uint32_t *dfa_blob;  // DEVF_DFA: the automaton (device memory), staged into LDS by the kernel
     const uint32_t *gtab;      // P2TR: 8-bit fixed-window generator table (global memory) for the tweak multiplication
-    const uint32_t *gtab16;    // ... and the 16-bit one (67 MB, built on the device at first use); nullptr = use gtab
+    const uint32_t *gtab16;    // ... and the wide-window one (built on the device at first use); nullptr = use gtab
+    uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22)
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
     uint32_t prio;             // seq_fwd: raise the waves' issue priority (set by launch_seq_fwd)
@@ -115,7 +116,8 @@ constexpr int KEYS_WG = 256;
 
 struct KeysArgs {
     const uint32_t *gtab;      // [32][255][20]: x limbs 0..8, y limbs 9..17 of d * 256^w * G (d = 1..255)
-    const uint32_t *gtab16;    // 16-bit windows: [16][65535][16 words] (core/ec.h: ec_mul_gen_w16); nullptr = use gtab
+    const uint32_t *gtab16;    // wide windows: [windows][2^bits - 1][16 words] (core/ec.h: ec_mul_gen_wide); nullptr = use gtab
+    uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22)
     const uint8_t *keys_be;    // n * 32 bytes big-endian, or nullptr: key i = base + i
     const DevFilter *filter;
     uint32_t *dump;            // dump mode: n * 5 words (zeroed for invalid keys)

@@ -324,7 +324,7 @@ seq_bwd_kernel(const SeqArgs args) {
     extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
-    const GenTables gtab{args.gtab, args.gtab16};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache)
+    const GenTables gtab{args.gtab, args.gtab16, args.gtab_bits};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache)
     u32 *dfa_lds = dyn_lds;
     if (FULL) {
         for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_fwd_kernel(const KeysArgs args) 
     (void)keys_load_scalar(args, idx, k);
 
     gej acc;
-    ec_mul_gen_tables(acc, k, GenTables{args.gtab, args.gtab16});
+    ec_mul_gen_tables(acc, k, GenTables{args.gtab, args.gtab16, args.gtab_bits});
 
     u32 *o = args.xyz + idx;
 #pragma unroll
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
     u32 k[8];
     const bool valid = keys_load_scalar(args, idx, k);
     u32 pl[NW];
-    const bool ok = payload_from_point<FMT>(x, y, GenTables{args.gtab, args.gtab16}, tree, pl) && valid;   // P2TR: workgroup-wide
+    const bool ok = payload_from_point<FMT>(x, y, GenTables{args.gtab, args.gtab16, args.gtab_bits}, tree, pl) && valid;   // P2TR: workgroup-wide
 
     if (idx >= args.n) return;
     if (args.dump) {
@@ -787,18 +787,26 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEven
     return hipGetLastError();
 }
 
-// ---- 16-bit fixed-window generator table, built on the device ---------------------------------------------------
-// Entry (w, d) = d * 2^(16 w) * G for d = 1 .. 65535: one lane per entry multiplies through the 8-bit table and
-// normalises with its own inversion (1 M entries x ~610 field multiplications: ~3 ms of the chip, once per context).
-// Output: eight little-endian words of x, eight of y per entry (core/ec.h: ec_mul_gen_w16).
-__global__ void __launch_bounds__(256) gen_table16_kernel(const u32 *tab8, u32 *tab16) {
-    const u32 idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= EC_TABLE16_ENTRIES) return;
-    const u32 w = idx / 65535u, d = idx % 65535u + 1u;
-    u32 k[8];
+// ---- wide fixed-window generator table, built on the device -----------------------------------------------------
+// Entry (w, d) = d * 2^(bits w) * G for d = 1 .. 2^bits - 1: one lane per entry multiplies through the 8-bit table and
+// normalises with its own inversion (~610 field multiplications per entry: 1 M entries ~3 ms of the chip, once per
+// context).  Entries whose scalar would not fit 256 bits (top window) are never addressed and stay unwritten.
+// Output: eight little-endian words of x, eight of y per entry (core/ec.h: ec_mul_gen_wide).
+__global__ void __launch_bounds__(256) gen_table_wide_kernel(const u32 *tab8, u32 *tab, u32 bits, unsigned long long entries) {
+    const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= entries) return;
+    const unsigned long long per = (1ull << bits) - 1ull;
+    const u32 w = (u32)(idx / per);
+    const unsigned long long d = idx % per + 1ull;
+    const u32 bit = w * bits;
+    if (bit + (64 - __clzll(d)) > 256) return;          // d * 2^bit >= 2^256: not a digit any scalar has
+    u32 k[9];
 #pragma unroll
-    for (int i = 0; i < 8; i++) k[i] = 0;
-    k[w >> 1] = d << ((w & 1u) * 16u);
+    for (int i = 0; i < 9; i++) k[i] = 0;
+    const u32 i0 = bit >> 5, sh = bit & 31u;
+    const unsigned long long lo = d << sh;              // d < 2^24, sh < 32: fits 64 bits
+    k[i0] = (u32)lo;
+    if (i0 + 1 < 8) k[i0 + 1] = (u32)(lo >> 32);
     gej p;
     ec_mul_gen_w8(p, k, tab8);
     fe zi, zi2, zi3, x, y;
@@ -812,15 +820,17 @@ __global__ void __launch_bounds__(256) gen_table16_kernel(const u32 *tab8, u32 *
     u32 xw[8], yw[8];
     fe_to_words(x, xw);
     fe_to_words(y, yw);
-    ec_u4 *o = reinterpret_cast<ec_u4 *>(tab16 + (size_t)idx * 16);
+    ec_u4 *o = reinterpret_cast<ec_u4 *>(tab + idx * 16ull);
     o[0] = ec_u4{{xw[0], xw[1], xw[2], xw[3]}};
     o[1] = ec_u4{{xw[4], xw[5], xw[6], xw[7]}};
     o[2] = ec_u4{{yw[0], yw[1], yw[2], yw[3]}};
     o[3] = ec_u4{{yw[4], yw[5], yw[6], yw[7]}};
 }
 
-hipError_t launch_gen_table16(const u32 *tab8, u32 *tab16, hipStream_t stream) {
-    hipLaunchKernelGGL(gen_table16_kernel, dim3((EC_TABLE16_ENTRIES + 255) / 256), dim3(256), 0, stream, tab8, tab16);
+hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 bits, hipStream_t stream) {
+    if (bits != 16 && bits != 20 && bits != 22) return hipErrorInvalidValue;
+    const unsigned long long entries = ec_wide_entries(bits);
+    hipLaunchKernelGGL(gen_table_wide_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, stream, tab8, tab, bits, entries);
     return hipGetLastError();
 }
 

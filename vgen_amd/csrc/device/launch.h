@@ -21,8 +21,8 @@ namespace vg {
 // sequential scan).  a.xyz / a.tree / a.root: scratch for a.groups = ceil(a.n / 256) workgroups.
 // `before_bwd` (optional) is recorded between the inversion stage and the backward stage.
 hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream, hipEvent_t before_bwd);
-// Builds the 16-bit fixed-window generator table (EC_TABLE16_WORDS words, core/ec.h) from the 8-bit one.
-hipError_t launch_gen_table16(const uint32_t *tab8, uint32_t *tab16, hipStream_t stream);
+// Builds the wide fixed-window generator table (bits = 16 | 20 | 22; ec_wide_words(bits) words, core/ec.h) from the 8-bit one.
+hipError_t launch_gen_table_wide(const uint32_t *tab8, uint32_t *tab, uint32_t bits, hipStream_t stream);
 // Enqueues the shader-clock probe: out[0] = shader-clock cycles, out[1] = 100 MHz ticks elapsed (>= ticks).
 hipError_t launch_clock_probe(unsigned long long *out, unsigned long long ticks, hipStream_t stream);
 }  // namespace vg

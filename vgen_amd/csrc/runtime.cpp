@@ -470,14 +470,22 @@ int ensure_gtab(vgen_ctx *c) {
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
         if (int rc = upload(c, c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t))) return rc;
     }
-    // the 16-bit table (half the additions per multiplication), built on the device from the 8-bit one: 67 MB,
-    // ~3 ms, once per context.  VGEN_GTAB_BITS=8 keeps the paths on the 8-bit table.
-    if (!c->d_gtab16 && env_u32("VGEN_GTAB_BITS", 16) == 16) {
-        HIP_TRY(c, hipMalloc((void **)&c->d_gtab16, (size_t)EC_TABLE16_WORDS * sizeof(uint32_t)));
-        hipStream_t st0 = nullptr;
-        if (int rc = stage_stream(c, c->bwd_streams, 0, &st0)) return rc;
-        HIP_TRY(c, launch_gen_table16(c->d_gtab, c->d_gtab16, st0));
-        HIP_TRY(c, hipStreamSynchronize(st0));
+    // The wide-window table, built on the device from the 8-bit one, once per context: 20-bit windows by default
+    // (13 windows, 12 additions per multiplication instead of 31; 872 MB of the 288 GB, ~40 ms to build).  Measured
+    // (KEYS mode / P2TR, Mkeys/s): 8 bits 576 / 610, 16 bits (67 MB) 1012 / 1087, 20 bits 1177 / 1217, 22 bits
+    // (3.2 GB, ~150 ms) 1257 / 1275.  VGEN_GTAB_BITS = 8 | 16 | 20 | 22 selects (8 = no wide table).
+    if (!c->d_gtab16) {
+        const uint32_t bits = env_u32("VGEN_GTAB_BITS", 20);
+        if (bits == 16 || bits == 20 || bits == 22) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_gtab16, (size_t)ec_wide_words(bits) * sizeof(uint32_t)));
+            hipStream_t st0 = nullptr;
+            if (int rc = stage_stream(c, c->bwd_streams, 0, &st0)) return rc;
+            HIP_TRY(c, launch_gen_table_wide(c->d_gtab, c->d_gtab16, bits, st0));
+            HIP_TRY(c, hipStreamSynchronize(st0));
+            c->gtab_bits = bits;
+        } else if (bits != 8) {
+            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20 or 22");
+        }
     }
     return VGEN_OK;
 }
@@ -507,6 +515,7 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     memset(&a, 0, sizeof a);
     a.gtab = c->d_gtab;
     a.gtab16 = c->d_gtab16;
+    a.gtab_bits = c->gtab_bits;
     a.keys_be = keys_dev;
     if (base)
         for (int i = 0; i < 8; i++) a.base[i] = base->w[i];
@@ -606,6 +615,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         if (int rc = ensure_gtab(c)) return rc;
         a.gtab = c->d_gtab;
         a.gtab16 = c->d_gtab16;
+        a.gtab_bits = c->gtab_bits;
         // ... and the tweaked points of the dispatch wait in scratch for their shared inversion:
         // tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
         const size_t tq_words = (size_t)2 * S * 27 * c->lanes, flag_words = (size_t)2 * S * c->lanes;

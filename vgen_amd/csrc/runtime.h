@@ -29,7 +29,8 @@ struct vgen_ctx {
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
     uint32_t *d_gtab = nullptr;          // 8-bit fixed-window generator table (arbitrary-scalar path, P2TR), built on first use
-    uint32_t *d_gtab16 = nullptr;        // 16-bit fixed-window generator table, built on the device from d_gtab at first use
+    uint32_t *d_gtab16 = nullptr;        // wide fixed-window generator table (gtab_bits bits), built on the device from d_gtab at first use
+    uint32_t gtab_bits = 0;
     vg::DevFilter *d_filter = nullptr;   // current device filter program
     uint32_t *d_dfa = nullptr;           // DEVF_DFA automaton of the current filter
     uint32_t *d_chk_lut = nullptr;       // Bech32 checksum tables of the current filter (when it tests the checksum)
