@@ -284,7 +284,14 @@ def main():
         args.frames = max(2, args.frames // per_dev)       # more than ~20 busy queues per device collapse the throughput
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    real_stdout = None
     if world > 1:
+        # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): the contract is ONE JSON line
+        # there, so everything this process and its libraries print goes to stderr and the line is written to the
+        # original descriptor at the end
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         # The data path has no collective (disjoint scalar ranges): the process group only carries the barriers and
         # the max of the elapsed time, so it runs over gloo — no RCCL communicator, no extra device queues beside
         # the frames' own.
@@ -452,7 +459,11 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
