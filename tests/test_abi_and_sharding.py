@@ -152,8 +152,8 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     out = _torchrun(os.path.join(ROOT, "bench.py"), ["--gpus", "2", "--steps", "64", "--warmup", "8", "--sustained-seconds", "0.3"],
                     29521, env_extra={"VGEN_BENCH_REHEARSE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout[:500]      # ONE line on stdout: gloo's own chatter must not reach it
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 64 and d["scaling"] == "weak" and d["value"] > 1000
     assert d["config"]["parallelism"].startswith("range-striped x2") and d["sustained"]["value"] > 1000

@@ -25,3 +25,23 @@ for fmt in (0, 2, 3, 4, 5):
             runs += 1; keys += batch
         r.close()
 print("soak ok: %d dispatches, %d keys, %.0f s" % (runs, keys, time.time() - t0))
+
+# second phase: twelve frames in flight at once (each on its own stream / hardware queue), all checked — no frame may
+# see another's scratch, tables or results whatever the overlap
+t1 = time.time()
+runs2 = keys2 = 0
+for fmt, batch in ((0, 16384), (5, 16384), (2, 32768), (3, 8192)):
+    F = 12
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=F)
+    r.set_filter(None)
+    t2 = time.time()
+    while time.time() - t2 < budget / 8:
+        starts = [min(rng.randrange(1, N) >> rng.randrange(0, 200) or 1, N - batch - 20) for _ in range(F)]
+        for f in range(F):
+            r.dispatch(starts[f], f)
+        for f in reversed(range(F)):          # consumed out of dispatch order on purpose
+            blob, _, _ = r.await_result(f)
+            assert blob == vo.payload_seq(fmt, starts[f], batch), (fmt, batch, f, hex(starts[f]))
+            runs2 += 1; keys2 += batch
+    r.close()
+print("concurrent soak ok: %d dispatches (12 in flight), %d keys, %.0f s" % (runs2, keys2, time.time() - t1))
