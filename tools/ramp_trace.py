@@ -1,0 +1,33 @@
+"""Timeline of a short run (the driver's --steps 20): when is each dispatch issued, when does each wait return?"""
+import sys, time
+sys.path.insert(0, ".")
+import vgen_amd as v
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+N = 1 << 20
+r = v.GpuRunner(batch_size=N, fmt=v.AddressFormat.P2pkh, frames=F, timing=False)
+r.set_filter(v.Pattern("^1Cat", False, v.AddressFormat.P2pkh))
+key = 0x3a8ae174e51b7b1117ab406c6570970f453c4376b6d381977db7c02fb5a993e0
+for rep in range(3):
+    for f in range(F):
+        r.dispatch(key, f); key += N
+    for f in range(F):
+        r.wait(f)
+    time.sleep(0.01)
+    ev = []
+    t0 = time.perf_counter()
+    issued = done = 0
+    for f in range(min(F, K)):
+        r.dispatch(key, f); key += N; issued += 1
+        ev.append(("d", issued, (time.perf_counter() - t0) * 1e6))
+    fw = 0
+    while done < K:
+        r.wait(fw); done += 1
+        ev.append(("w", done, (time.perf_counter() - t0) * 1e6))
+        if issued < K:
+            r.dispatch(key, fw); key += N; issued += 1
+            ev.append(("d", issued, (time.perf_counter() - t0) * 1e6))
+        fw = (fw + 1) % F
+    total = (time.perf_counter() - t0) * 1e6
+    print("F=%d K=%d total %.0f us = %.0f Mkeys/s" % (F, K, total, K * N / total))
+print(" ".join("%s%d@%.0f" % e for e in ev))
