@@ -162,17 +162,17 @@ class Pipeline:
         return issued, time.perf_counter() - t0
 
 
-def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, label, note=None):
+def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, label, note=None, endo=False):
     """One `other_configs` entry: sustained rate of the dispatch loop for another format / pattern."""
     fmt = vg.AddressFormat(FORMATS[fmt_name])
-    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False)
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False, endo=endo)
     pat = vg.Pattern(pattern, ci, fmt)
     r.set_filter(pat if pat.device_kind != 0 else None)
     p = Pipeline(r, seed_key(42, 0))
     p.run_steps(2 * frames)
     n, dt = p.run_seconds(seconds)
     r.close()
-    rate = n * batch / dt
+    rate = n * batch * (6 if endo else 1) / dt
     out = {"config": label, "format": fmt_name, "pattern": pattern + (" -i" if ci else ""), "value": round(rate / 1e6, 1),
            "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": n, "device_filter_kind": pat.device_kind,
            "chip_frac": round(rate * work_per_key(fmt_name) / 1e12 / PEAK_TLANEOPS, 4)}
@@ -462,6 +462,10 @@ def main():
               timed_config(vg, "p2pkh-uncompressed", "^1Cat", False, args.batch, F, local_rank, sec, "P2PKH, uncompressed public key"),
               timed_config(vg, "p2tr", "^bc1pqqq", False, args.batch, F, local_rank, sec, "P2TR (taproot tweak on the device)"),
               timed_config(vg, "p2pkh", "1[Oo]ri", False, args.batch, F, local_rank, sec, "unanchored pattern: full Base58Check + DFA match on the device"),
+              timed_config(vg, "p2pkh", "^1Cat", False, args.batch, F, local_rank, sec,
+                           "vanity search proper (VGEN_FLAG_ENDO): six keys per curve point — k, lambda k, lambda^2 k and their negations",
+                           note="what `vgen-hip generate` runs for unseeded P2PKH / P2WPKH searches; every dispatch tests 6 x 2^20 keys for one "
+                                "batch of point arithmetic; not a contiguous range, hence not the headline configuration", endo=True),
               keys_mode_config(vg, args.batch, min(F, 8), local_rank, sec)]
         oc += dump_mode_configs(vg, args.batch, local_rank, sec)
         out["other_configs"] = oc

@@ -51,6 +51,13 @@ typedef enum vgen_format {
 /* Parameters of vgen_create; replaces the arguments of GpuRunner::new(batch_size, backend)
  * (src/gpu.rs:138) plus the buffer sizing it derives from them (src/gpu.rs:391-500). */
 /* vgen_params.flags */
+#define VGEN_FLAG_ENDO 2u     /* vanity ("generate") searches only: every curve point of a dispatch is tested under its six
+                                 endomorphism / negation images — keys k, lambda k, lambda^2 k and their negations, public
+                                 keys (x, +-y), (beta x, +-y), (beta^2 x, +-y) — so a dispatch tests 6 x batch_size keys for
+                                 one batch_size of point arithmetic (P2PKH / P2WPKH formats with a prefilter pattern; other
+                                 combinations run as without the flag).  The keys tested are NOT a contiguous range:
+                                 vgen_scan refuses start / end / seed on such a context.  vgen_wait reports keys_tested
+                                 = 6 x batch_size and match indices variant * batch_size + i (vgen_key_variant). */
 #define VGEN_FLAG_TIMING 1u   /* record HIP events around every dispatch so that vgen_frame_kernel_ms /
                                  vgen_frame_dispatch_ms report durations (bench.py); without it a dispatch is
                                  three kernels and one copy, and the host loop is ~10 us per step cheaper */
@@ -206,6 +213,10 @@ int vgen_address_from_payload(uint32_t format, const uint8_t *payload, char *out
 int vgen_key_to_wif(uint32_t format, const uint8_t key_be[32], char *out, size_t cap);
 /* increment_key (src/gpu.rs:951-968): out = key + amount; VGEN_E_RANGE on overflow or invalid scalar. */
 int vgen_key_add(const uint8_t key_be[32], uint64_t amount, uint8_t out_be[32]);
+/* Endomorphism contexts (VGEN_FLAG_ENDO) test six keys per curve point; a match's index is variant * batch_size + i.
+ * This maps the base key start_key + i to the key of `variant`: 0..2 = lambda^variant * k, 3..5 = the negations
+ * (mod n; lambda * (x, y) = (beta * x, y) on secp256k1).  VGEN_E_RANGE for an invalid key. */
+int vgen_key_variant(const uint8_t key_be[32], uint32_t variant, uint8_t out_be[32]);
 /* AddressGenerator::generate (src/address.rs:92-151) on the host, for single keys (verify-style
  * use and tests). address cap >= 96, wif cap >= 72. VGEN_E_RANGE for an invalid key. */
 int vgen_derive(uint32_t format, const uint8_t key_be[32], char *address, size_t acap, char *wif, size_t wcap);

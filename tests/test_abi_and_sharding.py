@@ -33,6 +33,25 @@ def test_no_device_is_a_loud_error_not_a_cpu_fallback():
     assert e.value.status == -2 and "no CPU fallback" in str(e.value)
 
 
+def test_key_variants_of_endomorphism_contexts_are_lambda_multiples_mod_n():
+    """vgen_key_variant (host/scalar.h: 256 x 256 -> 512-bit product folded mod n) against Python integers."""
+    import random
+    import vgen_amd as vg
+    n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    lam = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+    assert pow(lam, 3, n) == 1
+    rng = random.Random(1)
+    keys = [1, 2, n - 1, n - 2, 2**255, lam, n - lam, (n + 1) // 2, 2**256 - n] + [rng.randrange(1, n) for _ in range(3000)]
+    for k in keys:
+        for v in range(6):
+            want = pow(lam, v % 3, n) * k % n
+            assert vg.key_variant(k, v) == (n - want if v >= 3 else want), (hex(k), v)
+    with pytest.raises(vg.VgenError):
+        vg.key_variant(0, 1)
+    with pytest.raises(vg.VgenError):
+        vg.key_variant(5, 6)
+
+
 def test_host_side_helpers_match_oracle():
     import vgen_amd as vg
     from oracle import pyoracle as vo

@@ -683,3 +683,81 @@ def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypat
     start = vo.seed_key(bits, 3)
     assert dump(r, start) == vo.payload_seq(3, start, 8192)
     r.close()
+
+
+# ---- endomorphism contexts (VGEN_FLAG_ENDO): six keys per curve point ---------------------------------------------
+
+LAMBDA = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+
+
+def variant_key(k, v):
+    kv = pow(LAMBDA, v % 3, N) * k % N
+    return N - kv if v >= 3 else kv
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_endomorphism_dump_is_the_oracle_on_all_six_images(vg, vo, fmt):
+    """A dispatch of an endomorphism context tests, for every base key k0 + i, the keys k, lambda k, lambda^2 k and
+    their negations (mod n); entry variant * batch + i of the dump must be the oracle's payload of exactly that key."""
+    batch = 8192
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), endo=True)
+    r.set_filter(None)
+    for start in (vo.seed_key(5, 0), 1, 2**200 + 12345):
+        r.dispatch(start, 0)
+        blob, _, tested = r.await_result(0)
+        assert tested == 6 * batch and len(blob) == 6 * batch * 20
+        for v in range(6):
+            assert vg.key_variant(start + 77, v) == variant_key(start + 77, v)
+            for i in list(range(0, batch, 97)) + [batch - 1]:
+                want = vo.payload(fmt, variant_key(start + i, v))
+                assert blob[20 * (v * batch + i):20 * (v * batch + i) + 20] == want, (hex(start), v, i)
+        # images 0 (the keys themselves) in full against the sequential oracle
+        assert blob[:20 * batch] == vo.payload_seq(fmt, start, batch)
+    r.close()
+
+
+def test_endomorphism_filter_mode_equals_dfa_over_its_own_dump(vg, vo):
+    batch = 1 << 17
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, endo=True, match_cap=8192)
+    start = vo.seed_key(11, 2)
+    r.set_filter(None)
+    r.dispatch(start, 0)
+    blob, _, tested = r.await_result(0)
+    assert tested == 6 * batch
+    for pattern in ("^1Cat", "^1[a-c]Z", "^1zz"):
+        pat = vg.Pattern(pattern, False, vg.AddressFormat.P2pkh)
+        assert pat.device_kind in (1, 2)
+        r.set_filter(pat)
+        r.dispatch(start, 1)
+        recs, n, tested = r.await_result(1)
+        assert tested == 6 * batch and n == len(recs)
+        want = [i for i in range(6 * batch) if pat.matches(vg.address_from_payload(0, blob[20 * i:20 * i + 20]))]
+        got_exact = [idx for idx, pl in recs if pat.matches(vg.address_from_payload(0, pl))]
+        assert got_exact == want and len(want) > 0, pattern
+        for idx, pl in recs:
+            assert pl == blob[20 * idx:20 * idx + 20]
+    r.close()
+
+
+def test_endomorphism_scan_returns_keys_that_really_own_their_addresses(vg, vo):
+    r = vg.GpuRunner(batch_size=1 << 18, fmt=vg.AddressFormat.P2pkh, frames=4, endo=True)
+    seen = []
+    res = vg.scan_gpu_with_runner("^1Cat", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=8), r, progress_cb=seen.append)
+    assert len(res.matches) == 8 and res.operations % (6 << 18) == 0 and seen[-1] == res.operations
+    for m in res.matches:
+        g = vo.generate(0, int(m.hex, 16))
+        assert m.address.startswith("1Cat") and (g["address"], g["wif"]) == (m.address, m.wif)
+    # some of eight random matches come from images other than the key walk itself (5 in 6 do on average)
+    # a contiguous range is not what such a context tests
+    for cfg in (vg.ScanConfig(count=1, seed=3), vg.ScanConfig(count=1, start=1, end=0xFFFF)):
+        with pytest.raises(vg.VgenError) as e:
+            vg.scan_gpu_with_runner("^1Cat", cfg, r)
+        assert "contiguous key range" in str(e.value)
+    # a pattern that needs the on-device DFA runs without the images (and says so through keys_tested)
+    pat = vg.Pattern("Cat", False, vg.AddressFormat.P2pkh)
+    assert pat.device_kind == 4
+    r.set_filter(pat)
+    r.dispatch(12345, 0)
+    _, _, tested = r.await_result(0)
+    assert tested == 1 << 18
+    r.close()

@@ -118,6 +118,7 @@ _L.vgen_frame_clock.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER
 _L.vgen_frame_dispatch_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
 _L.vgen_address_from_payload.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_key_to_wif.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+_L.vgen_key_variant.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p]
 _L.vgen_key_add.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
 _L.vgen_derive.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                            ctypes.c_size_t]
@@ -175,6 +176,13 @@ def key_add(key, amount):
     out = ctypes.create_string_buffer(32)
     rc = _L.vgen_key_add(_key(key), amount, out)
     return None if rc == E_RANGE else int.from_bytes(out.raw, "big")
+
+
+def key_variant(key, variant):
+    """vgen_key_variant: the key an endomorphism context tests as `variant` of base key `key`."""
+    out = ctypes.create_string_buffer(32)
+    _check(_L.vgen_key_variant(_key(key), variant, out))
+    return int.from_bytes(out.raw, "big")
 
 
 @dataclass
@@ -305,9 +313,10 @@ class GpuRunner:
     """GpuRunner (src/gpu.rs:116-131): one device, `frames` dispatches in flight."""
 
     def __init__(self, batch_size: int = 1 << 20, fmt: AddressFormat = AddressFormat.P2pkh, device: int = 0,
-                 frames: int = 2, match_cap: int = 4096, timing: bool = True):
+                 frames: int = 2, match_cap: int = 4096, timing: bool = True, endo: bool = False):
         # timing: VGEN_FLAG_TIMING — events around every dispatch so that kernel_ms() / dispatch_ms() work
-        p = _Params(ctypes.sizeof(_Params), device, batch_size, int(fmt), frames, match_cap, 1 if timing else 0)
+        # endo: VGEN_FLAG_ENDO — six keys per curve point (vanity searches on compressed-key formats)
+        p = _Params(ctypes.sizeof(_Params), device, batch_size, int(fmt), frames, match_cap, (1 if timing else 0) | (2 if endo else 0))
         h = ctypes.c_void_p()
         _check(_L.vgen_create(ctypes.byref(p), ctypes.byref(h)))
         self._h = h
@@ -358,9 +367,7 @@ class GpuRunner:
         n, tested = ctypes.c_uint32(), ctypes.c_uint64()
         _check(_L.vgen_wait(self._h, frame, recs, self.match_cap, ctypes.byref(n), ctypes.byref(tested)), self._h)
         if self._pattern is None:
-            buf = ctypes.create_string_buffer(self.batch_size * self.payload_bytes)
-            _check(_L.vgen_read_dump(self._h, frame, buf, len(buf)), self._h)
-            return buf.raw, 0, tested.value
+            return self.dump_view(frame), 0, tested.value
         k = min(n.value, self.match_cap)
         return [(recs[i].index, bytes(recs[i].payload)[:self.payload_bytes]) for i in range(k)], n.value, tested.value
 

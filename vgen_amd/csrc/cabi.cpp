@@ -245,6 +245,16 @@ int vgen_key_add(const uint8_t key_be[32], uint64_t amount, uint8_t out_be[32]) 
     return (carry || !vg::scalar_is_valid(r)) ? VGEN_E_RANGE : VGEN_OK;
 }
 
+int vgen_key_variant(const uint8_t key_be[32], uint32_t variant, uint8_t out_be[32]) {
+    if (!key_be || !out_be || variant >= 6) return VGEN_E_INVALID;
+    vg::Scalar k, r;
+    vg::scalar_from_be(k, key_be);
+    if (!vg::scalar_is_valid(k)) return VGEN_E_RANGE;
+    vg::scalar_variant(r, k, variant);
+    vg::scalar_to_be(r, out_be);
+    return VGEN_OK;
+}
+
 int vgen_derive(uint32_t format, const uint8_t key_be[32], char *address, size_t acap, char *wif, size_t wcap) {
     if (!key_be) return VGEN_E_INVALID;
     uint8_t payload[32];

@@ -30,6 +30,7 @@ struct Opts {
     std::string cmd, pattern, format = "p2pkh", output = "text", file, range, key, address, devices = "0", checkpoint, provider_table;
     bool has_pattern = false, ignore_case = false, quiet = false, json = false, no_gpu = false;
     uint64_t count = 1, repeat = 1, seed = 0;
+    bool no_endo = false;
     uint32_t batch = 1u << 20, frames = 16;
     int puzzle = 0;
     long prefix_length = -1;   // -l / --prefix-length (provider patterns)
@@ -148,6 +149,8 @@ void usage() {
             "  vgen-hip generate -p PATTERN [-f FORMAT] [-i] [-c COUNT] [-o text|json|jsonl|csv|minimal] [--file PATH]\n"
             "                    [--gpu-batch-size N] [--repeat N] [-q] [--seed S] [--devices 0,1,..|all] [--frames F]\n"
             "                    [--checkpoint FILE]   (resume an interrupted scan from FILE; written as the scan runs)\n"
+            "                    [--no-endo]           (unseeded P2PKH / P2WPKH searches on one device test six keys per curve\n"
+            "                                           point — k, lambda k, lambda^2 k and their negations; this walks k0 + i only)\n"
             "                    PATTERN may be a provider pattern boha:b1000:N [-l PREFIX_LENGTH] [--provider-table CSV]\n"
             "  vgen-hip range (--range START:END | --puzzle P) [-p PATTERN] [-f FORMAT] [-c COUNT (0 = whole range)] ...\n"
             "  vgen-hip estimate -p PATTERN [-f FORMAT] [-i]\n"
@@ -188,6 +191,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "-a" || a == "--address") o.address = val();
         else if (a == "--json") o.json = true;
         else if (a == "--no-gpu") o.no_gpu = true;
+        else if (a == "--no-endo") o.no_endo = true;
         else if (a == "--no-tui" || a == "--tui") {}                                   // no TUI in this build
         else if (a == "-l" || a == "--prefix-length") o.prefix_length = strtol(val().c_str(), nullptr, 10);
         else if (a == "--provider-table") o.provider_table = val();
@@ -333,6 +337,9 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         p.batch_size = o.batch;
         p.format = (uint32_t)fmt;
         p.frames = o.frames;
+        // a vanity search proper — random base, no range, no seed, no checkpoint, one device — may test any keys it likes:
+        // six images per curve point (VGEN_FLAG_ENDO, +30 % keys per second); everything else walks k0 + i
+        if (!o.no_endo && !has_range && !o.seed && o.checkpoint.empty() && devs.size() == 1 && (fmt == 0 || fmt == 1)) p.flags |= VGEN_FLAG_ENDO;
         vgen_ctx *c = nullptr;
         if (vgen_create(&p, &c) != VGEN_OK) die(std::string("GPU initialization failed: ") + vgen_last_error(nullptr));
         ctxs.push_back(c);

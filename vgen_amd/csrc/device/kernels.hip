@@ -90,6 +90,26 @@ __device__ __forceinline__ void lds_load_fe(const u32 *base, int stride, int col
     for (int i = 0; i < 9; i++) a.n[i] = base[i * stride + col];
 }
 
+// A field element parked in LDS across a register-hungry stretch (volatile: the compiler must not keep a copy in
+// registers and forward it to the reload).
+__device__ __forceinline__ void lds_park_fe(u32 *base, int stride, int col, const fe &a) {
+    volatile u32 *b = base;
+#pragma unroll
+    for (int i = 0; i < 9; i++) b[i * stride + col] = a.n[i];
+}
+
+__device__ __forceinline__ void lds_unpark_fe(u32 *base, int stride, int col, fe &a) {
+    volatile u32 *b = base;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.n[i] = b[i * stride + col];
+}
+
+// beta, the cube root of unity mod p behind the secp256k1 endomorphism lambda * (x, y) = (beta * x, y), in 29-bit limbs
+__device__ __forceinline__ void fe_set_beta(fe &b) {
+    b.n[0] = 0x119501EEu; b.n[1] = 0x09CB6143u; b.n[2] = 0x1D626570u; b.n[3] = 0x0092EA25u; b.n[4] = 0x034E99CFu;
+    b.n[5] = 0x03CF561Au; b.n[6] = 0x1C41B991u; b.n[7] = 0x056CAF80u; b.n[8] = 0x007AE96Au;
+}
+
 __device__ __forceinline__ void shfl_xor_fe(fe &r, const fe &a, int mask) {
 #pragma unroll
     for (int i = 0; i < 9; i++) r.n[i] = (u32)__shfl_xor((int)a.n[i], mask);
@@ -317,7 +337,11 @@ struct SeqWaves {
     static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH : 4;
 };
 
-template <int FMT, bool FULL>
+// ENDO (vanity searches; compressed-key formats with a prefilter or in dump mode): every point is tested under its six
+// endomorphism / negation images — (x, +-y), (beta x, +-y), (beta^2 x, +-y), the public keys of k, lambda k, lambda^2 k and
+// their negations — so six keys are hashed for one point's arithmetic plus two multiplications by beta.  Image `variant`
+// = s * 3 + e (e = power of beta, s = negated) of key index i is reported / dumped at variant * n + i.
+template <int FMT, bool FULL, bool ENDO = false>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SeqWaves<FMT>::value, SeqWaves<FMT>::value)))
 seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
@@ -370,6 +394,7 @@ seq_bwd_kernel(const SeqArgs args) {
         for (int i = 0; i < 9; i++) sib.n[i] = args.pre[(size_t)((S - 1) * 9 + i) * lanes + (u ^ 1u)];
         fe_mul(inv, ip, sib);
     }
+    if (ENDO) __syncthreads();   // every lane has read its pair's inverse: the tree's LDS now parks the x of the point in hand
 
     fe rx, ry;
 #pragma unroll
@@ -453,10 +478,48 @@ seq_bwd_kernel(const SeqArgs args) {
                 continue;
             }
 
+            const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
+            if (ENDO) {
+                const u32 ypar = y3.n[0] & 1u;
+                lds_park_fe(tree, WG, tid, x3);
+#pragma unroll 1
+                for (u32 v = 0; v < 6; v++) {
+                    const u32 e = v >> 1, sneg = v & 1u;   // (x,+) (x,-) (bx,+) (bx,-) (b^2 x,+) (b^2 x,-)
+                    fe xe;
+                    lds_unpark_fe(tree, WG, tid, xe);
+                    if (sneg == 0 && e > 0) {
+                        fe beta;
+                        fe_set_beta(beta);
+                        fe_mul(xe, xe, beta);
+                        fe_canonicalize_product(xe);
+                        lds_park_fe(tree, WG, tid, xe);
+                    }
+                    u32 xw[8], sha[8], ple[NW];
+                    fe_to_words(xe, xw);
+                    sha256_pub33(2u | (ypar ^ sneg), xw, sha);
+                    ripemd160_of_sha(sha, ple);
+                    const u32 vindex = (sneg * 3u + e) * args.n + index;
+                    if (dump) {
+                        u32 *o = args.dump + (size_t)vindex * NW;
+#pragma unroll
+                        for (int i = 0; i < NW; i++) o[i] = ple[i];
+                    } else if (filter_eval_n<NW>(args.filter, ple)) {
+                        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+                        if (slot < args.match_cap) {
+                            DevMatch *m = args.mrec + slot;
+                            m->index = vindex;
+                            m->reserved = 0;
+#pragma unroll
+                            for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? ple[i] : 0u;
+                        }
+                    }
+                }
+                continue;
+            }
+
             u32 pl[NW];
             const bool ok = payload_from_point<FMT>(x3, y3, gtab, tree, pl);
 
-            const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (dump) {
                 u32 *o = args.dump + (size_t)index * NW;
 #pragma unroll
@@ -903,6 +966,7 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
         return hipGetLastError();
     }
     if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+    else if (a.endo && FMT == VGF_P2PKH) hipLaunchKernelGGL((seq_bwd_kernel<VGF_P2PKH, false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
     else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), bwd_lds_pad(), stream, a);
     return hipGetLastError();
 }

@@ -82,4 +82,77 @@ inline uint64_t scalar_distance_to_n(const Scalar &a) {
     return ((uint64_t)d.w[1] << 32) | d.w[0];
 }
 
+// r = a * b mod n.  Schoolbook 256 x 256 -> 512 bits, then 2^256 = c (mod n), c = 2^256 - n (129 bits), folded until
+// nothing is left above bit 255 (at most five times) and finished by conditional subtractions.  Host-side, rare (one per reported match of an endomorphism scan).
+inline void scalar_mul_mod_n(Scalar &r, const Scalar &a, const Scalar &b) {
+    static const uint32_t C[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u};   // 2^256 - n
+    uint32_t t[24] = {0};
+    for (int i = 0; i < 8; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 8; j++) {
+            carry += (uint64_t)a.w[i] * b.w[j] + t[i + j];
+            t[i + j] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        t[i + 8] = (uint32_t)carry;
+    }
+    // value = lo(8 words) + hi * 2^256  ==  lo + hi * C; hi shrinks from 8 to 5 to 2 to 0..1 words
+    int hi_words = 8;
+    for (int round = 0; round < 6 && hi_words > 0; round++) {
+        uint32_t acc[24] = {0};
+        for (int i = 0; i < 8; i++) acc[i] = t[i];
+        for (int i = 0; i < hi_words; i++) {
+            uint64_t carry = 0;
+            for (int j = 0; j < 5; j++) {
+                carry += (uint64_t)t[8 + i] * C[j] + acc[i + j];
+                acc[i + j] = (uint32_t)carry;
+                carry >>= 32;
+            }
+            for (int k = i + 5; carry; k++) {
+                carry += acc[k];
+                acc[k] = (uint32_t)carry;
+                carry >>= 32;
+            }
+        }
+        memcpy(t, acc, sizeof t);
+        hi_words = 0;
+        for (int i = 23; i >= 8; i--)
+            if (t[i]) {
+                hi_words = i - 7;
+                break;
+            }
+    }
+    for (int i = 0; i < 8; i++) r.w[i] = t[i];
+    while (scalar_cmp_words(r.w, SCALAR_N) >= 0) {
+        int64_t bw = 0;
+        for (int i = 0; i < 8; i++) {
+            int64_t d = (int64_t)r.w[i] - SCALAR_N[i] + bw;
+            r.w[i] = (uint32_t)d;
+            bw = d >> 32;
+        }
+    }
+}
+
+// The secp256k1 endomorphism on scalars: lambda * (x, y) = (beta * x, y), lambda^3 = 1 (mod n).
+static const uint32_t SCALAR_LAMBDA[8] = {0x1B23BD72u, 0xDF02967Cu, 0x20816678u, 0x122E22EAu,
+                                          0x8812645Au, 0xA5261C02u, 0xC05C30E0u, 0x5363AD4Cu};
+
+// Key variant v of k (0 < k < n) as the endomorphism kernels enumerate them: v % 3 = power of lambda, v >= 3 = negated:
+// k, lambda k, lambda^2 k, -k, -lambda k, -lambda^2 k (mod n).  Public keys: (x,y), (bx,y), (b^2 x,y), (x,-y), ...
+inline void scalar_variant(Scalar &r, const Scalar &k, uint32_t v) {
+    Scalar lam;
+    memcpy(lam.w, SCALAR_LAMBDA, sizeof lam.w);
+    r = k;
+    for (uint32_t e = 0; e < v % 3; e++) {
+        Scalar t;
+        scalar_mul_mod_n(t, r, lam);
+        r = t;
+    }
+    if (v >= 3) {
+        Scalar t;
+        scalar_negate(t, r);
+        r = t;
+    }
+}
+
 }  // namespace vg

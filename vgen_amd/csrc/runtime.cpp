@@ -216,6 +216,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     c->format = p->format;
     c->payload_words = p->format == VGF_P2TR ? 8 : 5;
     c->timing = (p->flags & VGEN_FLAG_TIMING) != 0;
+    c->endo = (p->flags & VGEN_FLAG_ENDO) != 0 && (p->format == VGF_P2PKH || p->format == VGF_P2WPKH);
     c->S = env_u32("VGEN_SEQ_S", 8);
     auto bail = [&](int st, const std::string &m) {
         err = m;
@@ -387,7 +388,7 @@ namespace {
 // Allocated once, when dump mode is first selected — never while a dispatch of this context is in flight.
 int ensure_dump_slab(vgen_ctx *c) {
     if (c->d_dump_slab) return VGEN_OK;
-    const size_t per = up256((size_t)c->batch * c->payload_words * sizeof(uint32_t));
+    const size_t per = up256((size_t)c->batch * (c->endo ? 6 : 1) * c->payload_words * sizeof(uint32_t));
     HIP_TRY(c, hipMalloc((void **)&c->d_dump_slab, per * c->frames));
     HIP_TRY(c, hipHostMalloc((void **)&c->h_dump_slab, per * c->frames, hipHostMallocDefault));
     for (uint32_t i = 0; i < c->frames; i++) {
@@ -453,13 +454,14 @@ int ensure_frame(vgen_ctx *c, uint32_t frame) {
 int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys) {
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.s_bwd));
     if (dump)
-        HIP_TRY(c, hipMemcpyAsync(f.h_dump, f.d_dump, (size_t)c->batch * c->payload_words * sizeof(uint32_t), hipMemcpyDeviceToHost, f.s_bwd));
+        HIP_TRY(c, hipMemcpyAsync(f.h_dump, f.d_dump, (size_t)std::max<uint64_t>(keys, c->batch) * c->payload_words * sizeof(uint32_t), hipMemcpyDeviceToHost, f.s_bwd));
     else
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.s_bwd));
     HIP_TRY(c, hipEventRecord(f.ev_done, f.s_bwd));
     f.in_flight = true;
     f.dumped = dump;
     f.keys_tested = keys;
+    f.endo_applied = keys > c->batch;
     return VGEN_OK;
 }
 
@@ -611,6 +613,9 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         }
     }
     a.fmt = c->format;
+    // six images per point where the kernels have that form: prefilter or dump mode (not the on-device DFA match)
+    const bool endo_now = c->endo && (dump || c->h_filter.kind != DEVF_DFA);
+    a.endo = endo_now ? 1u : 0u;
     if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
         if (int rc = ensure_gtab(c)) return rc;
         a.gtab = c->d_gtab;
@@ -634,7 +639,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     }
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_mid, f.s_bwd));
     HIP_TRY(c, launch_seq_bwd((int)c->format, a, f.s_bwd));
-    return finish_dispatch(c, f, dump, c->batch);
+    return finish_dispatch(c, f, dump, endo_now ? (uint64_t)c->batch * 6 : c->batch);
 }
 
 int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32_t n) {
@@ -725,7 +730,7 @@ int rt_dump_view(vgen_ctx *c, uint32_t frame, const uint8_t **ptr, size_t *len) 
     if (f.in_flight) return c->fail(VGEN_E_STATE, "vgen_read_dump before vgen_wait");
     if (!f.dumped || !f.h_dump) return c->fail(VGEN_E_STATE, "frame's last dispatch was not in dump mode");
     *ptr = f.h_dump;
-    if (len) *len = (size_t)c->batch * c->payload_words * sizeof(uint32_t);
+    if (len) *len = (size_t)std::max<uint64_t>(f.keys_tested, c->batch) * c->payload_words * sizeof(uint32_t);
     return VGEN_OK;
 }
 

@@ -26,6 +26,7 @@ struct vgen_ctx {
     vg::SeqBaseCache base_cache;         // host-side incremental base points (host_ec.h)
     uint32_t payload_words = 5;
     bool timing = false;                 // VGEN_FLAG_TIMING: events around every dispatch
+    bool endo = false;                   // VGEN_FLAG_ENDO on a compressed-key format: six keys per point where the kernels support it
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
     uint32_t *d_gtab = nullptr;          // 8-bit fixed-window generator table (arbitrary-scalar path, P2TR), built on first use
@@ -54,6 +55,7 @@ struct vgen_ctx {
         uint8_t *h_match = nullptr;      // pinned mirror
         bool in_flight = false;
         bool dumped = false;             // last dispatch ran in dump mode
+        bool endo_applied = false;       // last dispatch tested the six images of every point (keys_tested = 6 x batch)
         vg::Scalar start{};
         bool timing_fresh = true;        // last_ms / last_total_ms already read from the events
         float last_ms = 0.f;             // dominant kernel (seq_bwd) of the last completed dispatch

@@ -79,12 +79,21 @@ void random_valid_key(Scalar &k) {
     }
 }
 
+// `images`: 1, or 6 when the dispatch tested the endomorphism / negation images of every point: index is then
+// variant * batch + i and the key is variant `index / batch` of batch_start + i (host/scalar.h).
 bool make_match(const vgen_filter &flt, uint32_t format, const Scalar &batch_start, uint32_t index,
-                const uint8_t *payload, const Scalar *end, vgen_generated &g) {
+                const uint8_t *payload, const Scalar *end, vgen_generated &g, uint32_t batch = 0, uint32_t images = 1) {
     std::string addr = address_from_payload(format, payload);
     if (addr.empty() || !flt.dfa.is_match(addr)) return false;          // pattern.matches, gpu.rs:1069
     Scalar k;
+    const uint32_t variant = images > 1 ? index / batch : 0;
+    if (images > 1) index %= batch;
     if (scalar_add_u64(k, batch_start, index) || !scalar_is_valid(k)) return false;   // increment_key -> None
+    if (variant) {
+        Scalar kv;
+        scalar_variant(kv, k, variant);
+        k = kv;
+    }
     if (end && scalar_cmp(k, *end) > 0) return false;                   // gpu.rs:1074-1078
     uint8_t kb[32];
     scalar_to_be(k, kb);
@@ -334,6 +343,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                std::vector<vgen_generated> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
                bool *range_done = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
+    if (ctx->endo && (cfg->has_start || cfg->has_end || cfg->seed || cfg->n_shards > 1 || cfg->checkpoint_path))
+        return ctx->fail(VGEN_E_INVALID, "a VGEN_FLAG_ENDO context tests six images of every point, not a contiguous key range: "
+                                         "it serves unseeded random scans only (no start / end / seed / shards / checkpoint)");
 
     const uint32_t N = ctx->batch;
     const size_t pbytes = (size_t)ctx->payload_words * 4;
@@ -352,8 +364,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         return p;
     };
     bool host_all = flt.dev.kind == DEVF_HOST_ALL;
-    if (!host_all && flt.selectivity >= 0 && flt.selectivity * (double)N * 4 > (double)ctx->match_cap) {
-        const uint64_t want = next_pow2((uint64_t)(flt.selectivity * (double)N * 4));
+    const double keys_per_dispatch = (double)N * (ctx->endo && flt.dev.kind != DEVF_DFA ? 6 : 1);
+    if (!host_all && flt.selectivity >= 0 && flt.selectivity * keys_per_dispatch * 4 > (double)ctx->match_cap) {
+        const uint64_t want = next_pow2((uint64_t)(flt.selectivity * keys_per_dispatch * 4));
         if (want <= N / 2) {
             int rc = vgen_set_match_cap(ctx, (uint32_t)want);
             if (rc != VGEN_OK) return rc;
@@ -464,6 +477,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         const Scalar batch_start = pend[frame].start;
         pend[frame].valid = false;
         const bool dumped = ctx->fr[frame].dumped;
+        const uint32_t images = tested > N ? (uint32_t)(tested / N) : 1;   // 6 for an endomorphism dispatch
         bool cut = false;      // this batch: a confirmed (or unexamined) match was dropped because `count` was reached
 
         if (dumped) {
@@ -476,11 +490,12 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
             const unsigned nt = pool->size();
             std::vector<std::vector<vgen_generated>> part(nt);
+            const uint32_t total = (uint32_t)tested;   // N, or 6 N for an endomorphism dispatch
             pool->run([&](unsigned t) {
-                const uint32_t lo = (uint32_t)((uint64_t)N * t / nt), hi = (uint32_t)((uint64_t)N * (t + 1) / nt);
+                const uint32_t lo = (uint32_t)((uint64_t)total * t / nt), hi = (uint32_t)((uint64_t)total * (t + 1) / nt);
                 vgen_generated g;
                 for (uint32_t i = lo; i < hi; i++)
-                    if (make_match(flt, cfg->format, batch_start, i, dump + (size_t)i * pbytes, end, g)) part[t].push_back(g);
+                    if (make_match(flt, cfg->format, batch_start, i, dump + (size_t)i * pbytes, end, g, N, images)) part[t].push_back(g);
             });
             for (auto &p : part)
                 for (auto &g : p)
@@ -529,25 +544,25 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                     const uint32_t lo = (uint32_t)((uint64_t)n_found * t / nt), hi = (uint32_t)((uint64_t)n_found * (t + 1) / nt);
                     vgen_generated gg;
                     for (uint32_t k = lo; k < hi; k++)
-                        if (make_match(flt, cfg->format, batch_start, recs[k].index, recs[k].payload, end, gg)) part[t].push_back(gg);
+                        if (make_match(flt, cfg->format, batch_start, recs[k].index, recs[k].payload, end, gg, N, images)) part[t].push_back(gg);
                 });
                 for (auto &p : part)
                     for (auto &gg : p)
                         if (!push(gg)) cut = true;
             } else {
                 for (; i < n_found && (ck || found() < count); i++)
-                    if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g)) (void)push(g);
+                    if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g, N, images)) (void)push(g);
                 cut = i < n_found;   // candidates left unexamined (conservative: they may not all be matches)
             }
         }
 
-        total_ops += N;                              // gpu.rs:1106
+        total_ops += tested;                         // gpu.rs:1106 (batch_size; six times that for an endomorphism dispatch)
         // With a checkpoint a batch is committed with every match it holds (push above), also those beyond
         // `count`: the file stays a consistent prefix of the scan whatever count a later run asks for.
         cut_any = cut_any || cut;
-        if (ck) ck->commit(ck_slot, batch_matches, N);
+        if (ck) ck->commit(ck_slot, batch_matches, tested);
         batch_matches.clear();
-        if (cb) cb(shared_ops ? N : total_ops, user);   // multi-device: the wrapper adds N to the shared count under its lock
+        if (cb) cb(shared_ops ? tested : total_ops, user);   // multi-device: the wrapper adds N to the shared count under its lock
         if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
