@@ -464,8 +464,10 @@ def main():
               timed_config(vg, "p2pkh", "1[Oo]ri", False, args.batch, F, local_rank, sec, "unanchored pattern: full Base58Check + DFA match on the device"),
               timed_config(vg, "p2pkh", "^1Cat", False, args.batch, F, local_rank, sec,
                            "vanity search proper (VGEN_FLAG_ENDO): six keys per curve point — k, lambda k, lambda^2 k and their negations",
-                           note="what `vgen-hip generate` runs for unseeded P2PKH / P2WPKH searches; every dispatch tests 6 x 2^20 keys for one "
+                           note="what `vgen-hip generate` runs for unseeded searches (any format but P2TR); every dispatch tests 6 x 2^20 keys for one "
                                 "batch of point arithmetic; not a contiguous range, hence not the headline configuration", endo=True),
+              timed_config(vg, "p2wpkh", "dead$", False, args.batch, F, local_rank, sec, "BASELINE config 3 as a vanity search (VGEN_FLAG_ENDO)", endo=True),
+              timed_config(vg, "ethereum", "^0xdead", True, args.batch, F, local_rank, sec, "BASELINE config 5 (one GPU) as a vanity search (VGEN_FLAG_ENDO)", endo=True),
               keys_mode_config(vg, args.batch, min(F, 8), local_rank, sec)]
         oc += dump_mode_configs(vg, args.batch, local_rank, sec)
         out["other_configs"] = oc

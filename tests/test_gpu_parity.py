@@ -695,7 +695,7 @@ def variant_key(k, v):
     return N - kv if v >= 3 else kv
 
 
-@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("fmt", [0, 1, 2, 4, 5])
 def test_endomorphism_dump_is_the_oracle_on_all_six_images(vg, vo, fmt):
     """A dispatch of an endomorphism context tests, for every base key k0 + i, the keys k, lambda k, lambda^2 k and
     their negations (mod n); entry variant * batch + i of the dump must be the oracle's payload of exactly that key."""

@@ -337,7 +337,7 @@ struct SeqWaves {
     static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH : 4;
 };
 
-// ENDO (vanity searches; compressed-key formats with a prefilter or in dump mode): every point is tested under its six
+// ENDO (vanity searches; every format but P2TR, with a prefilter or in dump mode): every point is tested under its six
 // endomorphism / negation images — (x, +-y), (beta x, +-y), (beta^2 x, +-y), the public keys of k, lambda k, lambda^2 k and
 // their negations — so six keys are hashed for one point's arithmetic plus two multiplications by beta.  Image `variant`
 // = s * 3 + e (e = power of beta, s = negated) of key index i is reported / dumped at variant * n + i.
@@ -345,6 +345,7 @@ template <int FMT, bool FULL, bool ENDO = false>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SeqWaves<FMT>::value, SeqWaves<FMT>::value)))
 seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
+    __shared__ u32 ypark[ENDO && (FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM) ? 9 * WG : 1];   // ENDO: the point's y
     extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
@@ -480,12 +481,16 @@ seq_bwd_kernel(const SeqArgs args) {
 
             const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (ENDO) {
+                // compressed-key formats need only the parity of y (flipped for the negations); the others the canonical
+                // y itself, parked beside x, and p - y for the negations
+                constexpr bool NEEDS_Y = FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM;
                 const u32 ypar = y3.n[0] & 1u;
                 lds_park_fe(tree, WG, tid, x3);
+                if (NEEDS_Y) lds_park_fe(ypark, WG, tid, y3);
 #pragma unroll 1
                 for (u32 v = 0; v < 6; v++) {
                     const u32 e = v >> 1, sneg = v & 1u;   // (x,+) (x,-) (bx,+) (bx,-) (b^2 x,+) (b^2 x,-)
-                    fe xe;
+                    fe xe, ye;
                     lds_unpark_fe(tree, WG, tid, xe);
                     if (sneg == 0 && e > 0) {
                         fe beta;
@@ -494,10 +499,19 @@ seq_bwd_kernel(const SeqArgs args) {
                         fe_canonicalize_product(xe);
                         lds_park_fe(tree, WG, tid, xe);
                     }
-                    u32 xw[8], sha[8], ple[NW];
-                    fe_to_words(xe, xw);
-                    sha256_pub33(2u | (ypar ^ sneg), xw, sha);
-                    ripemd160_of_sha(sha, ple);
+                    if (NEEDS_Y) {
+                        lds_unpark_fe(ypark, WG, tid, ye);
+                        if (sneg) {
+                            fe ny;
+                            fe_neg(ny, ye, 1);
+                            fe_normalize(ny);      // p - y, canonical (y != 0 on this curve)
+                            ye = ny;
+                        }
+                    } else {
+                        ye.n[0] = ypar ^ sneg;     // all a compressed key reads of y
+                    }
+                    u32 ple[NW];
+                    (void)payload_from_point<FMT>(xe, ye, gtab, tree, ple);
                     const u32 vindex = (sneg * 3u + e) * args.n + index;
                     if (dump) {
                         u32 *o = args.dump + (size_t)vindex * NW;
@@ -966,7 +980,7 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
         return hipGetLastError();
     }
     if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
-    else if (a.endo && FMT == VGF_P2PKH) hipLaunchKernelGGL((seq_bwd_kernel<VGF_P2PKH, false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
+    else if (a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
     else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), bwd_lds_pad(), stream, a);
     return hipGetLastError();
 }

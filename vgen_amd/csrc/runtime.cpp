@@ -216,7 +216,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     c->format = p->format;
     c->payload_words = p->format == VGF_P2TR ? 8 : 5;
     c->timing = (p->flags & VGEN_FLAG_TIMING) != 0;
-    c->endo = (p->flags & VGEN_FLAG_ENDO) != 0 && (p->format == VGF_P2PKH || p->format == VGF_P2WPKH);
+    c->endo = (p->flags & VGEN_FLAG_ENDO) != 0 && p->format != VGF_P2TR;
     c->S = env_u32("VGEN_SEQ_S", 8);
     auto bail = [&](int st, const std::string &m) {
         err = m;

@@ -26,7 +26,7 @@ struct vgen_ctx {
     vg::SeqBaseCache base_cache;         // host-side incremental base points (host_ec.h)
     uint32_t payload_words = 5;
     bool timing = false;                 // VGEN_FLAG_TIMING: events around every dispatch
-    bool endo = false;                   // VGEN_FLAG_ENDO on a compressed-key format: six keys per point where the kernels support it
+    bool endo = false;                   // VGEN_FLAG_ENDO (any format but P2TR): six keys per point where the kernels support it
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
     uint32_t *d_gtab = nullptr;          // 8-bit fixed-window generator table (arbitrary-scalar path, P2TR), built on first use
