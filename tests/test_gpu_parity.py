@@ -753,6 +753,13 @@ def test_endomorphism_scan_returns_keys_that_really_own_their_addresses(vg, vo):
         with pytest.raises(vg.VgenError) as e:
             vg.scan_gpu_with_runner("^1Cat", cfg, r)
         assert "contiguous key range" in str(e.value)
+    # two contexts (one per GPU in production): each walks from a random base of its own, one shared match counter
+    r2 = vg.GpuRunner(batch_size=1 << 18, fmt=vg.AddressFormat.P2pkh, frames=4, endo=True)
+    res = vg.scan_gpu_with_runner("^1Cat", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=6), [r, r2])
+    assert len(res.matches) == 6 and len(set(m.hex for m in res.matches)) == 6
+    for m in res.matches:
+        assert vo.generate(0, int(m.hex, 16))["address"] == m.address and m.address.startswith("1Cat")
+    r2.close()
     # a pattern that needs the on-device DFA runs without the images (and says so through keys_tested)
     pat = vg.Pattern("Cat", False, vg.AddressFormat.P2pkh)
     assert pat.device_kind == 4

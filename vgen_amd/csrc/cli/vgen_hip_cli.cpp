@@ -149,7 +149,7 @@ void usage() {
             "  vgen-hip generate -p PATTERN [-f FORMAT] [-i] [-c COUNT] [-o text|json|jsonl|csv|minimal] [--file PATH]\n"
             "                    [--gpu-batch-size N] [--repeat N] [-q] [--seed S] [--devices 0,1,..|all] [--frames F]\n"
             "                    [--checkpoint FILE]   (resume an interrupted scan from FILE; written as the scan runs)\n"
-            "                    [--no-endo]           (unseeded searches on one device, any format but P2TR, test six keys per curve\n"
+            "                    [--no-endo]           (unseeded searches, any format but P2TR, test six keys per curve\n"
             "                                           point — k, lambda k, lambda^2 k and their negations; this walks k0 + i only)\n"
             "                    PATTERN may be a provider pattern boha:b1000:N [-l PREFIX_LENGTH] [--provider-table CSV]\n"
             "  vgen-hip range (--range START:END | --puzzle P) [-p PATTERN] [-f FORMAT] [-c COUNT (0 = whole range)] ...\n"
@@ -337,9 +337,9 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         p.batch_size = o.batch;
         p.format = (uint32_t)fmt;
         p.frames = o.frames;
-        // a vanity search proper — random base, no range, no seed, no checkpoint, one device — may test any keys it likes:
+        // a vanity search proper — random base, no range, no seed, no checkpoint — may test any keys it likes:
         // six images per curve point (VGEN_FLAG_ENDO, +30 % keys per second); everything else walks k0 + i
-        if (!o.no_endo && !has_range && !o.seed && o.checkpoint.empty() && devs.size() == 1 && fmt != 3) p.flags |= VGEN_FLAG_ENDO;
+        if (!o.no_endo && !has_range && !o.seed && o.checkpoint.empty() && fmt != 3) p.flags |= VGEN_FLAG_ENDO;
         vgen_ctx *c = nullptr;
         if (vgen_create(&p, &c) != VGEN_OK) die(std::string("GPU initialization failed: ") + vgen_last_error(nullptr));
         ctxs.push_back(c);

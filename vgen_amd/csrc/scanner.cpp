@@ -676,11 +676,21 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     vgen_scan_config base = *cfg;
     Checkpoint ck;
     Checkpoint *ckp = nullptr;
+    // Endomorphism contexts test images of points, not a range to stripe: every device walks from a random base of its
+    // own (disjoint with overwhelming probability, SURVEY.md 8(e) "random mode"), sharing the match counter.
+    bool endo = false;
+    for (uint32_t i = 0; i < n_ctx; i++) endo = endo || ctxs[i]->endo;
+    if (endo) {
+        for (uint32_t i = 0; i < n_ctx; i++)
+            if (!ctxs[i]->endo) return ctxs[0]->fail(VGEN_E_INVALID, "vgen_scan_multi: VGEN_FLAG_ENDO must be set on all contexts or on none");
+        if (cfg->has_start || cfg->has_end || cfg->seed || cfg->checkpoint_path)
+            return ctxs[0]->fail(VGEN_E_INVALID, "VGEN_FLAG_ENDO contexts serve unseeded random scans only (no start / end / seed / checkpoint)");
+    }
     if (cfg->checkpoint_path) {
         int rc = open_checkpoint(ctxs[0], ck, pattern, base, ctxs[0]->batch, n_ctx, 0, n_ctx);
         if (rc != VGEN_OK) return rc;
         ckp = &ck;
-    } else {
+    } else if (!endo) {
         resolve_base(base);   // all shards must walk the same base key
     }
     std::atomic<uint64_t> found{0}, ops_shared{0};
@@ -703,8 +713,8 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     for (uint32_t i = 0; i < n_ctx && !skip_all; i++)
         th.emplace_back([&, i]() {
             vgen_scan_config c = base;
-            c.shard = i;
-            c.n_shards = n_ctx;
+            c.shard = endo ? 0 : i;
+            c.n_shards = endo ? 0 : n_ctx;
             bool rd = false;
             rcs[i] = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
                                 part[i], ops[i], ckp, i, &rd);
