@@ -753,6 +753,14 @@ def test_endomorphism_scan_returns_keys_that_really_own_their_addresses(vg, vo):
         with pytest.raises(vg.VgenError) as e:
             vg.scan_gpu_with_runner("^1Cat", cfg, r)
         assert "contiguous key range" in str(e.value)
+    # a pattern nearly every key matches goes through full dumps and host filtering: six images per point there too
+    rs = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=2, endo=True)
+    res = vg.scan_gpu_with_runner("^1[2-9A-Za-z]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=300), rs)
+    assert len(res.matches) == 300 and res.operations % (6 * 8192) == 0
+    for m in res.matches:
+        assert vo.generate(0, int(m.hex, 16))["address"] == m.address and re.match("^1[2-9A-Za-z]", m.address)
+    assert len(set(m.hex for m in res.matches)) == 300
+    rs.close()
     # two contexts (one per GPU in production): each walks from a random base of its own, one shared match counter
     r2 = vg.GpuRunner(batch_size=1 << 18, fmt=vg.AddressFormat.P2pkh, frames=4, endo=True)
     res = vg.scan_gpu_with_runner("^1Cat", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=6), [r, r2])
