@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--format", default="p2pkh", choices=sorted(FORMATS))
     ap.add_argument("--pattern", default="^1Cat")
     ap.add_argument("--ci", action="store_true")
+    ap.add_argument("--endo", action="store_true", help="profiling aid: run the legs on a VGEN_FLAG_ENDO context (six keys per curve "
+                                                        "point; NOT the BASELINE configuration, and said so in config.workload)")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="wall time of the `sustained` leg (0 = skip)")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -302,10 +304,11 @@ def main():
     fmt = vg.AddressFormat(FORMATS[args.format])
     # (no per-dispatch HIP events on the measured runner: they cost the host ~5 us per dispatch, which a short timed
     # region feels; launch durations are sampled afterwards on a runner of their own)
-    runner = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=args.frames, timing=False)
+    runner = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=args.frames, timing=False, endo=args.endo)
     pat = vg.Pattern(args.pattern, args.ci, fmt)
     runner.set_filter(pat if pat.device_kind != 0 else None)
     N, F = runner.batch_size, runner.frames
+    K6 = 6 if args.endo else 1          # keys per dispatch = K6 x N
     pipe = Pipeline(runner, seed_key(42, 0), world, rank)
 
     def barrier():
@@ -336,7 +339,7 @@ def main():
     cand, _ = pipe.run_steps(args.steps)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    keys = world * args.steps * N
+    keys = world * args.steps * N * K6
     value = keys / elapsed / 1e6
 
     # ---- the same loop for >= 3 s of wall time ----
@@ -356,7 +359,7 @@ def main():
             n_total = n_s
         if pipe.clk_ticks:   # MHz the CUs ran at, sampled by the seq_bwd launches of this leg themselves
             shader_mhz = pipe.clk_cycles / pipe.clk_ticks * 100.0
-        sustained = {"value": round(n_total * N / dt_s / 1e6, 2), "unit": "Mkeys/sec", "seconds": round(dt_s, 3),
+        sustained = {"value": round(n_total * N * K6 / dt_s / 1e6, 2), "unit": "Mkeys/sec", "seconds": round(dt_s, 3),
                      "dispatches": n_total, "frames_in_flight": F}
 
     w_key = work_per_key(args.format)
@@ -364,7 +367,7 @@ def main():
     # seq_fwd_kernel (half an F_p multiplication per key: 74 imul + 60 iop per multiplication)
     w_bwd = w_key - (74 * R_MUL + 60) // 2
     # HIP-event durations of seq_bwd launches while the frames overlap (informational), from a short run of their own
-    rt = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=args.frames, timing=True)
+    rt = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=args.frames, timing=True, endo=args.endo)
     rt.set_filter(pat if pat.device_kind != 0 else None)
     pt = Pipeline(rt, seed_key(42, 0), world, rank)
     pt.run_steps(2 * F)
@@ -414,7 +417,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic (sequential scalars from k0 = SHA-256('vgen-mi355x'||seed=42||shard=0) mod n)",
         "config": {"workload": f"{args.format} pattern {args.pattern!r}{' -i' if args.ci else ''}, "
-                               f"{N} keys/dispatch, compressed pubkey, sequential-range mode",
+                               + (f"{N} curve points/dispatch x 6 endomorphism / negation images (NOT the BASELINE configuration)" if args.endo
+                                  else f"{N} keys/dispatch, compressed pubkey, sequential-range mode"),
                    "keys_per_dispatch": N, "frames_in_flight": F, "topology": runner.topology(),
                    "parallelism": f"range-striped x{world}" + (" (REHEARSAL: ranks share a GPU)" if rehearse else ""),
                    "device_filter_kind": pat.device_kind, "candidates_reported": cand},
@@ -424,7 +428,7 @@ def main():
     if rank == 0 and world == 1:
         # the kernel alone: frames = 1, so every launch has the chip to itself (one wave per SIMD), HIP events
         # recorded on the launch's own stream immediately before and after seq_bwd_kernel
-        r1 = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=1)
+        r1 = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=1, endo=args.endo)
         r1.set_filter(pat if pat.device_kind != 0 else None)
         p1 = Pipeline(r1, seed_key(42, 0))
         p1.run_steps(8)
@@ -432,19 +436,19 @@ def main():
         r1.close()
         lone = sum(k1) / len(k1)
         roofline["lone_launch"] = {"avg_launch_ms": round(lone, 4), "launches": len(k1),
-                                   "achieved": round(N * w_bwd / (lone * 1e-3) / 1e12, 3),
-                                   "frac": round(N * w_bwd / (lone * 1e-3) / 1e12 / PEAK_TLANEOPS, 4),
-                                   "keys_per_s_equivalent": round(N / (lone * 1e-3) / 1e6, 1)}
+                                   "achieved": round(N * K6 * w_bwd / (lone * 1e-3) / 1e12, 3),
+                                   "frac": round(N * K6 * w_bwd / (lone * 1e-3) / 1e12 / PEAK_TLANEOPS, 4),
+                                   "keys_per_s_equivalent": round(N * K6 / (lone * 1e-3) / 1e6, 1)}
         # time-to-first-match (the second half of BASELINE.json's metric): a `generate -c 1` style scan
         # through the scanner (vgen_scan), warm = existing context, cold = including context creation
         # (offset-table build + allocations; the HIP runtime itself is already initialised here)
         t1 = time.perf_counter()
-        res = vg.scan_gpu_with_runner(args.pattern, vg.ScanConfig(format=fmt, count=1, seed=43,
+        res = vg.scan_gpu_with_runner(args.pattern, vg.ScanConfig(format=fmt, count=1, seed=0 if args.endo else 43,
                                                                   case_insensitive=args.ci), runner)
         warm = time.perf_counter() - t1
         t1 = time.perf_counter()
-        r2 = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=args.frames)
-        res2 = vg.scan_gpu_with_runner(args.pattern, vg.ScanConfig(format=fmt, count=1, seed=44,
+        r2 = vg.GpuRunner(batch_size=args.batch, fmt=fmt, device=local_rank, frames=args.frames, endo=args.endo)
+        res2 = vg.scan_gpu_with_runner(args.pattern, vg.ScanConfig(format=fmt, count=1, seed=0 if args.endo else 44,
                                                                    case_insensitive=args.ci), r2)
         cold = time.perf_counter() - t1
         r2.close()
