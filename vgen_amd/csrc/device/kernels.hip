@@ -90,16 +90,19 @@ __device__ __forceinline__ void lds_load_fe(const u32 *base, int stride, int col
     for (int i = 0; i < 9; i++) a.n[i] = base[i * stride + col];
 }
 
-// A field element parked in LDS across a register-hungry stretch (volatile: the compiler must not keep a copy in
-// registers and forward it to the reload).
+// A field element parked in LDS across a register-hungry stretch.  Volatile, so that the compiler does not keep a copy
+// in registers and forward it to the reload — and through an explicit LDS address-space pointer: a volatile access
+// through a generic pointer compiles to flat_store / flat_load with system scope and a 64-bit address per limb.
+typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
+
 __device__ __forceinline__ void lds_park_fe(u32 *base, int stride, int col, const fe &a) {
-    volatile u32 *b = base;
+    lds_vu32 *b = (lds_vu32 *)base;
 #pragma unroll
     for (int i = 0; i < 9; i++) b[i * stride + col] = a.n[i];
 }
 
 __device__ __forceinline__ void lds_unpark_fe(u32 *base, int stride, int col, fe &a) {
-    volatile u32 *b = base;
+    lds_vu32 *b = (lds_vu32 *)base;
 #pragma unroll
     for (int i = 0; i < 9; i++) a.n[i] = b[i * stride + col];
 }
