@@ -45,3 +45,27 @@ for fmt, batch in ((0, 16384), (5, 16384), (2, 32768), (3, 8192)):
             runs2 += 1; keys2 += batch
     r.close()
 print("concurrent soak ok: %d dispatches (12 in flight), %d keys, %.0f s" % (runs2, keys2, time.time() - t1))
+
+# third phase: endomorphism contexts — image 0 in full, the other five sampled, random bases, per format
+t1 = time.time()
+LAM = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+runs3 = keys3 = 0
+for fmt in (0, 1, 2, 4, 5):
+    batch = 16384
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=2, endo=True)
+    r.set_filter(None)
+    t2 = time.time()
+    while time.time() - t2 < budget / 10:
+        start = min(rng.randrange(1, N) >> rng.randrange(0, 200) or 1, N - batch - 20)
+        r.dispatch(start, 0)
+        blob, _, tested = r.await_result(0)
+        assert tested == 6 * batch
+        assert blob[:20 * batch] == vo.payload_seq(fmt, start, batch), (fmt, hex(start))
+        for _ in range(300):
+            v, i = rng.randrange(1, 6), rng.randrange(batch)
+            k = pow(LAM, v % 3, N) * (start + i) % N
+            k = N - k if v >= 3 else k
+            assert blob[20 * (v * batch + i):20 * (v * batch + i) + 20] == vo.payload(fmt, k), (fmt, hex(start), v, i)
+        runs3 += 1; keys3 += 6 * batch
+    r.close()
+print("endomorphism soak ok: %d dispatches, %d keys (image 0 in full, 300 sampled images per dispatch), %.0f s" % (runs3, keys3, time.time() - t1))
