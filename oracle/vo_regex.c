@@ -194,7 +194,27 @@ static int unicode_class_members(const char *n, uint8_t t[16]) {
         "finalpunctuation", "so", "othersymbol", "zl", "lineseparator", "zp", "paragraphseparator", "cf", "format", "cs", "surrogate",
         "co", "privateuse", "cn", "unassigned", "greek", "grek", "cyrillic", "cyrl", "han", "hani", "arabic", "arab", "hebrew", "hebr",
         "hiragana", "hira", "katakana", "kana", "hangul", "hang", "thai", "devanagari", "deva", "armenian", "armn", "georgian", "geor",
-        "inherited", "zinh", "unknown", "zzzz", NULL};
+        "inherited", "zinh", "unknown", "zzzz",
+        /* the other scripts of Unicode 16 (long names): none has an ASCII member */
+        "adlam", "ahom", "anatolianhieroglyphs", "avestan", "balinese", "bamum", "bassavah", "batak", "bengali",
+        "bhaiksuki", "bopomofo", "brahmi", "braille", "buginese", "buhid", "canadianaboriginal", "carian",
+        "caucasianalbanian", "chakma", "cham", "cherokee", "chorasmian", "coptic", "cuneiform", "cypriot",
+        "cyprominoan", "deseret", "divesakuru", "dogra", "duployan", "egyptianhieroglyphs", "elbasan", "elymaic",
+        "ethiopic", "garay", "glagolitic", "gothic", "grantha", "gujarati", "gunjalagondi", "gurmukhi",
+        "gurungkhema", "hanifirohingya", "hanunoo", "hatran", "imperialaramaic", "inscriptionalpahlavi",
+        "inscriptionalparthian", "javanese", "kaithi", "kannada", "kawi", "kayahli", "kharoshthi",
+        "khitansmallscript", "khmer", "khojki", "khudawadi", "kiratrai", "lao", "lepcha", "limbu", "lineara",
+        "linearb", "lisu", "lycian", "lydian", "mahajani", "makasar", "malayalam", "mandaic", "manichaean",
+        "marchen", "masaramgondi", "medefaidrin", "meeteimayek", "mendekikakui", "meroiticcursive",
+        "meroitichieroglyphs", "miao", "modi", "mongolian", "mro", "multani", "myanmar", "nabataean", "nagmundari",
+        "nandinagari", "newa", "newtailue", "nko", "nushu", "nyiakengpuachuehmong", "ogham", "olchiki",
+        "oldhungarian", "olditalic", "oldnortharabian", "oldpermic", "oldpersian", "oldsogdian", "oldsoutharabian",
+        "oldturkic", "olduyghur", "olonal", "oriya", "osage", "osmanya", "pahawhhmong", "palmyrene", "paucinhau",
+        "phagspa", "phoenician", "psalterpahlavi", "rejang", "runic", "samaritan", "saurashtra", "sharada",
+        "shavian", "siddham", "signwriting", "sinhala", "sogdian", "sorasompeng", "soyombo", "sundanese", "sunuwar",
+        "sylotinagri", "syriac", "tagalog", "tagbanwa", "taile", "taitham", "taiviet", "takri", "tamil", "tangsa",
+        "tangut", "telugu", "thaana", "tibetan", "tifinagh", "tirhuta", "todhri", "toto", "tulutigalari",
+        "ugaritic", "vai", "vithkuqi", "wancho", "warangciti", "yezidi", "yi", "zanabazarsquare", NULL};
     memset(t, 0, 16);
     if (name_in(n, empty)) return 1;
     if (!strcmp(n, "any") || !strcmp(n, "ascii") || !strcmp(n, "assigned")) {

@@ -50,7 +50,8 @@ EXPECT = [
     (r"[^a-z&&b]", "b", 0), (r"[^a-z&&b]", "a", 1), (r"[\w&&[^\d_]]+", "__1a", 1), (r"[\w&&[^\d_]]+$", "a1", 0),
     (r"[a&&b]", "a", 0), (r"[[a-c][x-z]]", "y", 1), (r"[a[b[c]]]+$", "abc", 1), (r"[\[\]]", "]", 1), (r"[]a]", "]", 1), (r"[^]a]", "]", 0),
     (r"\p{Lu}\p{Ll}+", "Hello", 1), (r"\pN", "a1", 1), (r"\PN", "11", 0), (r"\p{^L}", "ab", 0), (r"\p{^L}", "a1", 1),
-    (r"\p{Greek}", "abc", 0), (r"\P{Greek}", "a", 1), (r"\p{gc=Lu}", "aB", 1), (r"\p{gc!=Lu}", "AB", 0), (r"\p{sc=Latin}+$", "Ab", 1),
+    (r"\p{Greek}", "abc", 0), (r"\P{Greek}", "a", 1), (r"\p{Tamil}", "abc", 0), (r"\P{Old_Turkic}+$", "a1_", 1), (r"[\p{Hangul}a]", "a", 1),
+    (r"\p{sc=Canadian_Aboriginal}", "x", 0), (r"\p{gc=Lu}", "aB", 1), (r"\p{gc!=Lu}", "AB", 0), (r"\p{sc=Latin}+$", "Ab", 1),
     (r"\p{Uppercase_Letter}", "ab", 0), (r"\p{ uppercase-LETTER }", "aB", 1), (r"[\p{Nd}\p{Lu}]+$", "A1B2", 1), (r"\p{P}", "a-b", 1),
     (r"\p{S}", "a-b", 0), (r"\p{S}", "a+b", 1), (r"\p{Zs}", "a b", 1), (r"\p{Cc}", "a\tb", 1), (r"\p{Alphabetic}+$", "ab", 1),
     (r"\p{ASCII_Hex_Digit}{2}$", "fF", 1), (r"\p{Any}", "", 0), (r"\p{ascii}+$", "a~", 1), (r"\p{Common}", "ab", 0), (r"\p{Pc}", "a_b", 1),

@@ -162,6 +162,28 @@ const PropName PROPS[] = {
     {"patternwhitespace", "\x09\x0d  "}, {"patternsyntax", "!/:@[^``{~"}, {"terminalpunctuation", "!!,,..:;??"},
 };
 
+// Scripts without any ASCII member (Unicode 16 long names; the frequent ones with their four-letter codes are in PROPS):
+// \p{Tamil} matches no address character, \P{Tamil} every one.
+const char *const SCRIPTS_WITHOUT_ASCII[] = {
+    "adlam", "ahom", "anatolianhieroglyphs", "avestan", "balinese", "bamum", "bassavah", "batak", "bengali",
+    "bhaiksuki", "bopomofo", "brahmi", "braille", "buginese", "buhid", "canadianaboriginal", "carian",
+    "caucasianalbanian", "chakma", "cham", "cherokee", "chorasmian", "coptic", "cuneiform", "cypriot",
+    "cyprominoan", "deseret", "divesakuru", "dogra", "duployan", "egyptianhieroglyphs", "elbasan", "elymaic",
+    "ethiopic", "garay", "glagolitic", "gothic", "grantha", "gujarati", "gunjalagondi", "gurmukhi", "gurungkhema",
+    "hanifirohingya", "hanunoo", "hatran", "imperialaramaic", "inscriptionalpahlavi", "inscriptionalparthian",
+    "javanese", "kaithi", "kannada", "kawi", "kayahli", "kharoshthi", "khitansmallscript", "khmer", "khojki",
+    "khudawadi", "kiratrai", "lao", "lepcha", "limbu", "lineara", "linearb", "lisu", "lycian", "lydian", "mahajani",
+    "makasar", "malayalam", "mandaic", "manichaean", "marchen", "masaramgondi", "medefaidrin", "meeteimayek",
+    "mendekikakui", "meroiticcursive", "meroitichieroglyphs", "miao", "modi", "mongolian", "mro", "multani",
+    "myanmar", "nabataean", "nagmundari", "nandinagari", "newa", "newtailue", "nko", "nushu",
+    "nyiakengpuachuehmong", "ogham", "olchiki", "oldhungarian", "olditalic", "oldnortharabian", "oldpermic",
+    "oldpersian", "oldsogdian", "oldsoutharabian", "oldturkic", "olduyghur", "olonal", "oriya", "osage", "osmanya",
+    "pahawhhmong", "palmyrene", "paucinhau", "phagspa", "phoenician", "psalterpahlavi", "rejang", "runic",
+    "samaritan", "saurashtra", "sharada", "shavian", "siddham", "signwriting", "sinhala", "sogdian", "sorasompeng",
+    "soyombo", "sundanese", "sunuwar", "sylotinagri", "syriac", "tagalog", "tagbanwa", "taile", "taitham",
+    "taiviet", "takri", "tamil", "tangsa", "tangut", "telugu", "thaana", "tibetan", "tifinagh", "tirhuta", "todhri",
+    "toto", "tulutigalari", "ugaritic", "vai", "vithkuqi", "wancho", "warangciti", "yezidi", "yi", "zanabazarsquare"};
+
 // NUL cannot be written in the member strings above: U+0000 is added for the classes that contain it.
 bool prop_has_nul(const std::string &n) {
     return n == "any" || n == "ascii" || n == "assigned" || n == "c" || n == "other" || n == "cc" || n == "control" || n == "cntrl" ||
@@ -262,6 +284,11 @@ class Parser {
 
     static bool lookup_prop(const std::string &name, CharSet &t) {
         const std::string n = loose(name);
+        for (const char *sc : SCRIPTS_WITHOUT_ASCII)
+            if (n == sc) {
+                t.other = true;
+                return true;
+            }
         for (const PropName &p : PROPS)
             if (n == p.name) {
                 for (const char *m = p.members; m[0]; m += 2) t.add_range((unsigned char)m[0], (unsigned char)m[1]);
