@@ -13,7 +13,7 @@ for rep in range(3):
         r.dispatch(key, f); key += N
     for f in range(F):
         r.wait(f)
-    time.sleep(0.01)
+    time.sleep(float(sys.argv[3]) if len(sys.argv) > 3 else 0.01)
     ev = []
     t0 = time.perf_counter()
     issued = done = 0
