@@ -68,7 +68,7 @@ typedef struct vgen_params {
     uint32_t batch_size;   /* keys per dispatch; reference default 524288 (gpu.rs:83); must be a
                               multiple of 8192; 0 selects 1048576 */
     uint32_t format;       /* vgen_format */
-    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 2; max 20 (64 with
+    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 12; max 20 (64 with
                               VGEN_STREAMS=A,B).  One dispatch is one wave per SIMD, so throughput grows with the frames
                               in flight: 7.4 / 11.4 / 12.0 / 12.1 Gkeys/s at 2 / 4 / 8 / 12 (P2PKH, 2^20 keys each).  The
                               first twelve frames get a hardware queue each (vgen_get_topology), whatever

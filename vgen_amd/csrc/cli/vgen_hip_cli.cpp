@@ -31,7 +31,7 @@ struct Opts {
     bool has_pattern = false, ignore_case = false, quiet = false, json = false, no_gpu = false;
     uint64_t count = 1, repeat = 1, seed = 0;
     bool no_endo = false;
-    uint32_t batch = 1u << 20, frames = 16;
+    uint32_t batch = 1u << 20, frames = 12;   // twelve frames own twelve hardware queues (runtime.cpp)
     int puzzle = 0;
     long prefix_length = -1;   // -l / --prefix-length (provider patterns)
 };

@@ -211,7 +211,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     vgen_ctx *c = new vgen_ctx();
     c->device = p->device;
     c->batch = p->batch_size ? p->batch_size : (1u << 20);
-    c->frames = p->frames ? p->frames : 2;
+    c->frames = p->frames ? p->frames : 12;   // the engine's own optimum (the reference's wgpu runner keeps 2, src/gpu.rs:399)
     c->match_cap = p->match_cap ? p->match_cap : 4096;
     c->format = p->format;
     c->payload_words = p->format == VGF_P2TR ? 8 : 5;
