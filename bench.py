@@ -51,8 +51,27 @@ PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 N_SIMD = 256 * 4
 
 
-def work_per_key(fmt_name):
-    return W_IMUL[fmt_name] * R_MUL + W_IOP[fmt_name]
+W_EC_IMUL, W_EC_IOP = 518, 550       # the batched affine addition's share of W (per curve point)
+W_FMUL_IMUL, W_FMUL_IOP = 57, 60     # one more field multiplication
+
+
+def work_per_key(fmt_name, endo=False):
+    """W of one key.  With VGEN_FLAG_ENDO a curve point serves six keys: its addition is shared by six, two field
+    multiplications (beta x, beta^2 x) are added per point, and every key still pays its own hashes.  None for P2TR:
+    its tweak now runs on the 20-bit window table (13 mixed additions instead of 64) and no estimate of that
+    path's work was ever pinned by counters — the entry reports the rate only."""
+    if fmt_name == "p2tr":
+        return None
+    w = W_IMUL[fmt_name] * R_MUL + W_IOP[fmt_name]
+    if endo:
+        ec = W_EC_IMUL * R_MUL + W_EC_IOP
+        w = w - ec + (ec + 2 * (W_FMUL_IMUL * R_MUL + W_FMUL_IOP)) / 6.0
+    return w
+
+
+def chip_frac(rate, fmt_name, endo=False):
+    w = work_per_key(fmt_name, endo)
+    return None if w is None else round(rate * w / 1e12 / PEAK_TLANEOPS, 4)
 
 
 def seed_key(seed, shard=0):
@@ -175,7 +194,7 @@ def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, labe
     rate = n * batch * (6 if endo else 1) / dt
     out = {"config": label, "format": fmt_name, "pattern": pattern + (" -i" if ci else ""), "value": round(rate / 1e6, 1),
            "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": n, "device_filter_kind": pat.device_kind,
-           "chip_frac": round(rate * work_per_key(fmt_name) / 1e12 / PEAK_TLANEOPS, 4)}
+           "chip_frac": chip_frac(rate, fmt_name, endo), "work_per_key": work_per_key(fmt_name, endo)}
     if note:
         out["note"] = note
     return out
@@ -362,10 +381,10 @@ def main():
         sustained = {"value": round(n_total * N * K6 / dt_s / 1e6, 2), "unit": "Mkeys/sec", "seconds": round(dt_s, 3),
                      "dispatches": n_total, "frames_in_flight": F}
 
-    w_key = work_per_key(args.format)
+    w_key = work_per_key(args.format, args.endo)
     # the dominant kernel (seq_bwd_kernel) does everything except the per-lane prefix products of
     # seq_fwd_kernel (half an F_p multiplication per key: 74 imul + 60 iop per multiplication)
-    w_bwd = w_key - (74 * R_MUL + 60) // 2
+    w_bwd = None if w_key is None else w_key - (74 * R_MUL + 60) // 2 / K6
     # HIP-event durations of seq_bwd launches while the frames overlap (informational), from a short run of their own
     avg_ms = in_flight = None
     try:
@@ -381,7 +400,7 @@ def main():
         in_flight = round(sum(kms) * 1e-3 / elapsed_ov, 2)
     except Exception:   # noqa: BLE001  (informational only)
         pass
-    chip = value * 1e6 / world * w_key / 1e12
+    chip = None if w_key is None else value * 1e6 / world * w_key / 1e12
     traffic = None
     pmc = {}
     try:   # issue-side counters and HBM bytes per launch from the committed PMC passes (profiles/)
@@ -390,8 +409,8 @@ def main():
     except (OSError, ValueError):
         pass
     roofline = {
-        "bound": "valu", "achieved": round(chip, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
-        "frac": round(chip / PEAK_TLANEOPS, 4), "traffic": traffic,
+        "bound": "valu", "achieved": None if chip is None else round(chip, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
+        "frac": None if chip is None else round(chip / PEAK_TLANEOPS, 4), "traffic": traffic,
         "work_per_key": w_key, "kernel": "seq_bwd_kernel", "kernel_work_per_key": w_bwd,
         "hbm_gb_per_s": round(traffic * args.steps / elapsed / 1e9, 1) if traffic else None,
         "hbm_frac_of_8TBps": round(traffic * args.steps / elapsed / 8e12, 4) if traffic else None,
@@ -405,7 +424,7 @@ def main():
                 "rocprofv3 PMC pass).  avg_launch_ms_overlapped is the HIP-event duration of a launch while ~"
                 "mean_launches_in_flight of them share the chip; it is reported, not multiplied back.",
     }
-    if sustained:
+    if sustained and w_key is not None:
         s_chip = sustained["value"] * 1e6 / world * w_key / 1e12
         roofline["achieved_sustained"] = round(s_chip, 3)
         roofline["frac_sustained"] = round(s_chip / PEAK_TLANEOPS, 4)
@@ -442,8 +461,8 @@ def main():
             r1.close()
             lone = sum(k1) / len(k1)
             roofline["lone_launch"] = {"avg_launch_ms": round(lone, 4), "launches": len(k1),
-                                       "achieved": round(N * K6 * w_bwd / (lone * 1e-3) / 1e12, 3),
-                                       "frac": round(N * K6 * w_bwd / (lone * 1e-3) / 1e12 / PEAK_TLANEOPS, 4),
+                                       "achieved": None if w_bwd is None else round(N * K6 * w_bwd / (lone * 1e-3) / 1e12, 3),
+                                       "frac": None if w_bwd is None else round(N * K6 * w_bwd / (lone * 1e-3) / 1e12 / PEAK_TLANEOPS, 4),
                                        "keys_per_s_equivalent": round(N * K6 / (lone * 1e-3) / 1e6, 1)}
         except Exception as e:   # noqa: BLE001  (an auxiliary leg never costs the headline line)
             roofline["lone_launch"] = {"error": f"{type(e).__name__}: {e}"}
