@@ -14,7 +14,8 @@ max-over-ranks of the elapsed time.
 
 The JSON line: `value` is measured over EXACTLY --steps dispatches between two barrier+synchronize brackets (the
 contract).  Because a short region is mostly pipeline fill and drain (20 steps = 2 ms), the same loop is also run
-for >= 3 s of wall time: `sustained`.  Further objects: `roofline` (integer-VALU bound; SURVEY.md §8(d) yardstick
+for >= 3 s of wall time: `sustained` — before the contract's region, so that the region is measured on a device at its
+steady clocks (the metric is a steady-state rate; out of idle the shader clock needs milliseconds to come up).  Further objects: `roofline` (integer-VALU bound; SURVEY.md §8(d) yardstick
 re-based on measured issue rates; chip-level fraction from wall time, the kernel's lone-launch rate from a
 frames=1 pass timed with HIP events, and the issue-side counters VALU-busy / instructions per key from the
 committed PMC pass under profiles/), `other_configs` (the other single-GPU BASELINE configurations and modes,
@@ -342,26 +343,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # warm-up: the first pass over the frames also creates their streams (milliseconds each), so the step time
-    # that sizes the clock probe is taken from the rest of the warm-up only
-    if args.warmup < F:   # set-up, not a step: every frame gets its stream before anything is timed
-        pipe.run_steps(F)
-    w_first = min(args.warmup, F)
-    pipe.run_steps(w_first)
-    tw = time.perf_counter()
-    pipe.run_steps(args.warmup - w_first)
+    # set-up, not a step: every frame gets its stream (milliseconds each, created at first use) before anything is timed
+    pipe.run_steps(F)
     barrier()
-    per_step_ms = (time.perf_counter() - tw) / max(1, args.warmup - w_first) * 1e3 if args.warmup > w_first else 0.0
 
-    # ---- the contract's timed region: exactly --steps dispatches between two barrier + synchronize brackets ----
-    t0 = time.perf_counter()
-    cand, _ = pipe.run_steps(args.steps)
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    keys = world * args.steps * N * K6
-    value = keys / elapsed / 1e6
-
-    # ---- the same loop for >= 3 s of wall time ----
+    # ---- the same loop for >= 3 s of wall time.  It runs BEFORE the contract's region: BASELINE.json's metric is a
+    # steady-state rate, and a device coming out of idle spends its first milliseconds below its steady shader clock
+    # (tools/ramp_trace.py: ~2.18 GHz over a 2 ms burst after idle against 2.38 GHz sustained), which is all a
+    # 20-step region would see ----
     sustained = None
     shader_mhz = None
     if args.sustained_seconds > 0:
@@ -380,6 +369,27 @@ def main():
             shader_mhz = pipe.clk_cycles / pipe.clk_ticks * 100.0
         sustained = {"value": round(n_total * N * K6 / dt_s / 1e6, 2), "unit": "Mkeys/sec", "seconds": round(dt_s, 3),
                      "dispatches": n_total, "frames_in_flight": F}
+
+    # ---- the contract's --warmup untimed steps ----
+    pipe.run_steps(args.warmup)
+    barrier()
+
+    # ---- the contract's timed region: exactly --steps dispatches between two barrier + synchronize brackets ----
+    t0 = time.perf_counter()
+    cand, _ = pipe.run_steps(args.steps)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    keys = world * args.steps * N * K6
+    value = keys / elapsed / 1e6
+    # shader clock during the region, from the samples its last min(F, steps) seq_bwd launches left in their frames
+    # (read after the region: nothing is added to the timed loop)
+    region_mhz = None
+    try:
+        cs = [runner.frame_clock(f) for f in range(min(F, args.steps))]
+        if sum(t for _, t in cs):
+            region_mhz = round(sum(c for c, _ in cs) / sum(t for _, t in cs) * 100.0)
+    except Exception:   # noqa: BLE001  (dump-mode runs carry no clock sample)
+        pass
 
     w_key = work_per_key(args.format, args.endo)
     # the dominant kernel (seq_bwd_kernel) does everything except the per-lane prefix products of
@@ -428,6 +438,8 @@ def main():
         s_chip = sustained["value"] * 1e6 / world * w_key / 1e12
         roofline["achieved_sustained"] = round(s_chip, 3)
         roofline["frac_sustained"] = round(s_chip / PEAK_TLANEOPS, 4)
+        if region_mhz:
+            roofline["shader_clock_mhz_timed_region"] = region_mhz
         if shader_mhz:
             roofline["shader_clock_mhz"] = round(shader_mhz)
             roofline["frac_sustained_at_shader_clock"] = round(s_chip / (PEAK_TLANEOPS * shader_mhz / 2400.0), 4)

@@ -15,6 +15,7 @@ for rep in range(3):
         r.wait(f)
     time.sleep(float(sys.argv[3]) if len(sys.argv) > 3 else 0.01)
     ev = []
+    mhz = []
     t0 = time.perf_counter()
     issued = done = 0
     for f in range(min(F, K)):
@@ -24,6 +25,8 @@ for rep in range(3):
     while done < K:
         r.wait(fw); done += 1
         ev.append(("w", done, (time.perf_counter() - t0) * 1e6))
+        cyc, tck = r.frame_clock(fw)
+        mhz.append(round(cyc / tck * 100) if tck else 0)
         if issued < K:
             r.dispatch(key, fw); key += N; issued += 1
             ev.append(("d", issued, (time.perf_counter() - t0) * 1e6))
@@ -31,3 +34,4 @@ for rep in range(3):
     total = (time.perf_counter() - t0) * 1e6
     print("F=%d K=%d total %.0f us = %.0f Mkeys/s" % (F, K, total, K * N / total))
 print(" ".join("%s%d@%.0f" % e for e in ev))
+print("shader MHz seen by block 0 of each seq_bwd launch, in wait order:", mhz)
