@@ -1,4 +1,5 @@
-"""Timeline of a short run (the driver's --steps 20): when is each dispatch issued, when does each wait return?"""
+"""Timeline of a short run (the driver's --steps 20): when is each dispatch issued, when does each wait return?
+usage: ramp_trace.py [frames] [steps] [idle seconds before the window] [dispatches of steady load before it]"""
 import sys, time
 sys.path.insert(0, ".")
 import vgen_amd as v
@@ -8,11 +9,16 @@ N = 1 << 20
 r = v.GpuRunner(batch_size=N, fmt=v.AddressFormat.P2pkh, frames=F, timing=False)
 r.set_filter(v.Pattern("^1Cat", False, v.AddressFormat.P2pkh))
 key = 0x3a8ae174e51b7b1117ab406c6570970f453c4376b6d381977db7c02fb5a993e0
+HEAT = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # dispatches of steady load before every window
 for rep in range(3):
     for f in range(F):
         r.dispatch(key, f); key += N
+    fw = 0
+    for i in range(HEAT):
+        r.wait(fw); r.dispatch(key, fw); key += N
+        fw = (fw + 1) % F
     for f in range(F):
-        r.wait(f)
+        r.wait((fw + f) % F)
     time.sleep(float(sys.argv[3]) if len(sys.argv) > 3 else 0.01)
     ev = []
     mhz = []
