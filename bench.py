@@ -377,10 +377,25 @@ def main():
                      "dispatches": n_total, "frames_in_flight": F}
 
     # ---- the contract's timed region: exactly --steps dispatches between two barrier + synchronize brackets ----
+    # Opening bracket: barrier + synchronize, then every rank reads the clock.  Closing bracket: the rank's own
+    # synchronize, clock, then the barrier.  All ranks are processes of one node and time.perf_counter() is the
+    # system-wide CLOCK_MONOTONIC, so the job's elapsed time is (latest finish over ranks) - (earliest start over ranks):
+    # the wall time of the whole job, a little MORE than the maximum of the per-rank times, without the latency of the
+    # gloo barrier itself (hundreds of microseconds against a 2 ms region).  At N = 1 this is the plain bracket.
+    barrier()
     t0 = time.perf_counter()
     cand, _ = pipe.run_steps(args.steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    t_barrier = time.perf_counter()
+    if world > 1:
+        tt = torch.tensor([-t0, t1, t1 - t0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[1].item()) + float(tt[0].item())     # max(t1) - min(t0)
+        slowest_rank_s = float(tt[2].item())
+    else:
+        elapsed = slowest_rank_s = t1 - t0
     keys = world * args.steps * N * K6
     value = keys / elapsed / 1e6
     # shader clock during the region, from the samples its last min(F, steps) seq_bwd launches left in their frames
@@ -463,6 +478,12 @@ def main():
         "sustained": sustained,
         "roofline": roofline,
     }
+    if world > 1:
+        out["timing"] = {"elapsed_ms": round(elapsed * 1e3, 4), "slowest_rank_ms": round(slowest_rank_s * 1e3, 4),
+                         "closing_barrier_ms_rank0": round((t_barrier - t1) * 1e3, 4),
+                         "how": "elapsed = latest finish - earliest start over the ranks (one node, system-wide monotonic clock); "
+                                "start: after the opening barrier + synchronize, finish: after the rank's closing synchronize; "
+                                "the closing barrier follows the clock"}
     if rank == 0 and world == 1:
         # the kernel alone: frames = 1, so every launch has the chip to itself (one wave per SIMD), HIP events
         # recorded on the launch's own stream immediately before and after seq_bwd_kernel

@@ -177,6 +177,8 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     assert d["n_gpus"] == 2 and d["steps"] == 64 and d["scaling"] == "weak" and d["value"] > 1000
     assert d["config"]["parallelism"].startswith("range-striped x2") and d["sustained"]["value"] > 1000
     assert "cpu_baseline" not in d and "other_configs" not in d
+    t = d["timing"]   # whole-job wall time: latest finish - earliest start over the ranks, never less than the slowest rank's own time
+    assert t["elapsed_ms"] >= t["slowest_rank_ms"] > 0 and abs(t["elapsed_ms"] / 64 - d["ms_per_step"]) < 1e-3
 
 
 def test_cli_warns_about_impossible_patterns_before_touching_the_device():
