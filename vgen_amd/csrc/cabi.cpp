@@ -199,10 +199,7 @@ int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_
     if (fwd_streams) *fwd_streams = ctx->n_fwd;
     if (bwd_streams) *bwd_streams = ctx->n_bwd;
     if (hw_queues) *hw_queues = ctx->hw_queues;
-    if (oversubscribed) {
-        const uint32_t own = ctx->stream_kind == vg::STREAMS_CUMASK ? 1u << 30 : ctx->stream_kind == vg::STREAMS_PRIORITY ? 3 * ctx->hw_queues : ctx->hw_queues;
-        *oversubscribed = ctx->n_fwd + ctx->n_bwd > own ? 1 : 0;
-    }
+    if (oversubscribed) *oversubscribed = vg::rt_oversubscribed(ctx) ? 1 : 0;
     return VGEN_OK;
 }
 

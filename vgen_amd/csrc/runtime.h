@@ -96,6 +96,13 @@ namespace vg {
 
 enum { STREAMS_PLAIN = 0, STREAMS_PRIORITY = 1, STREAMS_CUMASK = 2 };
 
+// More stage streams than hardware queues the stream kind provides (plain: GPU_MAX_HW_QUEUES, priority pools: three
+// times that, CU-masked: one each): streams then share queues.
+inline bool rt_oversubscribed(const vgen_ctx *c) {
+    const uint32_t own = c->stream_kind == STREAMS_CUMASK ? 1u << 30 : c->stream_kind == STREAMS_PRIORITY ? 3 * c->hw_queues : c->hw_queues;
+    return c->n_fwd + c->n_bwd > own;
+}
+
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
 void rt_destroy(vgen_ctx *ctx);
 int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
