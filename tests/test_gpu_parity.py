@@ -53,6 +53,17 @@ def test_dump_matches_oracle_small_batches(vg, vo, fmt):
     r.close()
 
 
+@pytest.mark.parametrize("batch", [8192, 3 * 8192, 5 * 8192, 1 << 18])
+def test_offset_table_built_on_the_device_for_any_lane_count(vg, vo, batch):
+    """vgen_create builds the offset table R_u = (u S + S/2) G on the device (rtab_build_kernel: bits of u select the
+    doublings of S G).  Every key of a dispatch goes through one entry, so a dump equal to the oracle's checks all of
+    them — here also for lane counts that are not powers of two (the top bit of u is then not set for every prefix)."""
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh)
+    for start in (vo.seed_key(5, batch & 0xFFFF), 1):
+        assert dump(r, start) == vo.payload_seq(0, start, batch)
+    r.close()
+
+
 def test_dump_full_size_dispatch_p2pkh(vg, vo):
     # BASELINE config 2, dispatch 0: all 2^20 hash160 byte-equal to the oracle
     batch = 1 << 20

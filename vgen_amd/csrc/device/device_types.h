@@ -73,6 +73,19 @@ struct DevSeqQ {
     uint32_t qx[9], qy[9], nqx[9], nqy[9];
 };
 
+// Building the offset table on the device (rtab_build_kernel): lane u computes R_u = base + u * step from the
+// doublings pw[b] = 2^b * step (affine, canonical limbs, passed by value), bits of u selecting the summands.
+struct DevAffine {
+    uint32_t x[9], y[9];
+};
+struct RtabArgs {
+    uint32_t *rtab;            // [18][lanes], limb-major
+    uint32_t lanes;
+    uint32_t nbits;            // ceil(log2(lanes)) <= 24
+    DevAffine base;
+    DevAffine pw[24];
+};
+
 constexpr uint32_t SEQ_MAX_S = 16;   // keeps SeqArgs (passed by value as kernel arguments) under 4 KB
 constexpr int SEQ_WG = 256;          // lanes per workgroup of the seq_* kernels
 

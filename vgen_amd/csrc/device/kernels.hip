@@ -914,6 +914,60 @@ hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 bits, hipStream_
     return hipGetLastError();
 }
 
+// ---- offset table of the sequential path, built on the device -------------------------------------------------
+// R_u = base + u * step, one lane per entry: up to nbits branch-free mixed additions (summand b = 2^b * step where bit b
+// of u is set), then the lane's own inversion.  65 536 entries take ~0.2 ms of the chip; on the host's sixteen threads
+// the same table took 7 ms of vgen_create, most of the time to a cold first match.
+__global__ void __launch_bounds__(256) rtab_build_kernel(RtabArgs a) {
+    const u32 u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= a.lanes) return;
+    gej acc;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc.x.n[i] = a.base.x[i];
+        acc.y.n[i] = a.base.y[i];
+        acc.z.n[i] = i == 0 ? 1u : 0u;
+    }
+    acc.inf = 0;
+#pragma unroll 1
+    for (u32 b = 0; b < a.nbits; b++) {
+        ge p;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            p.x.n[i] = a.pw[b].x[i];
+            p.y.n[i] = a.pw[b].y[i];
+        }
+        gej sum;
+        gej_add_ge_nz(sum, acc, p);
+        const bool take = ((u >> b) & 1u) != 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            acc.x.n[i] = take ? sum.x.n[i] : acc.x.n[i];
+            acc.y.n[i] = take ? sum.y.n[i] : acc.y.n[i];
+            acc.z.n[i] = take ? sum.z.n[i] : acc.z.n[i];
+        }
+    }
+    fe zi, zi2, zi3, x, y;
+    fe_inv(zi, acc.z);
+    fe_sqr(zi2, zi);
+    fe_mul(zi3, zi2, zi);
+    fe_mul(x, acc.x, zi2);
+    fe_mul(y, acc.y, zi3);
+    fe_canonicalize_product(x);
+    fe_canonicalize_product(y);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        a.rtab[(size_t)i * a.lanes + u] = x.n[i];
+        a.rtab[(size_t)(9 + i) * a.lanes + u] = y.n[i];
+    }
+}
+
+hipError_t launch_rtab_build(const RtabArgs &a, hipStream_t stream) {
+    if (a.lanes == 0 || a.nbits > 24 || (a.nbits < 32 && (a.lanes - 1) >> a.nbits)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rtab_build_kernel, dim3((a.lanes + 255) / 256), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 // ---- shader-clock probe -----------------------------------------------------------------------------------
 // One wave that sleeps on the SALU for `ticks` of the constant 100 MHz counter (s_memrealtime) and reports
 // how far the shader-clock counter (s_memtime) moved meanwhile: the clock the CUs really ran at while the scan

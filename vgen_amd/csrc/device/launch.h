@@ -23,6 +23,10 @@ namespace vg {
 hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream, hipEvent_t before_bwd);
 // Builds the wide fixed-window generator table (bits = 16 | 20 | 22; ec_wide_words(bits) words, core/ec.h) from the 8-bit one.
 hipError_t launch_gen_table_wide(const uint32_t *tab8, uint32_t *tab, uint32_t bits, hipStream_t stream);
+// Builds the sequential path's offset table on the device: rtab[(i) * lanes + u] / rtab[(9 + i) * lanes + u] = limb i of
+// x / y of base + u * step (a.pw[b] = 2^b * step).  No pair (partial sum, summand) is exceptional as long as base is not a
+// multiple of step and the scalars stay far below n (runtime.cpp: base = S/2, step = S).
+hipError_t launch_rtab_build(const RtabArgs &a, hipStream_t stream);
 // Enqueues the shader-clock probe: out[0] = shader-clock cycles, out[1] = 100 MHz ticks elapsed (>= ticks).
 hipError_t launch_clock_probe(unsigned long long *out, unsigned long long ticks, hipStream_t stream);
 }  // namespace vg

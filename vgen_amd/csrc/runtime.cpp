@@ -1,6 +1,8 @@
 // runtime.cpp — see runtime.h.
 #include "runtime.h"
 
+#include <chrono>
+
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -208,6 +210,10 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         err = "unknown address format";
         return VGEN_E_INVALID;
     }
+    const bool trace = getenv("VGEN_TRACE_CREATE") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tlast = now();
+    auto lap = [&](const char *what) { if (trace) { double t = now(); fprintf(stderr, "[vgen_create] %-28s %.2f ms\n", what, t - tlast); tlast = t; } };
     vgen_ctx *c = new vgen_ctx();
     c->device = p->device;
     c->batch = p->batch_size ? p->batch_size : (1u << 20);
@@ -249,6 +255,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     // One device slab and one pinned slab for all frames (sixteen frames as separate allocations cost ~85 ms of
     // vgen_create, i.e. of the time to a cold first match); slices are 256-byte aligned.  Everything a dispatch
     // of this context's format touches is allocated here, nothing on the dispatch path.
+    lap("checks + hipSetDevice");
     c->fr.resize(c->frames);
     const size_t scratch_b = up256(scratch_words(c) * sizeof(uint32_t));
     const size_t p2tr_b = up256(p2tr_words(c) * sizeof(uint32_t));
@@ -263,27 +270,49 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     e = hipMalloc((void **)&c->d_filter, sizeof(DevFilter));
     if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(filter): ") + hipGetErrorString(e));
 
-    // offset table R_u = (u*S + S/2) * G, uploaded limb-major ([18][lanes]) for coalesced reads
-    std::vector<ge> tab;
-    host_build_stride_table(c->S / 2, c->S, c->lanes, tab);
-    std::vector<uint32_t> lm((size_t)18 * c->lanes);
-    for (uint32_t u = 0; u < c->lanes; u++)
-        for (int i = 0; i < 9; i++) {
-            lm[(size_t)i * c->lanes + u] = tab[u].x.n[i];
-            lm[(size_t)(9 + i) * c->lanes + u] = tab[u].y.n[i];
-        }
-    e = hipMalloc((void **)&c->d_rtab, lm.size() * sizeof(uint32_t));
+    lap("hipMalloc slab + filter");
+    // offset table R_u = (u*S + S/2) * G, limb-major ([18][lanes]) for coalesced reads — built on the device
+    // (rtab_build_kernel): the host only supplies (S/2) G and the doublings 2^b S G.  [The host build of the same table,
+    // host_build_stride_table on sixteen threads, was 7 of the 10 ms of vgen_create.]
+    RtabArgs ra;
+    memset(&ra, 0, sizeof ra);
+    ra.lanes = c->lanes;
+    while (ra.nbits < 24 && ((uint64_t)1 << ra.nbits) < c->lanes) ra.nbits++;
+    {
+        auto point = [&](uint64_t k, DevAffine &o) -> bool {
+            Scalar s{};
+            s.w[0] = (uint32_t)k;
+            s.w[1] = (uint32_t)(k >> 32);
+            ge g;
+            if (!host_ec_mul_gen(s, g)) return false;
+            for (int i = 0; i < 9; i++) {
+                o.x[i] = g.x.n[i];
+                o.y[i] = g.y.n[i];
+            }
+            return true;
+        };
+        bool ok = point(c->S / 2, ra.base);
+        for (uint32_t bit = 0; ok && bit < ra.nbits; bit++) ok = point((uint64_t)c->S << bit, ra.pw[bit]);
+        if (!ok) return bail(VGEN_E_INVALID, "offset table: point at infinity");
+    }
+    lap("host: base + doublings");
+    e = hipMalloc((void **)&c->d_rtab, (size_t)18 * c->lanes * sizeof(uint32_t));
     if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(rtab): ") + hipGetErrorString(e));
+    ra.rtab = c->d_rtab;
     // The match rings (monotonic counters) and the arrival counters start at zero; the rest of the scratch
-    // needs no initialisation but shares the slab.  Cleared and uploaded on stage stream 0 and waited for: the
+    // needs no initialisation but shares the slab.  Cleared and built on stage stream 0 and waited for: the
     // other stage streams do not synchronise with it, so nothing may be pending when vgen_create returns.
     hipStream_t st0 = nullptr;
+    lap("hipMalloc rtab");
     if (stage_stream(c, c->bwd_streams, 0, &st0) != VGEN_OK) return bail(VGEN_E_HIP, c->err);
+    lap("stream 0");
     if ((e = hipMemsetAsync(c->d_slab, 0, frame_b * c->frames, st0)) != hipSuccess ||
-        (e = hipMemcpyAsync(c->d_rtab, lm.data(), lm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st0)) != hipSuccess ||
+        (e = launch_rtab_build(ra, st0)) != hipSuccess ||
         (e = hipStreamSynchronize(st0)) != hipSuccess)
         return bail(VGEN_E_HIP, std::string("frame setup: ") + hipGetErrorString(e));
+    lap("memset + table kernel + sync");
     if (int rc = rt_set_match_cap(c, c->match_cap)) return bail(rc, c->err);
+    lap("match rings (device + pinned)");
     *out = c;
     return VGEN_OK;
 }

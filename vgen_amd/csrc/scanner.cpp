@@ -457,9 +457,13 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         return true;
     };
     auto may_launch = [&]() { return can_dispatch() && !stopped() && found() < count; };
+    // (a frame's stream — a hardware queue of its own — is created at its first dispatch and takes ~8 ms: a fresh context
+    // starts on frame 0 alone, so that an easy pattern's first match does not wait for a second queue it never needs)
     auto prime = [&]() {
-        while (active < std::min<uint32_t>(nf, 2) && may_launch())
+        while (active < std::min<uint32_t>(nf, 2) && may_launch()) {
+            if (active >= 1 && !ctx->fr[active].s_bwd) break;
             if (!launch(active++)) break;
+        }
     };
     prime();
 
@@ -503,10 +507,16 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         }
 
         bool dispatched_next = false;
+        bool ramp_later = false;
         if (may_launch()) {
             if (!launch(frame)) break;
             dispatched_next = true;
-            if (active < nf && may_launch() && !launch(active++)) break;   // ramp up: one more frame per batch
+            // ramp up: one more frame per batch — at once when its stream exists; a frame that still has to create its
+            // stream (~8 ms) joins after this batch's candidates have been examined, and only if the scan goes on
+            if (active < nf && may_launch()) {
+                if (!ctx->fr[active].s_bwd) ramp_later = true;
+                else if (!launch(active++)) break;
+            }
         }
 
         if (!dumped) {
@@ -564,6 +574,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         batch_matches.clear();
         if (cb) cb(shared_ops ? tested : total_ops, user);   // multi-device: the wrapper adds N to the shared count under its lock
         if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
+        if (ramp_later && active < nf && may_launch() && !launch(active++)) break;
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
     const bool all_processed = order.empty() && !cut_any;   // no dispatched batch was left unread or cut short
