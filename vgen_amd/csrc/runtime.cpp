@@ -91,48 +91,121 @@ void destroy_idle_streams() {
     }
 }
 
-int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStream_t *out) {
-    if (!pool[i]) {
-        if (c->stream_kind == STREAMS_CUMASK) {
-            {
-                StreamCache &sc = stream_cache();
-                std::lock_guard<std::mutex> g(sc.mu);
-                auto &idle = sc.idle[c->device];
-                if (!idle.empty()) {
-                    pool[i] = idle.back();
-                    idle.pop_back();
-                }
+// Creates the stream of slot i of a pool (no locking here).
+int create_stream(vgen_ctx *c, bool bwd_pool, uint32_t i, hipStream_t *out, std::string &err) {
+    hipError_t e = hipSuccess;
+    *out = nullptr;
+    if (c->stream_kind == STREAMS_CUMASK) {
+        {
+            StreamCache &sc = stream_cache();
+            std::lock_guard<std::mutex> g(sc.mu);
+            auto &idle = sc.idle[c->device];
+            if (!idle.empty()) {
+                *out = idle.back();
+                idle.pop_back();
             }
-            if (!pool[i]) {
-                static std::once_flag once;
-                std::call_once(once, []() {
-                    const char *v = getenv("VGEN_DESTROY_STREAMS_AT_EXIT");
-                    if (v && *v == '1') atexit(destroy_idle_streams);
-                });
-                std::vector<uint32_t> mask((c->cu_count + 31) / 32, 0xFFFFFFFFu);
-                HIP_TRY(c, hipExtStreamCreateWithCUMask(&pool[i], (uint32_t)mask.size(), mask.data()));
-            }
-        } else if (c->stream_kind == STREAMS_PRIORITY) {
-            // the runtime keeps one pool of GPU_MAX_HW_QUEUES hardware queues PER PRIORITY LEVEL: streams 0-3 take
-            // the normal level, 4-7 the next, 8-11 the third, so that twelve streams own twelve queues
-            int least = 0, greatest = 0;
-            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        }
+        if (!*out) {
+            static std::once_flag once;
+            std::call_once(once, []() {
+                const char *v = getenv("VGEN_DESTROY_STREAMS_AT_EXIT");
+                if (v && *v == '1') atexit(destroy_idle_streams);
+            });
+            std::vector<uint32_t> mask((c->cu_count + 31) / 32, 0xFFFFFFFFu);
+            e = hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+        }
+    } else if (c->stream_kind == STREAMS_PRIORITY) {
+        // the runtime keeps one pool of GPU_MAX_HW_QUEUES hardware queues PER PRIORITY LEVEL: streams 0-3 take
+        // the normal level, 4-7 the next, 8-11 the third, so that twelve streams own twelve queues
+        int least = 0, greatest = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) == hipSuccess) {
             const int levels = least - greatest + 1;   // 3 on this runtime: -1 (greatest), 0, 1 (least)
-            const uint32_t n = c->streams_created++;
+            const uint32_t n = bwd_pool ? i : c->n_bwd + i;   // bwd slots first, then the fwd slots
             int prio = 0;
             if (levels >= 3) {
                 static const int order[3] = {0, -1, 1};
                 prio = order[(n / c->hw_queues) % 3];
                 if (prio < greatest || prio > least) prio = 0;
             }
-            HIP_TRY(c, hipStreamCreateWithPriority(&pool[i], hipStreamNonBlocking, prio));
-        } else {
-            HIP_TRY(c, hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking));
+            e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
         }
+    } else {
+        e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    if (e != hipSuccess) {
+        err = std::string("stream creation: ") + hipGetErrorString(e);
+        return VGEN_E_HIP;
+    }
+    return VGEN_OK;
+}
+
+// The stream of slot i, created now if nobody has yet; if somebody (the helper thread) is creating it, waits for that.
+int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStream_t *out) {
+    const bool bwd_pool = &pool == &c->bwd_streams;
+    std::vector<char> &claimed = bwd_pool ? c->bwd_claimed : c->fwd_claimed;
+    std::unique_lock<std::mutex> lk(c->stream_mu);
+    if (claimed.size() < pool.size()) claimed.resize(pool.size(), 0);
+    c->stream_cv.wait(lk, [&]() { return pool[i] || !claimed[i]; });
+    if (!pool[i]) {
+        claimed[i] = 1;
+        lk.unlock();
+        hipStream_t st = nullptr;
+        std::string err;
+        const int rc = create_stream(c, bwd_pool, i, &st, err);
+        lk.lock();
+        claimed[i] = 0;
+        pool[i] = st;
+        c->stream_cv.notify_all();
+        if (rc != VGEN_OK) return c->fail(rc, err);
     }
     *out = pool[i];
     return VGEN_OK;
 }
+
+}  // namespace
+
+bool rt_prepare_streams(vgen_ctx *c) {
+    if (c->stream_kind == STREAMS_CUMASK) return false;   // those are cached per process and teardown-sensitive: first use only
+    std::lock_guard<std::mutex> g(c->stream_mu);
+    if (c->maker_started) return true;
+    c->maker_started = true;
+    c->stream_maker = std::thread([c]() {
+        if (hipSetDevice(c->device) != hipSuccess) return;
+        for (int pass = 0; pass < 2; pass++) {
+            const bool bwd_pool = pass == 0;
+            std::vector<hipStream_t> &pool = bwd_pool ? c->bwd_streams : c->fwd_streams;
+            std::vector<char> &claimed = bwd_pool ? c->bwd_claimed : c->fwd_claimed;
+            for (uint32_t i = 0; i < pool.size(); i++) {
+                if (c->maker_cancel.load()) return;
+                {
+                    std::lock_guard<std::mutex> lk(c->stream_mu);
+                    if (claimed.size() < pool.size()) claimed.resize(pool.size(), 0);
+                    if (pool[i] || claimed[i]) continue;
+                    claimed[i] = 1;
+                }
+                hipStream_t st = nullptr;
+                std::string err;
+                (void)create_stream(c, bwd_pool, i, &st, err);   // on failure the slot stays empty: its first user retries and reports
+                {
+                    std::lock_guard<std::mutex> lk(c->stream_mu);
+                    claimed[i] = 0;
+                    pool[i] = st;
+                }
+                c->stream_cv.notify_all();
+            }
+        }
+    });
+    return true;
+}
+
+bool rt_frame_ready(vgen_ctx *c, uint32_t frame) {
+    if (frame >= c->frames) return false;
+    if (c->fr[frame].s_bwd) return true;
+    std::lock_guard<std::mutex> g(c->stream_mu);
+    return c->bwd_streams[frame % c->n_bwd] != nullptr && (c->n_fwd == 0 || c->fwd_streams[frame % c->n_fwd] != nullptr);
+}
+
+namespace {
 
 void retire_stream(vgen_ctx *c, hipStream_t st) {
     if (!st) return;
@@ -355,6 +428,8 @@ int rt_set_match_cap(vgen_ctx *c, uint32_t cap) {
 
 void rt_destroy(vgen_ctx *c) {
     if (!c) return;
+    c->maker_cancel.store(true);
+    if (c->stream_maker.joinable()) c->stream_maker.join();   // (at most one stream creation away)
     (void)hipSetDevice(c->device);
     for (auto &st : c->fwd_streams)
         if (st) (void)hipStreamSynchronize(st);

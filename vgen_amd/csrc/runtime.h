@@ -10,7 +10,11 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vgen_hip.h"
@@ -71,6 +75,14 @@ struct vgen_ctx {
     bool per_frame_streams = true;
     bool fused_inv = false;                      // root inversions in seq_fwd's tail instead of a seq_inv_kernel launch
     std::vector<hipStream_t> fwd_streams, bwd_streams;
+    // Streams are created at first use (a hardware queue each, ~8 ms) or, once a scan has asked for them
+    // (rt_prepare_streams), by a helper thread while the scan runs on the frames it already has.
+    std::mutex stream_mu;                        // guards the two pools' slots and the claims below
+    std::condition_variable stream_cv;
+    std::vector<char> bwd_claimed, fwd_claimed;  // slot is being created by somebody: wait for it instead of creating another
+    std::thread stream_maker;
+    bool maker_started = false;
+    std::atomic<bool> maker_cancel{false};
     int stream_kind = 1;                         // vg::STREAMS_* (runtime.cpp: stage_stream)
     uint32_t streams_created = 0;
     uint32_t cu_count = 0;
@@ -104,6 +116,11 @@ inline bool rt_oversubscribed(const vgen_ctx *c) {
 }
 
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
+// Starts (once) a helper thread that creates the stage streams no frame has used yet; rt_frame_ready tells without
+// blocking whether `frame` could be dispatched to without creating a stream first.  Used by the scan loop to grow its
+// pipeline as queues become available instead of stalling ~8 ms per frame.  false: not supported for this stream kind.
+bool rt_prepare_streams(vgen_ctx *ctx);
+bool rt_frame_ready(vgen_ctx *ctx, uint32_t frame);
 void rt_destroy(vgen_ctx *ctx);
 int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 int rt_set_match_cap(vgen_ctx *ctx, uint32_t cap);

@@ -461,7 +461,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     // starts on frame 0 alone, so that an easy pattern's first match does not wait for a second queue it never needs)
     auto prime = [&]() {
         while (active < std::min<uint32_t>(nf, 2) && may_launch()) {
-            if (active >= 1 && !ctx->fr[active].s_bwd) break;
+            if (active >= 1 && !rt_frame_ready(ctx, active)) break;
             if (!launch(active++)) break;
         }
     };
@@ -511,10 +511,11 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         if (may_launch()) {
             if (!launch(frame)) break;
             dispatched_next = true;
-            // ramp up: one more frame per batch — at once when its stream exists; a frame that still has to create its
-            // stream (~8 ms) joins after this batch's candidates have been examined, and only if the scan goes on
+            // ramp up: one more frame per batch — at once when its stream exists; frames that still need their stream
+            // (a hardware queue, ~8 ms to create) join as a helper thread gets the streams made, which is asked for
+            // after this batch's candidates have been examined and only if the scan goes on
             if (active < nf && may_launch()) {
-                if (!ctx->fr[active].s_bwd) ramp_later = true;
+                if (!rt_frame_ready(ctx, active)) ramp_later = true;
                 else if (!launch(active++)) break;
             }
         }
@@ -574,7 +575,11 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         batch_matches.clear();
         if (cb) cb(shared_ops ? tested : total_ops, user);   // multi-device: the wrapper adds N to the shared count under its lock
         if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
-        if (ramp_later && active < nf && may_launch() && !launch(active++)) break;
+        if (ramp_later && active < nf && may_launch()) {
+            // not ready and no helper for this stream kind: create it here and now, as before
+            if (!rt_frame_ready(ctx, active) && rt_prepare_streams(ctx)) continue;
+            if (!launch(active++)) break;
+        }
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
     const bool all_processed = order.empty() && !cut_any;   // no dispatched batch was left unread or cut short
