@@ -164,11 +164,40 @@ int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStr
 
 }  // namespace
 
+// Contexts whose helper thread may still be running.  A process that exits without vgen_destroy (an error path of a host
+// application) must not reach the HIP runtime's teardown with such a thread inside hipStreamCreate: an atexit handler,
+// registered at the first helper's start (i.e. after the runtime registered its own, so it runs before it), stops them.
+struct MakerRegistry {
+    std::mutex mu;
+    std::vector<vgen_ctx *> live;
+};
+static MakerRegistry &maker_registry() {
+    static MakerRegistry *r = new MakerRegistry();
+    return *r;
+}
+static void stop_stream_maker(vgen_ctx *c) {
+    c->maker_cancel.store(true);
+    if (c->stream_maker.joinable()) c->stream_maker.join();   // at most one stream creation away
+}
+static void stop_all_stream_makers() {
+    MakerRegistry &r = maker_registry();
+    std::lock_guard<std::mutex> g(r.mu);
+    for (vgen_ctx *c : r.live) stop_stream_maker(c);
+    r.live.clear();
+}
+
 bool rt_prepare_streams(vgen_ctx *c) {
     if (c->stream_kind == STREAMS_CUMASK) return false;   // those are cached per process and teardown-sensitive: first use only
     std::lock_guard<std::mutex> g(c->stream_mu);
     if (c->maker_started) return true;
     c->maker_started = true;
+    {
+        static std::once_flag once;
+        std::call_once(once, []() { atexit(stop_all_stream_makers); });
+        MakerRegistry &r = maker_registry();
+        std::lock_guard<std::mutex> rg(r.mu);
+        r.live.push_back(c);
+    }
     c->stream_maker = std::thread([c]() {
         if (hipSetDevice(c->device) != hipSuccess) return;
         for (int pass = 0; pass < 2; pass++) {
@@ -428,8 +457,12 @@ int rt_set_match_cap(vgen_ctx *c, uint32_t cap) {
 
 void rt_destroy(vgen_ctx *c) {
     if (!c) return;
-    c->maker_cancel.store(true);
-    if (c->stream_maker.joinable()) c->stream_maker.join();   // (at most one stream creation away)
+    {
+        MakerRegistry &r = maker_registry();
+        std::lock_guard<std::mutex> g(r.mu);
+        r.live.erase(std::remove(r.live.begin(), r.live.end(), c), r.live.end());
+    }
+    stop_stream_maker(c);
     (void)hipSetDevice(c->device);
     for (auto &st : c->fwd_streams)
         if (st) (void)hipStreamSynchronize(st);
