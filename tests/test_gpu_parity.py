@@ -672,15 +672,24 @@ def test_permissive_pattern_grows_the_match_ring_instead_of_dumping(vg, vo):
     r.close()
 
 
-@pytest.mark.parametrize("bits", [8, 16, 20, 22])
+@pytest.mark.parametrize("bits", [8, 16, 20, 22, 24])
 def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypatch):
     """The arbitrary-scalar and taproot paths multiply through a fixed-window table of VGEN_GTAB_BITS-bit windows
-    (8: the host-built 653 KB table; 16 / 20 / 22: built on the device from it).  Every width must reproduce the
-    oracle: explicit scalars incl. the extremes, and the P2TR tweak multiplication."""
+    (8: the host-built 653 KB table; 16 / 20 / 22 / 24: built on the device from it, every entry as the sum of two
+    entries of a table of half the width).  Every width must reproduce the oracle: explicit scalars incl. the
+    extremes, one-digit scalars that hit the special entries of the two-level build in every window (low half zero,
+    high half zero, all ones, group boundaries), and the P2TR tweak multiplication."""
     monkeypatch.setenv("VGEN_GTAB_BITS", str(bits))
     import random
     rng = random.Random(bits)
     keys = [1, 2, N - 1, N - 2, 2**255, 0xFFFF, 0x10000, (1 << 200) + 5, (2**22 - 1) << 220, 2**256 - 1, 0, N] + [rng.randrange(1, N) for _ in range(500)]
+    h = bits // 2
+    for w in range((256 + bits - 1) // bits):
+        for digit in (1, 7, 8, 9, 2**h - 1, 2**h, 2**h + 1, (2**h - 1) << h, 3 << h, 2**bits - 8, 2**bits - 1, rng.randrange(1, 2**bits)):
+            k = digit << (w * bits)
+            if 0 < k < N:
+                keys.append(k)
+                keys.append((k + rng.randrange(1, N)) % N or 1)      # the same digit among random ones: carries do not matter, digits are independent
     r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh)
     r.set_filter(None)
     r.dispatch_keys(keys, 0)

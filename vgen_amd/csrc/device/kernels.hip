@@ -907,10 +907,133 @@ __global__ void __launch_bounds__(256) gen_table_wide_kernel(const u32 *tab8, u3
     o[3] = ec_u4{{yw[4], yw[5], yw[6], yw[7]}};
 }
 
-hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 bits, hipStream_t stream) {
-    if (bits != 16 && bits != 20 && bits != 22) return hipErrorInvalidValue;
-    const unsigned long long entries = ec_wide_entries(bits);
-    hipLaunchKernelGGL(gen_table_wide_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, stream, tab8, tab, bits, entries);
+// The same table in two levels: a digit d of `bits` bits splits into d = d_lo + 2^h d_hi (h = bits / 2), and
+//   d 2^(bits w) G = d_lo 2^(h 2w) G + d_hi 2^(h (2w+1)) G = small[2w][d_lo] + small[2w+1][d_hi],
+// one AFFINE addition of two entries of the h-bit table (same layout, a few thousand entries per window, built by
+// gen_table_wide_kernel).  A lane makes eight consecutive digits (same d_hi) and shares one inversion among their
+// additions: ~45 field multiplications per entry instead of ~610 — 20 bits in ~3 ms instead of ~40, which is what a
+// cold first P2TR match waits for.  No pair is exceptional: d_lo 2^(bits w) = +/- d_hi 2^(bits w + h) has no
+// solution with d_lo < 2^h.  Digits whose scalar would not fit 256 bits are skipped as in the one-level kernel.
+constexpr int GT_K = 8;   // digits per lane
+__global__ void __launch_bounds__(256) gen_table_combine_kernel(const u32 *small, u32 *tab, u32 bits, unsigned long long groups) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const u32 h = bits >> 1;
+    const unsigned long long per = (1ull << bits) - 1ull, per_h = (1ull << h) - 1ull;
+    const unsigned long long groups_per_window = (1ull << bits) / GT_K;
+    const u32 w = (u32)(g / groups_per_window);
+    const u32 d0 = (u32)(g % groups_per_window) * GT_K;     // digits d0 .. d0 + 7, same d_hi
+    const u32 d_hi = d0 >> h, lo0 = d0 & (u32)per_h;
+    const u32 bit = w * bits;
+    const u32 *win_lo = small + (unsigned long long)(2 * w) * per_h * 16ull;
+    const u32 *win_hi = small + (unsigned long long)(2 * w + 1) * per_h * 16ull;
+    auto load_words = [](const u32 *ent, u32 xw[8], u32 yw[8]) {
+        const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(ent);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const ec_u4 a = e4[q], b = e4[2 + q];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xw[4 * q + i] = a.v[i];
+                yw[4 * q + i] = b.v[i];
+            }
+        }
+    };
+    auto valid = [&](u32 d) { return d != 0 && bit + (32u - (u32)__clz(d)) <= 256u; };
+    u32 hxw[8], hyw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) hxw[i] = hyw[i] = 0;
+    const bool have_hi = d_hi != 0 && valid(d0 | 1u);     // (the smallest digit of the group with this d_hi fits)
+    if (have_hi) load_words(win_hi + (unsigned long long)(d_hi - 1) * 16ull, hxw, hyw);
+    fe hx, hy;
+    fe_from_words(hx, hxw);
+    fe_from_words(hy, hyw);
+
+    // forward: prefix products of the denominators (1 where no addition is needed)
+    fe pre[GT_K];
+    fe acc;
+#pragma unroll
+    for (int j = 0; j < GT_K; j++) {
+        const u32 d = d0 + j, d_lo = lo0 + j;
+        const bool add = have_hi && d_lo != 0 && valid(d);
+        fe dx;
+        fe_set_one(dx);
+        if (add) {
+            u32 xw[8], yw[8];
+            load_words(win_lo + (unsigned long long)(d_lo - 1) * 16ull, xw, yw);
+            fe lx;
+            fe_from_words(lx, xw);
+            fe_sub_n(dx, lx, hx);
+        }
+        if (j == 0) acc = dx;
+        else fe_mul(acc, acc, dx);
+        pre[j] = acc;
+    }
+    fe inv;
+    fe_inv(inv, acc);
+    // backward: each digit's inverse, the addition, the entry
+#pragma unroll
+    for (int j = GT_K - 1; j >= 0; j--) {
+        const u32 d = d0 + j, d_lo = lo0 + j;
+        const bool ok = valid(d);
+        const bool add = have_hi && d_lo != 0 && ok;
+        u32 xw[8], yw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) xw[i] = yw[i] = 0;
+        if (ok && d_lo != 0) load_words(win_lo + (unsigned long long)(d_lo - 1) * 16ull, xw, yw);
+        fe lx, ly, dx;
+        fe_from_words(lx, xw);
+        fe_from_words(ly, yw);
+        fe_set_one(dx);
+        if (add) fe_sub_n(dx, lx, hx);
+        fe idx;
+        if (j > 0) {
+            fe_mul(idx, inv, pre[j - 1]);
+            fe_mul(inv, inv, dx);
+        } else {
+            idx = inv;
+        }
+        if (!ok) continue;
+        u32 oxw[8], oyw[8];
+        if (add) {
+            fe dy, lam, x3, t, y3;
+            fe_sub_n(dy, ly, hy);
+            fe_mul(lam, dy, idx);
+            fe_sqr(x3, lam);
+            fe_sub_n(x3, x3, lx);
+            fe_sub_n(x3, x3, hx);
+            fe_sub_n(t, lx, x3);
+            fe_mul(y3, lam, t);
+            fe_sub_n(y3, y3, ly);
+            fe_canonicalize(x3);
+            fe_canonicalize(y3);
+            fe_to_words(x3, oxw);
+            fe_to_words(y3, oyw);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                oxw[i] = d_lo != 0 ? xw[i] : hxw[i];     // d_hi == 0: the low entry itself; d_lo == 0: the high one
+                oyw[i] = d_lo != 0 ? yw[i] : hyw[i];
+            }
+        }
+        ec_u4 *o = reinterpret_cast<ec_u4 *>(tab + ((unsigned long long)w * per + (d - 1)) * 16ull);
+        o[0] = ec_u4{{oxw[0], oxw[1], oxw[2], oxw[3]}};
+        o[1] = ec_u4{{oxw[4], oxw[5], oxw[6], oxw[7]}};
+        o[2] = ec_u4{{oyw[0], oyw[1], oyw[2], oyw[3]}};
+        o[3] = ec_u4{{oyw[4], oyw[5], oyw[6], oyw[7]}};
+    }
+}
+
+// tab: the wide table (ec_wide_words(bits) words); small: scratch for the half-width table (ec_wide_words(bits / 2) words).
+hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 *small, u32 bits, hipStream_t stream) {
+    if (bits != 16 && bits != 20 && bits != 22 && bits != 24) return hipErrorInvalidValue;
+    const u32 h = bits / 2;
+    const unsigned long long small_entries = ec_wide_entries(h);
+    hipLaunchKernelGGL(gen_table_wide_kernel, dim3((unsigned)((small_entries + 255) / 256)), dim3(256), 0, stream, tab8, small, h, small_entries);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const unsigned long long groups = (unsigned long long)ec_wide_windows(bits) * ((1ull << bits) / GT_K);
+    hipLaunchKernelGGL(gen_table_combine_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, small, tab, bits, groups);
     return hipGetLastError();
 }
 

@@ -21,8 +21,9 @@ namespace vg {
 // sequential scan).  a.xyz / a.tree / a.root: scratch for a.groups = ceil(a.n / 256) workgroups.
 // `before_bwd` (optional) is recorded between the inversion stage and the backward stage.
 hipError_t launch_keys_scan(int fmt, const KeysArgs &a, hipStream_t stream, hipEvent_t before_bwd);
-// Builds the wide fixed-window generator table (bits = 16 | 20 | 22; ec_wide_words(bits) words, core/ec.h) from the 8-bit one.
-hipError_t launch_gen_table_wide(const uint32_t *tab8, uint32_t *tab, uint32_t bits, hipStream_t stream);
+// Builds the wide fixed-window generator table (bits = 16 | 20 | 22 | 24; ec_wide_words(bits) words, core/ec.h) from the
+// 8-bit one, through a table of half the width (`small`: ec_wide_words(bits / 2) words of scratch).
+hipError_t launch_gen_table_wide(const uint32_t *tab8, uint32_t *tab, uint32_t *small, uint32_t bits, hipStream_t stream);
 // Builds the sequential path's offset table on the device: rtab[(i) * lanes + u] / rtab[(9 + i) * lanes + u] = limb i of
 // x / y of base + u * step (a.pw[b] = 2^b * step).  No pair (partial sum, summand) is exceptional as long as base is not a
 // multiple of step and the scalars stay far below n (runtime.cpp: base = S/2, step = S).

@@ -618,27 +618,44 @@ int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys) {
 }
 
 int ensure_gtab(vgen_ctx *c) {
+    const bool trace = getenv("VGEN_TRACE_CREATE") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tlast = now();
+    auto lap = [&](const char *what) { if (trace) { double t = now(); fprintf(stderr, "[generator tables] %-28s %.2f ms\n", what, t - tlast); tlast = t; } };
     if (!c->d_gtab) {
         std::vector<uint32_t> tab;
         host_gen_table8_limbs(tab);   // 8-bit windows, 652 800 B (core/ec.h)
+        lap("host: 8-bit table");
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
         if (int rc = upload(c, c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t))) return rc;
+        lap("upload");
     }
-    // The wide-window table, built on the device from the 8-bit one, once per context: 20-bit windows by default
-    // (13 windows, 12 additions per multiplication instead of 31; 872 MB of the 288 GB, ~40 ms to build).  Measured
-    // (KEYS mode / P2TR, Mkeys/s): 8 bits 576 / 610, 16 bits (67 MB) 1012 / 1087, 20 bits 1177 / 1217, 22 bits
-    // (3.2 GB, ~150 ms) 1257 / 1275.  VGEN_GTAB_BITS = 8 | 16 | 20 | 22 selects (8 = no wide table).
+    // The wide-window table, built on the device from the 8-bit one, once per context: 22-bit windows by default (12
+    // windows, 11 additions per multiplication instead of the 8-bit table's 31; 3.2 GB of the 288 GB).  Every entry is
+    // the affine sum of two entries of a table of half the width, eight entries per lane sharing an inversion
+    // (gen_table_combine_kernel): 20 bits build in 2.6 ms, 22 in ~10, 24 in 31 (one-level build: 40 / 150 ms / -).
+    // Measured, KEYS mode Mkeys/s: 8 bits 576, 16 bits (67 MB) 1014, 20 bits (872 MB) 1205, 22 bits 1272, 24 bits
+    // (11.8 GB, whose first hipMalloc in a process takes 0.6 s) 1359.  VGEN_GTAB_BITS = 8 | 16 | 20 | 22 | 24 selects.
     if (!c->d_gtab16) {
-        const uint32_t bits = env_u32("VGEN_GTAB_BITS", 20);
-        if (bits == 16 || bits == 20 || bits == 22) {
+        const uint32_t bits = env_u32("VGEN_GTAB_BITS", 22);
+        if (bits == 16 || bits == 20 || bits == 22 || bits == 24) {
+            uint32_t *small = nullptr;   // the half-width table the wide one is combined from (scratch)
             HIP_TRY(c, hipMalloc((void **)&c->d_gtab16, (size_t)ec_wide_words(bits) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc((void **)&small, (size_t)ec_wide_words(bits / 2) * sizeof(uint32_t)));
+            lap("hipMalloc wide + scratch");
             hipStream_t st0 = nullptr;
-            if (int rc = stage_stream(c, c->bwd_streams, 0, &st0)) return rc;
-            HIP_TRY(c, launch_gen_table_wide(c->d_gtab, c->d_gtab16, bits, st0));
-            HIP_TRY(c, hipStreamSynchronize(st0));
+            int rc = stage_stream(c, c->bwd_streams, 0, &st0);
+            hipError_t e = hipSuccess;
+            if (rc == VGEN_OK && ((e = launch_gen_table_wide(c->d_gtab, c->d_gtab16, small, bits, st0)) != hipSuccess ||
+                                  (e = hipStreamSynchronize(st0)) != hipSuccess))
+                rc = c->fail(VGEN_E_HIP, std::string("generator table: ") + hipGetErrorString(e));
+            lap("two kernels + sync");
+            (void)hipFree(small);
+            lap("hipFree scratch");
+            if (rc != VGEN_OK) return rc;
             c->gtab_bits = bits;
         } else if (bits != 8) {
-            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20 or 22");
+            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22 or 24");
         }
     }
     return VGEN_OK;
