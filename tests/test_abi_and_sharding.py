@@ -22,6 +22,10 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
     assert lib.vgen_abi_version() == 1
+    # ... and INTEGRATION.md shows the reference-side binding of every one of them
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    undocumented = [n for n in sorted(names) if n not in doc]
+    assert not undocumented, undocumented
 
 
 def test_no_device_is_a_loud_error_not_a_cpu_fallback():
