@@ -325,28 +325,42 @@ void host_gen_table_limbs(std::vector<uint32_t> &out) {
 }
 // 8-bit windows: entry (w, d) = d * 256^w * G = lo(d) * 16^(2w) * G + hi(d) * 16^(2w+1) * G, the sum of two
 // entries of the 4-bit table; 8160 additions, one shared inversion.
+// (Windows are independent: a few threads take four windows each, with an inversion per thread — 5.4 ms on one thread,
+// part of what the first P2TR / arbitrary-scalar dispatch of a context waits for.)
 void host_gen_table8_limbs(std::vector<uint32_t> &out) {
     std::call_once(g_gen_once, build_gen_table);
-    std::vector<gej> jac((size_t)32 * 255);
-    for (int w = 0; w < 32; w++)
-        for (int d = 1; d < 256; d++) {
-            const int lo = d & 15, hi = d >> 4;
-            gej acc;
-            if (lo) {
-                gej_from_ge(acc, g_gen_table[2 * w][lo]);
-                if (hi) gej_add_ge(acc, acc, g_gen_table[2 * w + 1][hi]);
-            } else {
-                gej_from_ge(acc, g_gen_table[2 * w + 1][hi]);
-            }
-            jac[(size_t)w * 255 + (d - 1)] = acc;
-        }
-    std::vector<ge> aff(jac.size());
-    host_batch_to_affine(jac.data(), aff.data(), jac.size());
     out.assign((size_t)32 * 255 * 20, 0u);
-    for (size_t e = 0; e < aff.size(); e++)
-        for (int i = 0; i < 9; i++) {
-            out[e * 20 + i] = aff[e].x.n[i];
-            out[e * 20 + 9 + i] = aff[e].y.n[i];
+    auto windows = [&out](int w0, int w1) {
+        const size_t n = (size_t)(w1 - w0) * 255;
+        std::vector<gej> jac(n);
+        for (int w = w0; w < w1; w++)
+            for (int d = 1; d < 256; d++) {
+                const int lo = d & 15, hi = d >> 4;
+                gej acc;
+                if (lo) {
+                    gej_from_ge(acc, g_gen_table[2 * w][lo]);
+                    if (hi) gej_add_ge(acc, acc, g_gen_table[2 * w + 1][hi]);
+                } else {
+                    gej_from_ge(acc, g_gen_table[2 * w + 1][hi]);
+                }
+                jac[(size_t)(w - w0) * 255 + (d - 1)] = acc;
+            }
+        std::vector<ge> aff(n);
+        host_batch_to_affine(jac.data(), aff.data(), n);
+        for (size_t e = 0; e < n; e++) {
+            const size_t o = ((size_t)w0 * 255 + e) * 20;
+            for (int i = 0; i < 9; i++) {
+                out[o + i] = aff[e].x.n[i];
+                out[o + 9 + i] = aff[e].y.n[i];
+            }
         }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt >= 8 ? 8 : nt >= 4 ? 4 : nt >= 2 ? 2 : 1;
+    const int per = 32 / (int)nt;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(windows, (int)t * per, (int)(t + 1) * per);
+    windows(0, per);
+    for (auto &x : th) x.join();
 }
 }  // namespace vg
