@@ -4,6 +4,6 @@ cp vgen_amd/libvgen_hip.so /tmp/libA.so
 echo "== A (in-tree)"; python tools/topo_sweep.py $ARGS 2>&1 | cut -c20-120
 for T in "$@"; do
   cp vgen_amd/libvgen_hip.so.$T vgen_amd/libvgen_hip.so
-  echo "== $T"; python tools/gpu_smoke.py 0 32768 2>&1 | tail -1 | cut -c1-80; python tools/topo_sweep.py $ARGS 2>&1 | cut -c20-120
+  echo "== $T"; python tests/manual/gpu_smoke.py 0 32768 2>&1 | tail -1 | cut -c1-80; python tools/topo_sweep.py $ARGS 2>&1 | cut -c20-120
 done
 cp /tmp/libA.so vgen_amd/libvgen_hip.so
