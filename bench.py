@@ -546,6 +546,8 @@ def main():
                        "batch of point arithmetic; not a contiguous range, hence not the headline configuration", endo=True)
         oc += leg(timed_config, vg, "p2wpkh", "dead$", False, args.batch, F, local_rank, sec, "BASELINE config 3 as a vanity search (VGEN_FLAG_ENDO)", endo=True)
         oc += leg(timed_config, vg, "ethereum", "^0xdead", True, args.batch, F, local_rank, sec, "BASELINE config 5 (one GPU) as a vanity search (VGEN_FLAG_ENDO)", endo=True)
+        oc += leg(timed_config, vg, "p2pkh", "1[Oo]ri", False, args.batch, F, local_rank, sec,
+                  "unanchored pattern as a vanity search (VGEN_FLAG_ENDO): on-device Base58Check + DFA on six images per point", endo=True)
         oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec)
         oc += leg(dump_mode_configs, vg, args.batch, local_rank, sec)
         out["other_configs"] = oc

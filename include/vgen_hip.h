@@ -54,8 +54,8 @@ typedef enum vgen_format {
 #define VGEN_FLAG_ENDO 2u     /* vanity ("generate") searches only: every curve point of a dispatch is tested under its six
                                  endomorphism / negation images — keys k, lambda k, lambda^2 k and their negations, public
                                  keys (x, +-y), (beta x, +-y), (beta^2 x, +-y) — so a dispatch tests 6 x batch_size keys for
-                                 one batch_size of point arithmetic (every format but P2TR, with a prefilter pattern or in dump
-                                 mode; on-device DFA patterns and P2TR run as without the flag).  The keys tested are NOT a contiguous range:
+                                 one batch_size of point arithmetic (every format but P2TR, which runs as without the flag; with a
+                                 prefilter pattern, an on-device DFA pattern or in dump mode).  The keys tested are NOT a contiguous range:
                                  vgen_scan refuses start / end / seed on such a context.  vgen_wait reports keys_tested
                                  = 6 x batch_size and match indices variant * batch_size + i (vgen_key_variant). */
 #define VGEN_FLAG_TIMING 1u   /* record HIP events around every dispatch so that vgen_frame_kernel_ms /

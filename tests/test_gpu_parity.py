@@ -744,9 +744,9 @@ def test_endomorphism_filter_mode_equals_dfa_over_its_own_dump(vg, vo):
     r.dispatch(start, 0)
     blob, _, tested = r.await_result(0)
     assert tested == 6 * batch
-    for pattern in ("^1Cat", "^1[a-c]Z", "^1zz"):
+    for pattern in ("^1Cat", "^1[a-c]Z", "^1zz", "Cat", "zz$"):     # the last two: the whole DFA on the device, six images per point
         pat = vg.Pattern(pattern, False, vg.AddressFormat.P2pkh)
-        assert pat.device_kind in (1, 2)
+        assert pat.device_kind in ((1, 2) if pattern[0] == "^" else (4,))
         r.set_filter(pat)
         r.dispatch(start, 1)
         recs, n, tested = r.await_result(1)
@@ -788,11 +788,15 @@ def test_endomorphism_scan_returns_keys_that_really_own_their_addresses(vg, vo):
     for m in res.matches:
         assert vo.generate(0, int(m.hex, 16))["address"] == m.address and m.address.startswith("1Cat")
     r2.close()
-    # a pattern that needs the on-device DFA runs without the images (and says so through keys_tested)
+    # a pattern that needs the on-device DFA tests the six images as well
     pat = vg.Pattern("Cat", False, vg.AddressFormat.P2pkh)
     assert pat.device_kind == 4
     r.set_filter(pat)
     r.dispatch(12345, 0)
     _, _, tested = r.await_result(0)
-    assert tested == 1 << 18
+    assert tested == 6 << 18
+    res = vg.scan_gpu_with_runner("CatS", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=5), r)
+    assert len(res.matches) == 5 and res.operations % (6 << 18) == 0
+    for m in res.matches:
+        assert "CatS" in m.address and vo.generate(0, int(m.hex, 16))["address"] == m.address
     r.close()

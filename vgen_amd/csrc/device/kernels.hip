@@ -340,7 +340,7 @@ struct SeqWaves {
     static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH : 4;
 };
 
-// ENDO (vanity searches; every format but P2TR, with a prefilter or in dump mode): every point is tested under its six
+// ENDO (vanity searches; every format but P2TR, with a prefilter, the on-device DFA or in dump mode): every point is tested under its six
 // endomorphism / negation images — (x, +-y), (beta x, +-y), (beta^2 x, +-y), the public keys of k, lambda k, lambda^2 k and
 // their negations — so six keys are hashed for one point's arithmetic plus two multiplications by beta.  Image `variant`
 // = s * 3 + e (e = power of beta, s = negated) of key index i is reported / dumped at variant * n + i.
@@ -520,7 +520,7 @@ seq_bwd_kernel(const SeqArgs args) {
                         u32 *o = args.dump + (size_t)vindex * NW;
 #pragma unroll
                         for (int i = 0; i < NW; i++) o[i] = ple[i];
-                    } else if (filter_eval_n<NW>(args.filter, ple)) {
+                    } else if (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple)) {
                         const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
                         if (slot < args.match_cap) {
                             DevMatch *m = args.mrec + slot;
@@ -1159,7 +1159,8 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
         else hipLaunchKernelGGL((p2tr_finish_kernel<false>), dim3(a.groups), dim3(WG), 0, stream, a);
         return hipGetLastError();
     }
-    if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+    if (full && a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), true, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+    else if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     else if (a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
     else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), bwd_lds_pad(), stream, a);
     return hipGetLastError();

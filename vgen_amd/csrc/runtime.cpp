@@ -782,8 +782,8 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         }
     }
     a.fmt = c->format;
-    // six images per point where the kernels have that form: prefilter or dump mode (not the on-device DFA match)
-    const bool endo_now = c->endo && (dump || c->h_filter.kind != DEVF_DFA);
+    // six images per point (every format but P2TR: c->endo is never set there), whatever the filter
+    const bool endo_now = c->endo;
     a.endo = endo_now ? 1u : 0u;
     if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
         if (int rc = ensure_gtab(c)) return rc;

@@ -364,7 +364,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         return p;
     };
     bool host_all = flt.dev.kind == DEVF_HOST_ALL;
-    const double keys_per_dispatch = (double)N * (ctx->endo && flt.dev.kind != DEVF_DFA ? 6 : 1);
+    const double keys_per_dispatch = (double)N * (ctx->endo ? 6 : 1);
     if (!host_all && flt.selectivity >= 0 && flt.selectivity * keys_per_dispatch * 4 > (double)ctx->match_cap) {
         const uint64_t want = next_pow2((uint64_t)(flt.selectivity * keys_per_dispatch * 4));
         if (want <= N / 2) {
