@@ -56,22 +56,28 @@ W_EC_IMUL, W_EC_IOP = 518, 550       # the batched affine addition's share of W 
 W_FMUL_IMUL, W_FMUL_IOP = 57, 60     # one more field multiplication
 
 
-def work_per_key(fmt_name, endo=False):
+# A pattern evaluated as its whole DFA on the device needs the address string: for the Base58Check formats the 4-byte
+# checksum (two more SHA-256 compressions) and the base conversion, for Bech32 the checksum polymod; the DFA walk itself.
+W_FULL_IOP = {"p2pkh": 2 * 1450 + 400, "p2sh-p2wpkh": 2 * 1450 + 400, "p2pkh-uncompressed": 2 * 1450 + 400, "p2wpkh": 500 + 150,
+              "ethereum": 150}
+
+
+def work_per_key(fmt_name, endo=False, full=False):
     """W of one key.  With VGEN_FLAG_ENDO a curve point serves six keys: its addition is shared by six, two field
     multiplications (beta x, beta^2 x) are added per point, and every key still pays its own hashes.  None for P2TR:
     its tweak now runs on the 20-bit window table (13 mixed additions instead of 64) and no estimate of that
     path's work was ever pinned by counters — the entry reports the rate only."""
     if fmt_name == "p2tr":
         return None
-    w = W_IMUL[fmt_name] * R_MUL + W_IOP[fmt_name]
+    w = W_IMUL[fmt_name] * R_MUL + W_IOP[fmt_name] + (W_FULL_IOP.get(fmt_name, 0) if full else 0)
     if endo:
         ec = W_EC_IMUL * R_MUL + W_EC_IOP
         w = w - ec + (ec + 2 * (W_FMUL_IMUL * R_MUL + W_FMUL_IOP)) / 6.0
     return w
 
 
-def chip_frac(rate, fmt_name, endo=False):
-    w = work_per_key(fmt_name, endo)
+def chip_frac(rate, fmt_name, endo=False, full=False):
+    w = work_per_key(fmt_name, endo, full)
     return None if w is None else round(rate * w / 1e12 / PEAK_TLANEOPS, 4)
 
 
@@ -196,7 +202,7 @@ def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, labe
     rate = n * batch * (6 if endo else 1) / dt
     out = {"config": label, "format": fmt_name, "pattern": pattern + (" -i" if ci else ""), "value": round(rate / 1e6, 1),
            "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": n, "device_filter_kind": pat.device_kind,
-           "chip_frac": chip_frac(rate, fmt_name, endo), "work_per_key": work_per_key(fmt_name, endo)}
+           "chip_frac": chip_frac(rate, fmt_name, endo, pat.device_kind == 4), "work_per_key": work_per_key(fmt_name, endo, pat.device_kind == 4)}
     if note:
         out["note"] = note
     return out
