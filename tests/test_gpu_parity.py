@@ -707,6 +707,32 @@ def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypat
 
 # ---- endomorphism contexts (VGEN_FLAG_ENDO): six keys per curve point ---------------------------------------------
 
+@pytest.mark.parametrize("fmt,pattern,ci", [(1, "cat", False), (1, "q[7x]q", False), (2, "Dog", False), (2, "ab$", False), (4, "1[Oo]r", False), (5, "dead0", True), (5, "bEEf", False)])
+def test_endomorphism_with_the_whole_dfa_on_the_device(vg, vo, fmt, pattern, ci):
+    """Unanchored / Base58-suffix patterns are matched on the device against the encoded address of every one of the six
+    images (seq_bwd_kernel<FMT, FULL, ENDO>): the confirmed match set equals the pattern applied to the context's own
+    dump, image by image."""
+    batch = 1 << 16
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), endo=True, match_cap=16384)
+    start = vo.seed_key(21, fmt)
+    r.set_filter(None)
+    r.dispatch(start, 0)
+    blob, _, tested = r.await_result(0)
+    assert tested == 6 * batch
+    pat = vg.Pattern(pattern, ci, vg.AddressFormat(fmt))
+    assert pat.device_kind == 4
+    r.set_filter(pat)
+    r.dispatch(start, 1)
+    recs, n, tested = r.await_result(1)
+    assert tested == 6 * batch and n == len(recs)
+    want = [i for i in range(6 * batch) if pat.matches(vg.address_from_payload(fmt, blob[20 * i:20 * i + 20]))]
+    got = [idx for idx, pl in recs if pat.matches(vg.address_from_payload(fmt, pl))]
+    assert got == want and len(want) > 0
+    for idx, pl in recs:
+        assert pl == blob[20 * idx:20 * idx + 20]
+    r.close()
+
+
 LAMBDA = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
 
 
