@@ -469,6 +469,18 @@ def main():
     if pmc:
         roofline["issue"] = {k: pmc[k] for k in ("valu_busy", "valu_instr_per_key", "valu_instr_per_key_all_kernels", "waves_per_simd",
                                                  "source", "how") if k in pmc}
+        # The same bound from wall time: VALU instructions retired per second (instructions per key from the counters x the
+        # keys per second of this run) against one wave64 VALU instruction per SIMD every 4 cycles at the measured shader
+        # clock — the issue rate of the instruction classes that make up ~60 % of the mix (v_alignbit, v_add3, v_mad_u64_u32,
+        # v_bfe ...: 35-38 T lane-instructions/s in profiles/r01_ubench_valu.jsonl); v_add / v_xor / v_bitop3 can issue in 2.
+        ipk = pmc.get("valu_instr_per_key_all_kernels")
+        rate_keys = (sustained["value"] if sustained else value) * 1e6 / world
+        if ipk and not args.endo:
+            mhz = shader_mhz or region_mhz or 2400.0
+            peak_t = N_SIMD * mhz * 1e6 / 4.0 * 64 / 1e12
+            roofline["issue"].update({"valu_lane_instr_per_s_T": round(rate_keys * ipk / 1e12, 2),
+                                      "issue_peak_T_at_4_cycles_per_wave_instr": round(peak_t, 2),
+                                      "frac_of_issue_peak": round(rate_keys * ipk / 1e12 / peak_t, 4)})
 
     out = {
         "metric": "Mkeys/sec (keys tried per second)", "value": round(value, 2), "unit": "Mkeys/sec", "n_gpus": world,
