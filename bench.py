@@ -105,6 +105,18 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+def cpu_model():
+    """Model name of the host CPU (core count AND model beside the CPU baseline)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
     """The oracle's restatement of scan_range_cpu (reference src/scanner.rs:211-330) on this host's cores."""
     from oracle import pyoracle as vo
@@ -118,7 +130,7 @@ def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
     # and one thread (SURVEY 8(d) asks for both), on a sample of ~3 s
     n1 = int(max(20000, min(rate / cores * 3.0, 5e6)))
     one = vo.scan_range(fmt, pattern, start, start + n1 - 1, count=10**9, ci=ci, threads=1)
-    return {"value": res["operations"] / res["elapsed_secs"] / 1e6, "unit": "Mkeys/sec", "cores": cores, "kind": "port",
+    return {"value": res["operations"] / res["elapsed_secs"] / 1e6, "unit": "Mkeys/sec", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "single_thread_value": one["operations"] / one["elapsed_secs"] / 1e6,
             "sample": f"oracle scan_range (full scalar mult + hash + encode + regex per key) over {res['operations']} "
                       f"consecutive keys from k0(seed=42), {cores} threads, {res['elapsed_secs']:.1f} s "
@@ -189,13 +201,14 @@ class Pipeline:
         return issued, time.perf_counter() - t0
 
 
-def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, label, note=None, endo=False):
-    """One `other_configs` entry: sustained rate of the dispatch loop for another format / pattern."""
+def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, label, note=None, endo=False, k0=None):
+    """One `other_configs` entry: sustained rate of the dispatch loop for another format / pattern (keys from k0, default
+    the seeded base key)."""
     fmt = vg.AddressFormat(FORMATS[fmt_name])
     r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False, endo=endo)
     pat = vg.Pattern(pattern, ci, fmt)
     r.set_filter(pat if pat.device_kind != 0 else None)
-    p = Pipeline(r, seed_key(42, 0))
+    p = Pipeline(r, seed_key(42, 0) if k0 is None else k0)
     p.run_steps(2 * frames)
     n, dt = p.run_seconds(seconds)
     r.close()
@@ -279,6 +292,31 @@ def dump_mode_configs(vg, batch, device, seconds):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a child process
+    (rendezvous on 127.0.0.1, a free port), pass the same arguments on, relay the one JSON line of rank 0.
+    -> exit code.  The child's stderr goes straight through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in p.stdout.splitlines():     # anything else a library printed there: to stderr, the contract is ONE line on stdout
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if p.returncode == 0 and not lines:
+        print("bench.py: the ranks exited without printing the result line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,9 +335,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    # --gpus N is the number of ranks, one per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) the two must
+    # agree; without one, N > 1 makes this process the launcher: it starts the N ranks as a CHILD (nothing here has
+    # touched HIP or imported torch yet — never an exec of a process that has), relays rank 0's single JSON line and
+    # exits with the child's code.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (one rank per GPU: they must agree)")
 
     import torch   # first: the process then shares torch's HIP runtime with libvgen_hip.so
     import torch.distributed as dist
@@ -308,6 +356,9 @@ def main():
     # VGEN_BENCH_REHEARSE=1: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share
     # devices).  Never the measured configuration: one rank per GPU is.
     rehearse = world > 1 and os.environ.get("VGEN_BENCH_REHEARSE") == "1"
+    if torch.cuda.device_count() < world and not rehearse:
+        sys.exit(f"bench.py: --gpus {world} needs {world} devices, {torch.cuda.device_count()} visible "
+                 "(VGEN_BENCH_REHEARSE=1 lets ranks share a device for a rehearsal; its numbers are not a measurement)")
     if rehearse:
         per_dev = -(-world // torch.cuda.device_count())   # ranks sharing one GPU split the frames between them:
         args.frames = max(2, args.frames // per_dev)       # more than ~20 busy queues per device collapse the throughput
@@ -553,7 +604,7 @@ def main():
         oc += leg(timed_config, vg, "p2wpkh", "dead$", False, args.batch, F, local_rank, sec, "BASELINE config 3: P2WPKH bech32 suffix")
         oc += leg(timed_config, vg, "ethereum", "^0xdead", True, args.batch, F, local_rank, sec, "BASELINE config 5 (one GPU): Ethereum, case-insensitive")
         oc += leg(timed_config, vg, "p2pkh", "^13zb1hQbWVsc2S7ZTZnP2G4undNNpdh5so$", False, args.batch, F, local_rank, sec,
-                  "BASELINE config 4 (one GPU): puzzle-66 exact address", note="keys from k0(seed=42), not the puzzle range: the rate does not depend on the range")
+                  "BASELINE config 4 (one GPU): puzzle-66 exact address", note="sequential scalars from 2^65, the start of the puzzle-66 range [2^65, 2^66 - 1]", k0=1 << 65)
         oc += leg(timed_config, vg, "p2sh-p2wpkh", "^3Cat", False, args.batch, F, local_rank, sec, "P2SH-P2WPKH prefix")
         oc += leg(timed_config, vg, "p2pkh-uncompressed", "^1Cat", False, args.batch, F, local_rank, sec, "P2PKH, uncompressed public key")
         oc += leg(timed_config, vg, "p2tr", "^bc1pqqq", False, args.batch, F, local_rank, sec, "P2TR (taproot tweak on the device)")
@@ -573,7 +624,7 @@ def main():
         try:
             out["cpu_baseline"] = cpu_baseline(args.format, args.pattern, args.ci)
         except Exception as e:   # noqa: BLE001  (the oracle library missing or failing must not cost the line)
-            out["cpu_baseline"] = {"value": None, "unit": "Mkeys/sec", "cores": usable_cores(), "kind": "port", "sample": None,
+            out["cpu_baseline"] = {"value": None, "unit": "Mkeys/sec", "cores": usable_cores(), "cpu_model": cpu_model(), "kind": "port", "sample": None,
                                    "error": f"{type(e).__name__}: {e}"}
     if world > 1:
         dist.destroy_process_group()

@@ -185,6 +185,53 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     assert t["elapsed_ms"] >= t["slowest_rank_ms"] > 0 and abs(t["elapsed_ms"] / 64 - d["ms_per_step"]) < 1e-3
 
 
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if not (env_extra and k in env_extra):
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_gpus_flag_and_launcher_world_size_must_agree():
+    """`--gpus` is the number of ranks: a launcher that started another number is an error, decided before torch or HIP
+    are touched (so it is testable without a device)."""
+    out = _bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=60)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and out.stdout == ""
+    out = _bench(["--gpus", "0"], timeout=60)
+    assert out.returncode != 0
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """Plain `python bench.py --gpus 2` (no launcher) must start two ranks as a child process.  Without a device every rank
+    refuses loudly (no CPU fallback) and the launcher passes the failure on; on a GPU box the twin test below gets the line."""
+    import vgen_amd as vg
+    if vg.device_count() > 0:
+        pytest.skip("a GPU is present: covered by test_bench_plain_gpus_2_prints_n_gpus_2")
+    out = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert out.stderr.count("needs an MI355X") >= 2, out.stderr[-1500:]      # both ranks ran and said so
+
+
+@pytest.mark.gpu
+def test_bench_plain_gpus_2_prints_n_gpus_2():
+    """The driver's shape of command without a launcher: `python bench.py --gpus 2` starts its two ranks itself (here
+    sharing the test box's one GPU, VGEN_BENCH_REHEARSE=1) and relays ONE line with n_gpus = 2; without the rehearsal
+    switch a box with fewer GPUs than ranks is refused instead of silently measuring something else."""
+    import json
+    import vgen_amd as vg
+    args = ["--gpus", "2", "--steps", "64", "--warmup", "8", "--sustained-seconds", "0.3"]
+    out = _bench(args, {"VGEN_BENCH_REHEARSE": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 64 and d["value"] > 1000 and d["config"]["parallelism"].startswith("range-striped x2")
+    if vg.device_count() < 2:
+        out = _bench(args)
+        assert out.returncode != 0 and out.stdout.strip() == "" and "needs 2 devices" in out.stderr
+
+
 def test_cli_warns_about_impossible_patterns_before_touching_the_device():
     """lib.rs:684-706.  Without a device the command then fails loudly (no CPU scan path in this build)."""
     import subprocess
