@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define VGEN_ABI_VERSION 1
+#define VGEN_ABI_VERSION 2   /* 2: frames = 0 selects 12; vgen_get_topology reports streams / priority levels; vgen_dispatch_random;
+                                  vgen_scan_multi returns partial results beside an error */
 
 typedef enum vgen_status {
     VGEN_OK = 0,
@@ -68,8 +69,7 @@ typedef struct vgen_params {
     uint32_t batch_size;   /* keys per dispatch; reference default 524288 (gpu.rs:83); must be a
                               multiple of 8192; 0 selects 1048576 */
     uint32_t format;       /* vgen_format */
-    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 12; max 20 (64 with
-                              VGEN_STREAMS=A,B).  One dispatch is one wave per SIMD, so throughput grows with the frames
+    uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 12; max 20.  One dispatch is one wave per SIMD, so throughput grows with the frames
                               in flight: 7.4 / 11.4 / 12.0 / 12.1 Gkeys/s at 2 / 4 / 8 / 12 (P2PKH, 2^20 keys each).  The
                               first twelve frames get a hardware queue each (vgen_get_topology), whatever
                               GPU_MAX_HW_QUEUES is; multiples of 4 balance the queue pools */
@@ -112,14 +112,14 @@ const char *vgen_last_error(const vgen_ctx *ctx);
 /* The batch size / frame count actually in use (after defaults). */
 int vgen_get_info(const vgen_ctx *ctx, uint32_t *batch_size, uint32_t *frames, uint32_t *match_cap);
 /* How the context reaches the device (the reference's wgpu queue, src/gpu.rs:116-131, has no counterpart to
- * tune).  Default layout: one stream per frame (*fwd_streams = 0, *bwd_streams = frames).  The HIP runtime keeps
- * one pool of GPU_MAX_HW_QUEUES (default 4, reported in *hw_queues) hardware queues per stream priority level, and
- * the context spreads its streams over the three levels: up to 3 x *hw_queues streams own a queue each.
- * *oversubscribed == 1 reports that the context has more streams than that (frames > 12 by default): the surplus
+ * tune): one stream per frame (*streams = frames).  The HIP runtime keeps one pool of GPU_MAX_HW_QUEUES (default 4,
+ * reported in *hw_queues) hardware queues per stream priority level (*priority_levels: 3 on ROCm 7.2), and the
+ * context spreads its streams over the levels: up to *priority_levels x *hw_queues streams own a queue each.
+ * *oversubscribed == 1 reports that the context has more frames than that (frames > 12 by default): the surplus
  * streams share queues, which costs little (11.6 Gkeys/s on 4 queues against 12.1 on 12) but buys nothing.
- * With VGEN_STREAMS=A,B the first halves of all dispatches (denominators, product trees, root inversions) share A
- * streams and their second halves (per-key work, result copies) B streams.  Any pointer may be NULL. */
-int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_streams, uint32_t *hw_queues,
+ * Side effect to know about: frames 4-7 run on the runtime's HIGH priority level and 8-11 on its LOW one, relative to
+ * the host application's own default-priority streams.  Any pointer may be NULL. */
+int vgen_get_topology(const vgen_ctx *ctx, uint32_t *streams, uint32_t *hw_queues, uint32_t *priority_levels,
                       int32_t *oversubscribed);
 
 /* ---- pattern: Pattern::new / Pattern::matches (src/pattern.rs:21-45) -------------------------------- */
@@ -136,8 +136,14 @@ void vgen_filter_free(vgen_filter *f);
 int vgen_filter_matches(const vgen_filter *f, const char *address);
 /* How the device evaluates this filter: 0 = every key is reported to the host (no usable
  * prefilter; reference-equivalent host filtering), 1 = hash160 range test (Base58 prefixes),
- * 2 = masked-bits test (Bech32 / hex prefixes and suffixes), 3 = match-all. */
+ * 2 = masked-bits test (Bech32 / hex prefixes and suffixes), 3 = match-all, 4 = the pattern's whole DFA runs on the
+ * device over the encoded address (unanchored patterns, Base58 suffixes). */
 int vgen_filter_device_kind(const vgen_filter *f);
+/* Size in bytes of the automaton a kind-4 filter stages into LDS (at most 48 KiB; 0 for the other kinds).  With the
+ * product tree (and, on a VGEN_FLAG_ENDO context of the uncompressed / Ethereum formats, the parked y coordinate)
+ * beside it a workgroup must stay within 64 KiB of LDS: an ENDO dispatch whose automaton does not leave room for the
+ * parked coordinate tests the plain keys only (vgen_wait then reports keys_tested = batch_size for it). */
+int vgen_filter_dfa_bytes(const vgen_filter *f);
 /* Pattern::validate_charset(format) (src/pattern.rs:49-177): the characters of `pattern` that can never
  * occur in an address of `format` (literals outside classes; members of non-negated classes with no
  * valid member), in order of first appearance.  Writes up to cap-1 characters + NUL into `out` and the
@@ -154,7 +160,8 @@ const char *vgen_format_charset_name(uint32_t format);
  * index order — the reference kernel's behaviour, src/shaders/search.wgsl:2-31). */
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 
-/* Resizes the match rings of all frames to match_cap records per dispatch (clamped to [256, batch_size]); only while
+/* Resizes the match rings of all frames to match_cap records per dispatch (clamped to [256, batch_size], 6 x batch_size on a
+ * VGEN_FLAG_ENDO context); only while
  * no dispatch is in flight.  vgen_scan uses it to keep permissive patterns on the device filter: the reference hands
  * EVERY hash to the host (src/gpu.rs:602-658); here the ring grows to hold the expected candidates instead. */
 int vgen_set_match_cap(vgen_ctx *ctx, uint32_t match_cap);

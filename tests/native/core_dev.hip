@@ -12,7 +12,7 @@
 using namespace vg;
 
 enum { OP_MUL, OP_SQR, OP_MUL_ADD, OP_SQR_ADD, OP_CANON_PRODUCT, OP_CANON, OP_PARITY_WEAK, OP_INV, OP_NORMALIZE,
-       OP_NORMALIZE_WEAK, OP_NEG, OP_MUL_THEN_CANON_PRODUCT, OP_TO_WORDS };
+       OP_NORMALIZE_WEAK, OP_NEG, OP_MUL_THEN_CANON_PRODUCT, OP_TO_WORDS, OP_INV_FERMAT };
 
 __global__ void __launch_bounds__(64) fe_kernel(int op, int n, const u32 *a, const u32 *b, const u32 *c, u32 *r) {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(64) fe_kernel(int op, int n, const u32 *a, con
     case OP_CANON: w = x; fe_canonicalize(w); break;
     case OP_PARITY_WEAK: w.n[0] = fe_parity_weak(x); break;
     case OP_INV: fe_inv(w, x); break;
+    case OP_INV_FERMAT: fe_inv_fermat(w, x); break;
     case OP_NORMALIZE: w = x; fe_normalize(w); break;
     case OP_NORMALIZE_WEAK: w = x; fe_normalize_weak(w); break;
     case OP_NEG: fe_neg(w, x, y.n[0]); break;

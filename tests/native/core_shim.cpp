@@ -36,6 +36,19 @@ void core_fe_inv(const u32 *a, u32 *r) {
     fe_inv(z, x);
     for (int i = 0; i < 9; i++) r[i] = z.n[i];
 }
+void core_fe_inv_fermat(const u32 *a, u32 *r) {
+    fe x, z;
+    for (int i = 0; i < 9; i++) x.n[i] = a[i];
+    fe_inv_fermat(z, x);
+    for (int i = 0; i < 9; i++) r[i] = z.n[i];
+}
+// One batch of 29 divsteps on given low words (unit test of the matrix against the textbook recurrence).
+int core_fe_divsteps29(int zeta, u32 f, u32 g, int *t) {
+    int32_t tt[4];
+    const int32_t z = fe_divsteps29_(zeta, f, g, tt);
+    for (int i = 0; i < 4; i++) t[i] = tt[i];
+    return z;
+}
 void core_fe_words(const u32 *a, u32 *w, u32 *back) {
     fe x, y;
     for (int i = 0; i < 9; i++) x.n[i] = a[i];

@@ -120,15 +120,67 @@ def test_neg(core, mag):
         assert all(x < 2**32 for x in r)
 
 
+def inverse_vectors(rng, n_random):
+    """Inputs for the inversion tests: edge values, powers of two and their neighbours / negatives (long runs of even
+    or odd divsteps), values whose gcd walk is slow, random ones."""
+    v = [0, 1, 2, 3, P - 1, P - 2, P - 3, (P + 1) // 2, (P - 1) // 2, 2**255, 2**256 % P, 977, 2**32 + 977, 2**32 + 976]
+    v += [(1 << k) % P for k in range(1, 256)] + [P - (1 << k) for k in range(256)] + [(1 << k) - 1 for k in range(2, 257, 7)]
+    v += [pow(3, k, P) for k in range(1, 40)] + [P // k for k in range(2, 40)]
+    v += [rng.randrange(1, P) for _ in range(n_random)]
+    return [x % P for x in v]
+
+
 def test_inv(core):
+    """fe_inv = divsteps (safegcd) inversion: canonical a^-1 against Python, for canonical and for weakly normalised /
+    higher-magnitude inputs; the Fermat ladder (fe_inv_fermat) agrees."""
     rng = random.Random(9)
-    for v in [1, 2, P - 1, P - 2, 2**255, 977] + [rng.randrange(1, P) for _ in range(60)]:
+    for v in inverse_vectors(rng, 4000):
         r = A9()
         core.core_fe_inv(A9(*limbs_of(v)), r)
+        check_mag1(list(r))
+        assert val(r) == (pow(v, -1, P) if v else 0), hex(v)
+    for mag in (1, 2, 3, 7):
+        for style in ["max", "mixed", "rand", "rand", "mixed"]:
+            for _ in range(40):
+                a = rand_limbs(rng, mag, style)
+                r = A9()
+                core.core_fe_inv(A9(*a), r)
+                assert val(r) == (pow(val(a), -1, P) if val(a) % P else 0), a
+    for v in [1, 2, P - 1, P - 2, 2**255, 977] + [rng.randrange(1, P) for _ in range(60)]:
+        r = A9()
+        core.core_fe_inv_fermat(A9(*limbs_of(v)), r)
         assert (val(r) * v) % P == 1
     r = A9()
-    core.core_fe_inv(A9(*limbs_of(0)), r)
+    core.core_fe_inv_fermat(A9(*limbs_of(0)), r)
     assert val(r) % P == 0
+
+
+def test_divsteps_batch_is_the_textbook_recurrence(core):
+    """One batch of 29 divsteps (masks, low 32 bits only) against the definition on Python integers: the matrix t must
+    satisfy t [f, g] = 2^29 [f', g'] for the (f', g') the recurrence reaches, and delta must agree."""
+    rng = random.Random(29)
+    T4 = ctypes.c_int * 4
+    for _ in range(3000):
+        f = rng.getrandbits(rng.choice([8, 31, 64, 256])) | 1
+        g = rng.getrandbits(rng.choice([1, 8, 31, 64, 256])) * rng.choice([1, 1, 2, 16, 2**20])
+        if rng.random() < 0.3:
+            f, g = -f, -g if rng.random() < 0.5 else g
+        twice_delta = rng.choice([1, 1, 3, -1, -5, 7, 29, -41])          # 2 delta, odd
+        zeta = -(twice_delta + 1) // 2                                    # zeta = -(delta + 1/2)
+        t = T4()
+        z2 = core.core_fe_divsteps29(zeta, f & 0xFFFFFFFF, g & 0xFFFFFFFF, t)
+        ff, gg, td = f, g, twice_delta
+        for _i in range(29):
+            if td > 0 and gg & 1:
+                td, ff, gg = 2 - td, gg, (gg - ff) // 2
+            elif gg & 1:
+                td, gg = td + 2, (gg + ff) // 2
+            else:
+                td, gg = td + 2, gg // 2
+        u, v, q, r = list(t)
+        assert u * f + v * g == ff << 29 and q * f + r * g == gg << 29
+        assert z2 == -(td + 1) // 2
+        assert abs(u) + abs(v) <= 1 << 29 and abs(q) + abs(r) <= 1 << 29
 
 
 def test_word_conversion_roundtrip(core):

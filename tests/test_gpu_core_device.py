@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 (OP_MUL, OP_SQR, OP_MUL_ADD, OP_SQR_ADD, OP_CANON_PRODUCT, OP_CANON, OP_PARITY_WEAK, OP_INV, OP_NORMALIZE,
- OP_NORMALIZE_WEAK, OP_NEG, OP_MUL_THEN_CANON_PRODUCT, OP_TO_WORDS) = range(13)
+ OP_NORMALIZE_WEAK, OP_NEG, OP_MUL_THEN_CANON_PRODUCT, OP_TO_WORDS, OP_INV_FERMAT) = range(14)
 H_PUB33, H_PUB65, H_SCRIPT22, H_KECCAK = range(4)
 
 
@@ -149,8 +149,21 @@ def test_device_normalize_neg(dev, mag):
 
 def test_device_inverse_and_word_conversion(dev):
     rng = random.Random(9)
-    vals = [1, 2, P - 1, P - 2, 2**255, 977, 0] + [rng.randrange(1, P) for _ in range(121)]
-    for v, r in zip(vals, run_fe(dev, OP_INV, [limbs_of(v) for v in vals])):
+    from test_core_field import inverse_vectors
+    # the divsteps inversion as hipcc compiles it (signed 64-bit multiply-adds, the wave-uniform early exit: the lanes of
+    # a wave need different numbers of batches, and vectors that finish at once sit beside ones that need them all)
+    vals = inverse_vectors(rng, 1500)
+    rows = run_fe(dev, OP_INV, [limbs_of(v) for v in vals])
+    for v, r in zip(vals, rows):
+        check_mag1(r)
+        assert val(r) == (pow(v, -1, P) if v else 0), hex(v)
+    # weakly normalised / higher-magnitude inputs, as the product trees hand them over
+    cases = [rand_limbs(rng, m, s) for m in (1, 2, 7) for s in ["max", "mixed", "rand"] for _ in range(64)]
+    for x, r in zip(cases, run_fe(dev, OP_INV, cases)):
+        assert val(r) == (pow(val(x), -1, P) if val(x) % P else 0)
+    # ... and the Fermat ladder kept as its cross-check
+    some = vals[:256]
+    for v, r in zip(some, run_fe(dev, OP_INV_FERMAT, [limbs_of(v) for v in some])):
         assert (val(r) * v) % P == (1 if v else 0)
     vals = [0, 1, P - 1, 2**256 - 1, 2**255] + [rng.randrange(2**256) for _ in range(200)]
     for v, r in zip(vals, run_fe(dev, OP_TO_WORDS, [limbs_of(v) for v in vals])):

@@ -645,12 +645,12 @@ def test_frames_own_their_hardware_queues_without_environment_help(vg):
     assert "GPU_MAX_HW_QUEUES" not in os.environ or int(os.environ["GPU_MAX_HW_QUEUES"]) >= 4
     r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=12)
     t = r.topology()
-    assert t["bwd_streams"] == 12 and t["fwd_streams"] == 0 and not t["oversubscribed"]
+    assert t["streams"] == 12 and t["priority_levels"] * t["hw_queues"] >= 12 and not t["oversubscribed"]
     r.close()
     r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=16)
     assert r.topology()["oversubscribed"]          # more frames than queues is allowed, and reported
     r.close()
-    # contexts are created and destroyed repeatedly in one process (streams are recycled, never torn down)
+    # contexts are created and destroyed repeatedly in one process (every context creates and destroys its own streams)
     for frames in (4, 8, 4, 12):
         r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=frames)
         r.set_filter(None)
@@ -741,6 +741,32 @@ def test_endomorphism_with_the_whole_dfa_on_the_device(vg, vo, fmt, pattern, ci)
     for idx in got[:16]:
         k = variant_key(start + idx % batch, idx // batch)
         assert vo.generate(fmt, k)["address"] == vo.address_from_hash160(fmt, blob[20 * idx:20 * idx + 20])
+    r.close()
+
+
+@pytest.mark.parametrize("fmt", [5, 4])
+def test_endomorphism_with_an_automaton_that_nearly_fills_the_lds(vg, vo, fmt):
+    """The formats that park y beside the product tree hold 2 x 9 KiB of static LDS; with a 46.7 KB automaton the workgroup
+    uses 65 136 of its 65 536 bytes.  Such a dispatch must still test all six images and report exactly the oracle's matches
+    (a dispatch whose automaton left no room would test the plain keys only and say so in keys_tested: runtime.cpp)."""
+    batch = 1 << 15
+    pat = vg.Pattern("a.{9}b.c|d{12}", fmt == 5, vg.AddressFormat(fmt))
+    assert pat.device_kind == 4 and 45000 < pat.dfa_bytes <= 64 * 1024 - 2 * 9 * 256 * 4
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), endo=True, match_cap=16384)
+    start = vo.seed_key(33, fmt)
+    r.set_filter(None)
+    r.dispatch(start, 0)
+    blob, _, tested = r.await_result(0)
+    assert tested == 6 * batch
+    r.set_filter(pat)
+    r.dispatch(start, 1)
+    recs, n, tested = r.await_result(1)
+    assert tested == 6 * batch and n == len(recs)
+    ore = vo.Regex("a.{9}b.c|d{12}", fmt == 5)
+    want = [i for i in range(6 * batch) if ore.matches(vo.address_from_hash160(fmt, blob[20 * i:20 * i + 20]))]
+    assert [idx for idx, _ in recs] == want and len(want) > 0
+    for idx in want[:8]:
+        assert vo.generate(fmt, variant_key(start + idx % batch, idx // batch))["address"] == vo.address_from_hash160(fmt, blob[20 * idx:20 * idx + 20])
     r.close()
 
 

@@ -94,6 +94,7 @@ _L.vgen_filter_free.argtypes = [ctypes.c_void_p]
 _L.vgen_filter_free.restype = None
 _L.vgen_filter_matches.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
 _L.vgen_filter_device_kind.argtypes = [ctypes.c_void_p]
+_L.vgen_filter_dfa_bytes.argtypes = [ctypes.c_void_p]
 _L.vgen_pattern_invalid_chars.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t,
                                           ctypes.POINTER(ctypes.c_size_t)]
 _L.vgen_pattern_difficulty.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
@@ -112,7 +113,7 @@ _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match
                          ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
 _L.vgen_read_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
 _L.vgen_dump_view.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
-_L.vgen_get_topology.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint32)] * 3 + [ctypes.POINTER(ctypes.c_int32)]
+_L.vgen_get_topology.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint32)] * 3 + [ctypes.POINTER(ctypes.c_int32)]   # streams, hw_queues, priority_levels, oversubscribed
 _L.vgen_frame_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
 _L.vgen_frame_clock.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
 _L.vgen_frame_dispatch_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
@@ -218,6 +219,11 @@ class Pattern:
     @property
     def device_kind(self) -> int:
         return _L.vgen_filter_device_kind(self._h)
+
+    @property
+    def dfa_bytes(self) -> int:
+        """vgen_filter_dfa_bytes: LDS bytes of the on-device automaton (device_kind 4), else 0."""
+        return _L.vgen_filter_dfa_bytes(self._h)
 
     def validate_charset(self, fmt: Optional[AddressFormat] = None) -> List[str]:
         """Pattern::validate_charset (src/pattern.rs:49-177): characters that can never occur in `fmt` addresses."""
@@ -327,10 +333,11 @@ class GpuRunner:
         self._pattern = None
 
     def topology(self) -> dict:
-        """vgen_get_topology: stage streams of the context, the HIP hardware-queue limit, and whether they fit."""
-        a, b, q, o = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int32()
-        _check(_L.vgen_get_topology(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(q), ctypes.byref(o)), self._h)
-        return {"fwd_streams": a.value, "bwd_streams": b.value, "hw_queues": q.value, "oversubscribed": bool(o.value)}
+        """vgen_get_topology: streams of the context (one per frame), the HIP hardware-queue limit per stream priority
+        level, the number of levels, and whether every stream owns a queue."""
+        a, q, l, o = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int32()
+        _check(_L.vgen_get_topology(self._h, ctypes.byref(a), ctypes.byref(q), ctypes.byref(l), ctypes.byref(o)), self._h)
+        return {"streams": a.value, "hw_queues": q.value, "priority_levels": l.value, "oversubscribed": bool(o.value)}
 
     def dump_view(self, frame: int) -> bytes:
         """vgen_dump_view: the frame's payloads from the pinned buffer its dump-mode dispatch copied itself into."""

@@ -16,8 +16,9 @@
 namespace {
 thread_local std::string g_last_error;
 
-// (No load-time side effects: the library neither sets nor needs GPU_MAX_HW_QUEUES.  A context drives its frames
-// through at most four stage streams — runtime.h — which fit the HIP default of four hardware queues.)
+// (No load-time side effects: the library neither sets nor needs GPU_MAX_HW_QUEUES.  A context drives every frame
+// through a stream of its own, spread over the runtime's stream priority levels so that each owns a hardware queue —
+// runtime.cpp: create_stream.)
 
 int copy_out(const std::string &s, char *out, size_t cap) {
     if (!out || cap < s.size() + 1) return VGEN_E_INVALID;
@@ -97,6 +98,8 @@ int vgen_filter_matches(const vgen_filter *f, const char *address) {
 }
 
 int vgen_filter_device_kind(const vgen_filter *f) { return f ? (int)f->dev.kind : VGEN_E_INVALID; }
+
+int vgen_filter_dfa_bytes(const vgen_filter *f) { return f ? (f->dev.kind == vg::DEVF_DFA ? (int)f->dev.dfa_bytes : 0) : VGEN_E_INVALID; }
 
 int vgen_pattern_invalid_chars(const char *pattern, int case_insensitive, uint32_t format, char *out, size_t cap,
                                size_t *n) {
@@ -193,12 +196,12 @@ int vgen_dump_view(vgen_ctx *ctx, uint32_t frame, const uint8_t **ptr, size_t *l
     return vg::rt_dump_view(ctx, frame, ptr, len);
 }
 
-int vgen_get_topology(const vgen_ctx *ctx, uint32_t *fwd_streams, uint32_t *bwd_streams, uint32_t *hw_queues,
+int vgen_get_topology(const vgen_ctx *ctx, uint32_t *streams, uint32_t *hw_queues, uint32_t *priority_levels,
                       int32_t *oversubscribed) {
     if (!ctx) return VGEN_E_INVALID;
-    if (fwd_streams) *fwd_streams = ctx->n_fwd;
-    if (bwd_streams) *bwd_streams = ctx->n_bwd;
+    if (streams) *streams = ctx->frames;
     if (hw_queues) *hw_queues = ctx->hw_queues;
+    if (priority_levels) *priority_levels = ctx->prio_levels;
     if (oversubscribed) *oversubscribed = vg::rt_oversubscribed(ctx) ? 1 : 0;
     return VGEN_OK;
 }

@@ -98,8 +98,6 @@ struct SeqArgs {
     uint32_t *pre;             // scratch: prefix products [S][9][lanes]
     uint32_t *tree;            // scratch: product-tree nodes [groups][9][SEQ_WG]
     uint32_t *root;            // scratch: tree roots / their inverses [9][groups]
-    uint32_t *arrive;          // scratch: [ceil(groups/64)] arrival counters of seq_fwd's inversion tail (zero between
-                               // dispatches); nullptr = the roots are inverted by a seq_inv_kernel launch instead
     uint32_t lanes;            // N / (2*S)
     uint32_t groups;           // lanes / SEQ_WG
     uint32_t n;                // N
@@ -112,7 +110,7 @@ struct SeqArgs {
     uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22)
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
-    uint32_t prio;             // seq_fwd: raise the waves' issue priority (set by launch_seq_fwd)
+    uint32_t reserved0;
     uint32_t endo;             // seq_bwd: test the six endomorphism / negation images of every point (kernels.hip: ENDO)
     // P2TR only: the tweaked points Q = P + t*G of a dispatch wait for a second shared inversion.
     uint32_t *tq;              // [2S key steps][27][lanes]: X(Q), Z(Q), running product of the lane's Z's

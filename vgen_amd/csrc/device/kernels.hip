@@ -14,7 +14,7 @@
 //     lane chains its S denominators (prefix products parked in L2-resident global scratch); the 256
 //     lane products of a workgroup are combined by an LDS product tree whose ROOT is written out
 //     (seq_fwd_kernel).  seq_inv_kernel then inverts the roots of all workgroups with one root per
-//     LANE — a 270-multiplication Fermat chain is a serial dependency no matter what, so it only pays
+//     LANE — an inversion (divsteps, core/fe.h) is a serial dependency no matter what, so it only pays
 //     when all 64 lanes of the wave carry different roots.  seq_bwd_kernel walks the trees back down
 //     and runs the per-key tail.  Cost per key: ~4.5 field multiplications; the inversion is noise.
 //     (A fused single kernel with the inversion inside was measured first: the lone inverting wave
@@ -28,8 +28,12 @@
 //     paths that need a scalar multiplication per key: arbitrary scalars (keys_fwd / keys_bwd) and the taproot
 //     tweak (seq_bwd<P2TR> parks Q = P + t*G, p2tr_finish_kernel completes it).  Fused forms with the inversion
 //     inside one kernel were measured first and lost a third to a half to the lone inverting wave.
-//   * One launch is ~1 wave per SIMD at the default batch, so the device is filled by frames in flight (16
-//     streams, runtime.cpp); seq_bwd is capped at 128 VGPRs so that four launches share a SIMD.
+//   * One launch is ~1 wave per SIMD at the default batch, so the device is filled by frames in flight (twelve by
+//     default, one stream each: runtime.cpp); seq_bwd is capped at 128 VGPRs so that four launches share a SIMD.
+//   * The waves of the short, latency-bound first half of a dispatch (seq_fwd_kernel, seq_inv_kernel) raise their issue
+//     priority (s_setprio 3) over the seq_bwd waves of other frames they share a SIMD with — same instruction count, but
+//     the chain of the NEXT dispatch is not slowed to a quarter of its speed by the arbiter's round robin
+//     (profiles/r02_queue_sweep.txt: 11.4 instead of 9.5 Gkeys/s at four frames).
 #include <hip/hip_runtime.h>
 
 #include "../core/dfa_eval.h"
@@ -40,36 +44,10 @@
 #include "device_types.h"
 #include "launch.h"
 
-#include <stdlib.h>
-
 namespace vg {
 
 constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 
-// Scheduling knobs of the dispatch chain (host side, read once):
-//   VGEN_CHAIN_PRIO (default 1): the waves of the short, latency-bound first half of a dispatch (seq_fwd_kernel,
-//     seq_inv_kernel) raise their issue priority (s_setprio 3) over the seq_bwd waves of other frames they share
-//     a SIMD with — same instruction count, but the chain of the NEXT dispatch is not slowed to a quarter of its
-//     speed by the arbiter's round robin.
-//   VGEN_BWD_LDS_PAD (bytes, default 0): extra dynamic LDS per seq_bwd workgroup; 40960 caps the kernel at three
-//     workgroups per CU (3 waves per SIMD, 384 of 512 VGPRs), leaving register room for first-half waves of
-//     other frames to start without waiting for a seq_bwd wave to retire.
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-static int chain_prio() {
-    static const int v = env_int("VGEN_CHAIN_PRIO", 1);
-    return v;
-}
-static unsigned bwd_lds_pad() {
-    static const int v = env_int("VGEN_BWD_LDS_PAD", 0);
-    return v > 0 && v <= 48 * 1024 ? (unsigned)v & ~255u : 0u;
-}
-
-#ifndef VG_FWD_TAIL_WAVES
-#define VG_FWD_TAIL_WAVES 4
-#endif
 #ifndef VG_SEQ_WAVES_P2TR
 #define VG_SEQ_WAVES_P2TR 2
 #endif
@@ -228,16 +206,9 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
 
 // ---- stage 1: denominators, per-lane products, workgroup product tree ---------------------------------
 
-// INV_TAIL: the root inversions ride in the tail of this kernel instead of a kernel of their own.  Workgroups
-// are counted in as they publish their root (one counter per run of 64 consecutive workgroups); the workgroup
-// that completes a run inverts its 64 roots, ONE ROOT PER LANE of its first wave, while every other workgroup
-// has already retired — nobody waits on anybody, so the grid drains whatever the residency.  A dispatch is then
-// two launches (fwd+inv -> bwd) and the inversion needs neither a launch nor a hardware queue of its own.
-// (Register budget 128 with the tail: a first-half wave then fits into the slot one retiring seq_bwd wave frees.)
-template <bool INV_TAIL>
-__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(INV_TAIL ? VG_FWD_TAIL_WAVES : 1, INV_TAIL ? VG_FWD_TAIL_WAVES : 8)))
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, 8)))
 seq_fwd_kernel(const SeqArgs args) {
-    if (args.prio) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);
     __shared__ u32 tree[9 * WG];
     const int tid = threadIdx.x;
     const u32 S = args.s;
@@ -287,34 +258,12 @@ seq_fwd_kernel(const SeqArgs args) {
 #pragma unroll
     for (int i = 0; i < 9; i++) tg[i * WG + tid] = tree[i * WG + tid];
     if (tid < 9) args.root[(size_t)tid * args.groups + blockIdx.x] = tree[tid * WG + 1];
-    if (!INV_TAIL || tid >= 64) return;
-
-    // first wave only: release the root, count this workgroup in, and if it was the last of its run, invert
-    const u32 run = blockIdx.x >> 6;
-    const u32 members = min(64u, args.groups - (run << 6));
-    __threadfence();   // the root stores above are visible device-wide (all XCDs) before the arrival is
-    u32 last = 0;
-    if (tid == 0) last = atomicAdd(&args.arrive[run], 1u) == members - 1 ? 1u : 0u;
-    last = (u32)__builtin_amdgcn_readfirstlane((int)last);
-    if (!last) return;
-    __threadfence();   // acquire: the other workgroups' roots, written on other XCDs, are read from memory
-    const u32 g = (run << 6) + (u32)tid;
-    const u32 gg = g < args.groups ? g : args.groups - 1;
-    fe r, ri;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.n[i] = args.root[(size_t)i * args.groups + gg];
-    fe_inv(ri, r);
-    if (g < args.groups) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) args.root[(size_t)i * args.groups + g] = ri.n[i];
-    }
-    if (tid == 0) args.arrive[run] = 0;   // ready for the frame's next dispatch (ordered by the kernel boundary)
 }
 
 // ---- stage 2: invert every workgroup's root, one root per lane -----------------------------------------
 
-__global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups, u32 prio) {
-    if (prio) __builtin_amdgcn_s_setprio(3);
+__global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
+    __builtin_amdgcn_s_setprio(3);
     const u32 g = blockIdx.x * 64 + threadIdx.x;
     const u32 gg = g < groups ? g : groups - 1;
     fe r, ri;
@@ -858,7 +807,7 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEven
     hipLaunchKernelGGL(keys_fwd_kernel, dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups, (u32)chain_prio());
+    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (before_bwd && (e = hipEventRecord(before_bwd, stream)) != hipSuccess) return e;
@@ -1152,7 +1101,7 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
         hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root2, a.groups, (u32)chain_prio());
+        hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root2, a.groups);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (full) hipLaunchKernelGGL((p2tr_finish_kernel<true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
@@ -1162,23 +1111,17 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
     if (full && a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), true, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     else if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     else if (a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
-    else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), bwd_lds_pad(), stream, a);
+    else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
     return hipGetLastError();
 }
 
 
-hipError_t launch_seq_fwd(const SeqArgs &a_in, hipStream_t stream) {
-    if (a_in.lanes % WG != 0 || a_in.groups != a_in.lanes / WG || a_in.s < 2 || a_in.s > SEQ_MAX_S) return hipErrorInvalidValue;
-    SeqArgs a = a_in;
-    a.prio = (u32)chain_prio();
-    if (a.arrive) {
-        hipLaunchKernelGGL(seq_fwd_kernel<true>, dim3(a.groups), dim3(WG), 0, stream, a);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(seq_fwd_kernel<false>, dim3(a.groups), dim3(WG), 0, stream, a);
+hipError_t launch_seq_fwd(const SeqArgs &a, hipStream_t stream) {
+    if (a.lanes % WG != 0 || a.groups != a.lanes / WG || a.s < 2 || a.s > SEQ_MAX_S) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seq_fwd_kernel, dim3(a.groups), dim3(WG), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups, (u32)chain_prio());
+    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
     return hipGetLastError();
 }
 

@@ -7,8 +7,8 @@
 namespace vg {
 
 // The sequential-range scan in its two halves (a.lanes must be a multiple of 256):
-//   launch_seq_fwd  denominators, prefix products, workgroup product trees and the inverted tree roots
-//                   (in the kernel's tail when a.arrive is set, else by a seq_inv_kernel launch behind it);
+//   launch_seq_fwd  denominators, prefix products, workgroup product trees (seq_fwd_kernel) and the inverted tree roots
+//                   (seq_inv_kernel behind it);
 //   launch_seq_bwd  everything per key (tree walk-down, additions, hashes, filter / dump), after the first half
 //                   of the same dispatch has completed (same stream, or an event between two streams).
 hipError_t launch_seq_fwd(const SeqArgs &a, hipStream_t stream);

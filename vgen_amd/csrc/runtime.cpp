@@ -3,13 +3,11 @@
 
 #include <chrono>
 
-#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
-#include <map>
 #include <mutex>
 
 #include "device/launch.h"
@@ -37,9 +35,9 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
     return x > 0 ? (uint32_t)x : dflt;
 }
 
-// pre [S][9][lanes] | tree [groups][9][WG] | root [9][groups] | arrive [ceil(groups/64)]
+// pre [S][9][lanes] | tree [groups][9][WG] | root [9][groups]
 size_t scratch_words(const vgen_ctx *c) {
-    return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups + (c->groups + 63) / 64;
+    return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
 }
 
 // P2TR: tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
@@ -55,83 +53,31 @@ void fe_canon_neg(fe &r, const fe &a) {
 
 size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-// Stage stream `i` of `pool`, created on first use (a stream costs ~5 ms: a scan's first dispatches should be
-// running while the later streams are still being set up).
+// Frame i's stream, created on first use (a stream costs ~5-8 ms: a scan's first dispatches should be running while
+// the later streams are still being set up).
 //
 // Which streams own a hardware queue (measured with tools/queue_probe.hip, profiles/r02_queue_probe.txt): ordinary
 // streams share the runtime's pool of GPU_MAX_HW_QUEUES (default 4) queues — the 5th, 9th, 13th stream each add a
-// full serial round —, but the runtime keeps one such pool PER PRIORITY LEVEL, and CU-masked streams
-// (hipExtStreamCreateWithCUMask, all CUs enabled) get a queue each without limit.  Default: priority pools, i.e.
-// twelve queues with no environment variable and whether or not the host initialised HIP first.  CU-masked
-// streams (VGEN_STREAM_KIND=cumask) measure 3 % faster at 20 frames (12.4 vs 12.1 Gkeys/s at 12) but their
-// teardown is broken on this runtime (ROCm 7.2): hipStreamDestroy deletes the hardware queue, and that was seen
-// to block forever when another process held queues on the device (tools/cli_hang_probe.py), as was creating a
-// stream after such a deletion (second vgen_create of a process); never destroying them instead crashes the
-// runtime's own exit handlers once several contexts have come and gone.  CU-masked streams are therefore cached
-// per process and device and handed from context to context, and left for measurements only.
-struct StreamCache {
-    std::mutex mu;
-    std::map<int, std::vector<hipStream_t>> idle;   // device -> streams not in use by any context
-};
-StreamCache &stream_cache() {
-    static StreamCache *sc = new StreamCache();   // the object itself is never freed (no static-destruction order to get wrong)
-    return *sc;
-}
+// full serial round —, but the runtime keeps one such pool PER PRIORITY LEVEL.  The context therefore spreads its
+// frames' streams over the levels hipDeviceGetStreamPriorityRange reports (three on ROCm 7.2: twelve streams own
+// twelve queues with no environment variable and whether or not the host initialised HIP first); on a runtime with
+// fewer levels the surplus streams share queues, which vgen_get_topology reports as `oversubscribed`.
+// [CU-masked streams (hipExtStreamCreateWithCUMask) also get a queue each and measured 2-3 % faster at 12-20 frames,
+// but their teardown is broken on ROCm 7.2 — see DESIGN.md "two events" — and they are not part of the library.]
 
-// VGEN_DESTROY_STREAMS_AT_EXIT=1: the idle CU-masked streams are destroyed by an atexit() handler registered at the
-// first stream creation — i.e. after the HIP runtime registered its own teardown, so it runs before it (rocprofv3's
-// exit handlers crash on queues that outlive it).
-void destroy_idle_streams() {
-    StreamCache &sc = stream_cache();
-    std::lock_guard<std::mutex> g(sc.mu);
-    for (auto &kv : sc.idle) {
-        if (hipSetDevice(kv.first) != hipSuccess) continue;
-        for (hipStream_t st : kv.second) (void)hipStreamDestroy(st);
-        kv.second.clear();
-    }
-}
-
-// Creates the stream of slot i of a pool (no locking here).
-int create_stream(vgen_ctx *c, bool bwd_pool, uint32_t i, hipStream_t *out, std::string &err) {
-    hipError_t e = hipSuccess;
+// Creates the stream of frame i (no locking here).
+int create_stream(vgen_ctx *c, uint32_t i, hipStream_t *out, std::string &err) {
     *out = nullptr;
-    if (c->stream_kind == STREAMS_CUMASK) {
-        {
-            StreamCache &sc = stream_cache();
-            std::lock_guard<std::mutex> g(sc.mu);
-            auto &idle = sc.idle[c->device];
-            if (!idle.empty()) {
-                *out = idle.back();
-                idle.pop_back();
-            }
-        }
-        if (!*out) {
-            static std::once_flag once;
-            std::call_once(once, []() {
-                const char *v = getenv("VGEN_DESTROY_STREAMS_AT_EXIT");
-                if (v && *v == '1') atexit(destroy_idle_streams);
-            });
-            std::vector<uint32_t> mask((c->cu_count + 31) / 32, 0xFFFFFFFFu);
-            e = hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
-        }
-    } else if (c->stream_kind == STREAMS_PRIORITY) {
-        // the runtime keeps one pool of GPU_MAX_HW_QUEUES hardware queues PER PRIORITY LEVEL: streams 0-3 take
-        // the normal level, 4-7 the next, 8-11 the third, so that twelve streams own twelve queues
-        int least = 0, greatest = 0;
-        if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) == hipSuccess) {
-            const int levels = least - greatest + 1;   // 3 on this runtime: -1 (greatest), 0, 1 (least)
-            const uint32_t n = bwd_pool ? i : c->n_bwd + i;   // bwd slots first, then the fwd slots
-            int prio = 0;
-            if (levels >= 3) {
-                static const int order[3] = {0, -1, 1};
-                prio = order[(n / c->hw_queues) % 3];
-                if (prio < greatest || prio > least) prio = 0;
-            }
-            e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
-        }
-    } else {
-        e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    int prio = 0;
+    if (c->prio_levels >= 3) {
+        // streams 0-3 take the normal level, 4-7 the next, 8-11 the third
+        static const int order[3] = {0, -1, 1};
+        prio = order[(i / c->hw_queues) % 3];
+        if (prio < c->prio_greatest || prio > c->prio_least) prio = 0;
+    } else if (c->prio_levels == 2) {
+        prio = (i / c->hw_queues) % 2 ? c->prio_greatest : c->prio_least;
     }
+    const hipError_t e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
     if (e != hipSuccess) {
         err = std::string("stream creation: ") + hipGetErrorString(e);
         return VGEN_E_HIP;
@@ -139,26 +85,23 @@ int create_stream(vgen_ctx *c, bool bwd_pool, uint32_t i, hipStream_t *out, std:
     return VGEN_OK;
 }
 
-// The stream of slot i, created now if nobody has yet; if somebody (the helper thread) is creating it, waits for that.
-int stage_stream(vgen_ctx *c, std::vector<hipStream_t> &pool, uint32_t i, hipStream_t *out) {
-    const bool bwd_pool = &pool == &c->bwd_streams;
-    std::vector<char> &claimed = bwd_pool ? c->bwd_claimed : c->fwd_claimed;
+// The stream of frame i, created now if nobody has yet; if somebody (the helper thread) is creating it, waits for that.
+int frame_stream(vgen_ctx *c, uint32_t i, hipStream_t *out) {
     std::unique_lock<std::mutex> lk(c->stream_mu);
-    if (claimed.size() < pool.size()) claimed.resize(pool.size(), 0);
-    c->stream_cv.wait(lk, [&]() { return pool[i] || !claimed[i]; });
-    if (!pool[i]) {
-        claimed[i] = 1;
+    c->stream_cv.wait(lk, [&]() { return c->streams[i] || !c->claimed[i]; });
+    if (!c->streams[i]) {
+        c->claimed[i] = 1;
         lk.unlock();
         hipStream_t st = nullptr;
         std::string err;
-        const int rc = create_stream(c, bwd_pool, i, &st, err);
+        const int rc = create_stream(c, i, &st, err);
         lk.lock();
-        claimed[i] = 0;
-        pool[i] = st;
+        c->claimed[i] = 0;
+        c->streams[i] = st;
         c->stream_cv.notify_all();
         if (rc != VGEN_OK) return c->fail(rc, err);
     }
-    *out = pool[i];
+    *out = c->streams[i];
     return VGEN_OK;
 }
 
@@ -187,7 +130,6 @@ static void stop_all_stream_makers() {
 }
 
 bool rt_prepare_streams(vgen_ctx *c) {
-    if (c->stream_kind == STREAMS_CUMASK) return false;   // those are cached per process and teardown-sensitive: first use only
     std::lock_guard<std::mutex> g(c->stream_mu);
     if (c->maker_started) return true;
     c->maker_started = true;
@@ -200,28 +142,22 @@ bool rt_prepare_streams(vgen_ctx *c) {
     }
     c->stream_maker = std::thread([c]() {
         if (hipSetDevice(c->device) != hipSuccess) return;
-        for (int pass = 0; pass < 2; pass++) {
-            const bool bwd_pool = pass == 0;
-            std::vector<hipStream_t> &pool = bwd_pool ? c->bwd_streams : c->fwd_streams;
-            std::vector<char> &claimed = bwd_pool ? c->bwd_claimed : c->fwd_claimed;
-            for (uint32_t i = 0; i < pool.size(); i++) {
-                if (c->maker_cancel.load()) return;
-                {
-                    std::lock_guard<std::mutex> lk(c->stream_mu);
-                    if (claimed.size() < pool.size()) claimed.resize(pool.size(), 0);
-                    if (pool[i] || claimed[i]) continue;
-                    claimed[i] = 1;
-                }
-                hipStream_t st = nullptr;
-                std::string err;
-                (void)create_stream(c, bwd_pool, i, &st, err);   // on failure the slot stays empty: its first user retries and reports
-                {
-                    std::lock_guard<std::mutex> lk(c->stream_mu);
-                    claimed[i] = 0;
-                    pool[i] = st;
-                }
-                c->stream_cv.notify_all();
+        for (uint32_t i = 0; i < c->streams.size(); i++) {
+            if (c->maker_cancel.load()) return;
+            {
+                std::lock_guard<std::mutex> lk(c->stream_mu);
+                if (c->streams[i] || c->claimed[i]) continue;
+                c->claimed[i] = 1;
             }
+            hipStream_t st = nullptr;
+            std::string err;
+            (void)create_stream(c, i, &st, err);   // on failure the slot stays empty: its first user retries and reports
+            {
+                std::lock_guard<std::mutex> lk(c->stream_mu);
+                c->claimed[i] = 0;
+                c->streams[i] = st;
+            }
+            c->stream_cv.notify_all();
         }
     });
     return true;
@@ -229,67 +165,21 @@ bool rt_prepare_streams(vgen_ctx *c) {
 
 bool rt_frame_ready(vgen_ctx *c, uint32_t frame) {
     if (frame >= c->frames) return false;
-    if (c->fr[frame].s_bwd) return true;
+    if (c->fr[frame].s) return true;
     std::lock_guard<std::mutex> g(c->stream_mu);
-    return c->bwd_streams[frame % c->n_bwd] != nullptr && (c->n_fwd == 0 || c->fwd_streams[frame % c->n_fwd] != nullptr);
+    return c->streams[frame] != nullptr;
 }
 
 namespace {
 
-void retire_stream(vgen_ctx *c, hipStream_t st) {
-    if (!st) return;
-    (void)hipStreamSynchronize(st);
-    if (c->stream_kind == STREAMS_CUMASK) {
-        StreamCache &sc = stream_cache();
-        std::lock_guard<std::mutex> g(sc.mu);
-        sc.idle[c->device].push_back(st);
-    } else {
-        (void)hipStreamDestroy(st);
-    }
-}
-
-// Blocking upload that never touches the null stream (whose queue would otherwise be a fifth one next to the
-// four stage streams, and which the non-blocking stage streams do not synchronise with anyway).
+// Blocking upload that never touches the null stream (whose queue would otherwise be one more next to the frames'
+// own, and which the non-blocking frame streams do not synchronise with anyway).
 int upload(vgen_ctx *c, void *dst, const void *src, size_t bytes) {
     hipStream_t st;
-    if (int rc = stage_stream(c, c->bwd_streams, 0, &st)) return rc;
+    if (int rc = frame_stream(c, 0, &st)) return rc;
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     return VGEN_OK;
-}
-
-// VGEN_STREAMS: "frame" (default: one private stream per frame carries both halves of its dispatches) or "A,B"
-// (A streams shared by the first halves, B by the second halves; A may be 0).  Measured with every stream on a
-// hardware queue of its own (profiles/r02_topology_sweep.txt): per-frame streams win at every frame count; the
-// stage layouts only pay when queues are scarce (VGEN_STREAM_KIND=plain with the default GPU_MAX_HW_QUEUES=4:
-// "2,2" reaches 10.8 Gkeys/s where 16 per-frame streams on 4 shared queues reach 9.7).
-// VGEN_FUSED_INV=1: the root inversions ride in seq_fwd's tail (last-arriver pattern, kernels.hip) instead of a
-// seq_inv_kernel launch.  Off by default: it saves a launch, but the tail needs ~128 VGPRs where seq_fwd alone
-// needs 64, which packs worse beside seq_bwd waves once many frames overlap (11.4 vs 11.8 Gkeys/s at 16 frames,
-// 11.5 vs 12.0 at 20), and at 1-8 frames the two forms measure within run-to-run noise of each other
-// (profiles/r02_topology_sweep.txt, profiles/r02_fused_inv_ab.txt).
-void parse_topology(vgen_ctx *c) {
-    const char *v = getenv("VGEN_STREAMS");
-    c->per_frame_streams = true;
-    c->n_fwd = 0;
-    c->n_bwd = c->frames;
-    if (v && *v && strcmp(v, "frame") != 0) {
-        unsigned a = 2, b = 2;
-        if (sscanf(v, "%u,%u", &a, &b) == 2 && a <= 16 && b >= 1 && b <= 16) {
-            c->per_frame_streams = false;
-            c->n_fwd = a;
-            c->n_bwd = b;
-        }
-    }
-    // VGEN_STREAM_KIND: "priority" (default) | "plain" (one priority level: GPU_MAX_HW_QUEUES queues in all) |
-    // "cumask" (CU-masked streams, a hardware queue each without limit — see stage_stream for why not by default)
-    const char *k = getenv("VGEN_STREAM_KIND");
-    if (k && !strcmp(k, "plain")) c->stream_kind = STREAMS_PLAIN;
-    else if (k && !strcmp(k, "cumask")) c->stream_kind = STREAMS_CUMASK;
-    c->fused_inv = false;
-    const char *fi = getenv("VGEN_FUSED_INV");
-    if (fi && (*fi == '0' || *fi == '1')) c->fused_inv = *fi == '1';
-    c->hw_queues = env_u32("GPU_MAX_HW_QUEUES", 4);
 }
 
 }  // namespace
@@ -331,19 +221,18 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         rt_destroy(c);
         return st;
     };
-    if (c->frames > 64) return bail(VGEN_E_INVALID, "frames must be <= 64");
-    parse_topology(c);
-    if (c->per_frame_streams && c->frames > 20)
-        return bail(VGEN_E_INVALID, "frames must be <= 20 (one hardware queue per frame: beyond ~22 busy queues per device the throughput "
-                                    "collapses to ~1 Gkeys/s; VGEN_STREAMS=A,B shares A+B queues among up to 64 frames)");
+    if (c->frames > 20)
+        return bail(VGEN_E_INVALID, "frames must be <= 20 (one stream per frame: beyond ~22 busy queues per device the throughput "
+                                    "collapses to ~1 Gkeys/s)");
+    c->hw_queues = env_u32("GPU_MAX_HW_QUEUES", 4);   // the HIP runtime's own setting: queues per priority level
     if (c->S < 2 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two in [2, 16]");
     if (c->batch % 8192 != 0 || c->batch % (2 * SEQ_WG * c->S) != 0 || c->batch < 8192)
         return bail(VGEN_E_INVALID, "batch_size must be a multiple of 8192 (and of 512*S)");
     if (c->match_cap < FIRST_COPY) c->match_cap = FIRST_COPY;
     c->lanes = c->batch / (2 * c->S);
     c->groups = c->lanes / SEQ_WG;
-    c->fwd_streams.assign(c->n_fwd, nullptr);
-    c->bwd_streams.assign(c->n_bwd, nullptr);
+    c->streams.assign(c->frames, nullptr);
+    c->claimed.assign(c->frames, 0);
 
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return bail(VGEN_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -352,6 +241,13 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device)) != hipSuccess || cus <= 0)
             return bail(VGEN_E_HIP, std::string("hipDeviceGetAttribute: ") + hipGetErrorString(e));
         c->cu_count = (uint32_t)cus;
+        // stream priority levels of this runtime: one pool of hardware queues each (see create_stream)
+        int least = 0, greatest = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) != hipSuccess)
+            return bail(VGEN_E_HIP, std::string("hipDeviceGetStreamPriorityRange: ") + hipGetErrorString(e));
+        c->prio_least = least;
+        c->prio_greatest = greatest;
+        c->prio_levels = (uint32_t)std::max(1, least - greatest + 1);
     }
 
     // One device slab and one pinned slab for all frames (sixteen frames as separate allocations cost ~85 ms of
@@ -401,12 +297,12 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     e = hipMalloc((void **)&c->d_rtab, (size_t)18 * c->lanes * sizeof(uint32_t));
     if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(rtab): ") + hipGetErrorString(e));
     ra.rtab = c->d_rtab;
-    // The match rings (monotonic counters) and the arrival counters start at zero; the rest of the scratch
-    // needs no initialisation but shares the slab.  Cleared and built on stage stream 0 and waited for: the
-    // other stage streams do not synchronise with it, so nothing may be pending when vgen_create returns.
+    // The scratch needs no initialisation (the memset only makes a first read of never-written padding deterministic);
+    // cleared and built on frame 0's stream and waited for: the other frames' streams do not synchronise with it, so
+    // nothing may be pending when vgen_create returns.
     hipStream_t st0 = nullptr;
     lap("hipMalloc rtab");
-    if (stage_stream(c, c->bwd_streams, 0, &st0) != VGEN_OK) return bail(VGEN_E_HIP, c->err);
+    if (frame_stream(c, 0, &st0) != VGEN_OK) return bail(VGEN_E_HIP, c->err);
     lap("stream 0");
     if ((e = hipMemsetAsync(c->d_slab, 0, frame_b * c->frames, st0)) != hipSuccess ||
         (e = launch_rtab_build(ra, st0)) != hipSuccess ||
@@ -427,7 +323,9 @@ int rt_set_match_cap(vgen_ctx *c, uint32_t cap) {
     for (auto &f : c->fr)
         if (f.in_flight) return c->fail(VGEN_E_STATE, "vgen_set_match_cap while a dispatch is in flight");
     if (cap < FIRST_COPY) cap = FIRST_COPY;
-    if (cap > c->batch) cap = c->batch;   // a dispatch cannot report more candidates than keys
+    // a dispatch cannot report more candidates than it tests keys: batch, or six images of each on an ENDO context
+    const uint64_t most = (uint64_t)c->batch * (c->endo ? 6 : 1);
+    if (cap > most) cap = (uint32_t)std::min<uint64_t>(most, 0xFFFFFFFFu);
     if (c->d_match_slab && cap == c->match_cap) return VGEN_OK;
     const size_t match_b = up256(match_bytes(cap));
     uint8_t *d = nullptr, *h = nullptr;
@@ -436,10 +334,17 @@ int rt_set_match_cap(vgen_ctx *c, uint32_t cap) {
         (void)hipFree(d);
         return c->fail(VGEN_E_NOMEM, "match ring allocation failed (pinned host memory)");
     }
+    // from here on every failure releases the two new buffers: the context keeps its old rings
+    auto drop = [&](int rc) {
+        (void)hipFree(d);
+        (void)hipHostFree(h);
+        return rc;
+    };
     hipStream_t st0 = nullptr;
-    if (int rc = stage_stream(c, c->bwd_streams, 0, &st0)) return rc;
-    HIP_TRY(c, hipMemsetAsync(d, 0, match_b * c->frames, st0));
-    HIP_TRY(c, hipStreamSynchronize(st0));
+    if (int rc = frame_stream(c, 0, &st0)) return drop(rc);
+    hipError_t e;
+    if ((e = hipMemsetAsync(d, 0, match_b * c->frames, st0)) != hipSuccess || (e = hipStreamSynchronize(st0)) != hipSuccess)
+        return drop(c->fail(VGEN_E_HIP, std::string("match ring setup: ") + hipGetErrorString(e)));
     if (c->d_match_slab) (void)hipFree(c->d_match_slab);
     if (c->h_slab) (void)hipHostFree(c->h_slab);
     c->d_match_slab = d;
@@ -464,16 +369,14 @@ void rt_destroy(vgen_ctx *c) {
     }
     stop_stream_maker(c);
     (void)hipSetDevice(c->device);
-    for (auto &st : c->fwd_streams)
-        if (st) (void)hipStreamSynchronize(st);
-    for (auto &st : c->bwd_streams)
+    for (auto &st : c->streams)
         if (st) (void)hipStreamSynchronize(st);
     for (auto &f : c->fr) {
-        for (hipEvent_t ev : {f.ev_fwd, f.ev_done, f.ev_start, f.ev_mid, f.ev_stop})
+        for (hipEvent_t ev : {f.ev_done, f.ev_start, f.ev_mid, f.ev_stop})
             if (ev) (void)hipEventDestroy(ev);
     }
-    for (auto &st : c->fwd_streams) retire_stream(c, st);
-    for (auto &st : c->bwd_streams) retire_stream(c, st);
+    for (auto &st : c->streams)
+        if (st) (void)hipStreamDestroy(st);
     if (c->probe_stream) {
         (void)hipStreamSynchronize(c->probe_stream);
         (void)hipStreamDestroy(c->probe_stream);
@@ -488,6 +391,7 @@ void rt_destroy(vgen_ctx *c) {
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_gtab16) (void)hipFree(c->d_gtab16);
+    if (c->d_gtab_small) (void)hipFree(c->d_gtab_small);
     if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
     if (c->d_dfa) (void)hipFree(c->d_dfa);
     if (c->d_filter) (void)hipFree(c->d_filter);
@@ -526,9 +430,22 @@ namespace {
 int ensure_dump_slab(vgen_ctx *c) {
     if (c->d_dump_slab) return VGEN_OK;
     const size_t per = up256((size_t)c->batch * (c->endo ? 6 : 1) * c->payload_words * sizeof(uint32_t));
-    HIP_TRY(c, hipMalloc((void **)&c->d_dump_slab, per * c->frames));
-    HIP_TRY(c, hipHostMalloc((void **)&c->h_dump_slab, per * c->frames, hipHostMallocDefault));
-    for (uint32_t i = 0; i < c->frames; i++) {
+    // Pinned host memory is the scarce part (an ENDO context at the CLI's defaults would pin 1.5 GB, 24 GB at 2^24 keys
+    // per dispatch): dump mode serves at most ~1 GiB worth of frames, never fewer than two — the host-side filter behind
+    // it runs at a few Mkeys/s, so two dumps in flight already keep it fed.  vgen_get_info / rt_dump_frames report it.
+    const size_t budget = (size_t)1 << 30;
+    uint32_t n = (uint32_t)std::min<size_t>(c->frames, std::max<size_t>(2, budget / per));
+    n = std::min(n, c->frames);
+    uint8_t *d = nullptr, *h = nullptr;
+    if (hipMalloc((void **)&d, per * n) != hipSuccess) return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed");
+    if (hipHostMalloc((void **)&h, per * n, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(d);
+        return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed (pinned host memory)");
+    }
+    c->d_dump_slab = d;
+    c->h_dump_slab = h;
+    c->dump_frames = n;
+    for (uint32_t i = 0; i < n; i++) {
         c->fr[i].d_dump = reinterpret_cast<uint32_t *>(c->d_dump_slab + per * i);
         c->fr[i].h_dump = c->h_dump_slab + per * i;
     }
@@ -568,15 +485,11 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
 
 namespace {
 
-// The frame's stage streams and events, created on first use.
+// The frame's stream and events, created on first use.
 int ensure_frame(vgen_ctx *c, uint32_t frame) {
     vgen_ctx::Frame &f = c->fr[frame];
-    if (f.s_bwd) return VGEN_OK;
-    if (int rc = stage_stream(c, c->bwd_streams, frame % c->n_bwd, &f.s_bwd)) return rc;
-    f.s_fwd = f.s_bwd;
-    if (c->n_fwd)
-        if (int rc = stage_stream(c, c->fwd_streams, frame % c->n_fwd, &f.s_fwd)) return rc;
-    HIP_TRY(c, hipEventCreateWithFlags(&f.ev_fwd, hipEventDisableTiming));
+    if (f.s) return VGEN_OK;
+    if (int rc = frame_stream(c, frame, &f.s)) return rc;
     HIP_TRY(c, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
     if (c->timing) {
         HIP_TRY(c, hipEventCreate(&f.ev_start));
@@ -586,17 +499,17 @@ int ensure_frame(vgen_ctx *c, uint32_t frame) {
     return VGEN_OK;
 }
 
-// How vgen_wait waits.  A frame whose bwd stream is its own (the default topology) synchronises that STREAM: the HIP
-// runtime then retires the stream's finished commands as the loop goes.  Waiting on an event instead leaves them to
-// the next device-wide synchronisation, which a host that calls hipDeviceSynchronize / torch.cuda.synchronize()
-// after a scan then pays for in one piece (measured: 0.2-0.4 ms after twenty dispatches, against 10 us).  Frames
-// that share stage streams (VGEN_STREAMS=A,B) wait on the event recorded behind their own dispatch, and so do frames
-// whose streams share hardware queues (more than twelve frames): a stream synchronisation there also waits for the
-// queue's other streams (16 frames: 10.9 instead of 12.0 Gkeys/s).
-inline bool frame_owns_stream(const vgen_ctx *c) { return c->n_bwd >= c->frames && !rt_oversubscribed(c); }
+// How vgen_wait waits.  A frame whose stream owns its hardware queue synchronises that STREAM: the HIP runtime then
+// retires the stream's finished commands as the loop goes.  Waiting on an event instead leaves them to the next
+// device-wide synchronisation, which a host that calls hipDeviceSynchronize / torch.cuda.synchronize() after a scan
+// then pays for in one piece (measured: 0.2-0.4 ms after twenty dispatches, against 10 us).  Frames whose streams share
+// hardware queues (more frames than priority levels x GPU_MAX_HW_QUEUES: more than twelve by default) wait on the
+// event recorded behind their own dispatch: a stream synchronisation there also waits for the queue's other streams
+// (16 frames: 10.9 instead of 12.0 Gkeys/s).
+inline bool frame_owns_stream(const vgen_ctx *c) { return !rt_oversubscribed(c); }
 
 int wait_done(vgen_ctx *c, vgen_ctx::Frame &f) {
-    if (frame_owns_stream(c)) HIP_TRY(c, hipStreamSynchronize(f.s_bwd));
+    if (frame_owns_stream(c)) HIP_TRY(c, hipStreamSynchronize(f.s));
     else HIP_TRY(c, hipEventSynchronize(f.ev_done));
     return VGEN_OK;
 }
@@ -604,12 +517,12 @@ int wait_done(vgen_ctx *c, vgen_ctx::Frame &f) {
 // What follows the last kernel of a dispatch on the frame's bwd stream: the copy of the results and the event
 // vgen_wait waits on.
 int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys) {
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.s_bwd));
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.s));
     if (dump)
-        HIP_TRY(c, hipMemcpyAsync(f.h_dump, f.d_dump, (size_t)std::max<uint64_t>(keys, c->batch) * c->payload_words * sizeof(uint32_t), hipMemcpyDeviceToHost, f.s_bwd));
+        HIP_TRY(c, hipMemcpyAsync(f.h_dump, f.d_dump, (size_t)std::max<uint64_t>(keys, c->batch) * c->payload_words * sizeof(uint32_t), hipMemcpyDeviceToHost, f.s));
     else
-        HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.s_bwd));
-    if (!frame_owns_stream(c)) HIP_TRY(c, hipEventRecord(f.ev_done, f.s_bwd));
+        HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.s));
+    if (!frame_owns_stream(c)) HIP_TRY(c, hipEventRecord(f.ev_done, f.s));
     f.in_flight = true;
     f.dumped = dump;
     f.keys_tested = keys;
@@ -617,7 +530,12 @@ int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys) {
     return VGEN_OK;
 }
 
-int ensure_gtab(vgen_ctx *c) {
+// Generator tables of the paths that multiply a scalar per key.  `wide`: the dispatch is worth the wide-window table
+// (every P2TR dispatch, arbitrary-scalar dispatches of a few thousand keys or more); a handful of keys, or the rare
+// sequential batch that touches the group order, runs on the always-present 8-bit table instead of paying 3.2 GB and
+// ~10 ms for it.  A wide table that cannot be had (allocation or build failure) is not an error either: the context
+// notes why (vgen_last_error) and stays on the 8-bit table.
+int ensure_gtab(vgen_ctx *c, bool wide) {
     const bool trace = getenv("VGEN_TRACE_CREATE") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tlast = now();
@@ -627,7 +545,11 @@ int ensure_gtab(vgen_ctx *c) {
         host_gen_table8_limbs(tab);   // 8-bit windows, 652 800 B (core/ec.h)
         lap("host: 8-bit table");
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
-        if (int rc = upload(c, c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t))) return rc;
+        if (int rc = upload(c, c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t))) {
+            (void)hipFree(c->d_gtab);
+            c->d_gtab = nullptr;
+            return rc;
+        }
         lap("upload");
     }
     // The wide-window table, built on the device from the 8-bit one, once per context: 22-bit windows by default (12
@@ -636,25 +558,32 @@ int ensure_gtab(vgen_ctx *c) {
     // (gen_table_combine_kernel): 20 bits build in 2.6 ms, 22 in ~10, 24 in 31 (one-level build: 40 / 150 ms / -).
     // Measured, KEYS mode Mkeys/s: 8 bits 576, 16 bits (67 MB) 1014, 20 bits (872 MB) 1205, 22 bits 1272, 24 bits
     // (11.8 GB, whose first hipMalloc in a process takes 0.6 s) 1359.  VGEN_GTAB_BITS = 8 | 16 | 20 | 22 | 24 selects.
-    if (!c->d_gtab16) {
+    if (wide && !c->d_gtab16 && !c->gtab_wide_failed) {
         const uint32_t bits = env_u32("VGEN_GTAB_BITS", 22);
-        if (bits == 16 || bits == 20 || bits == 22 || bits == 24) {
-            uint32_t *small = nullptr;   // the half-width table the wide one is combined from (scratch)
-            HIP_TRY(c, hipMalloc((void **)&c->d_gtab16, (size_t)ec_wide_words(bits) * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc((void **)&small, (size_t)ec_wide_words(bits / 2) * sizeof(uint32_t)));
+        if (bits == 8) {
+            c->gtab_wide_failed = true;   // (asked for: nothing to build)
+        } else if (bits == 16 || bits == 20 || bits == 22 || bits == 24) {
+            uint32_t *wide_tab = nullptr, *small = nullptr;   // small: the half-width table the wide one is combined from
+            hipError_t e = hipMalloc((void **)&wide_tab, (size_t)ec_wide_words(bits) * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_wide_words(bits / 2) * sizeof(uint32_t));
             lap("hipMalloc wide + scratch");
             hipStream_t st0 = nullptr;
-            int rc = stage_stream(c, c->bwd_streams, 0, &st0);
-            hipError_t e = hipSuccess;
-            if (rc == VGEN_OK && ((e = launch_gen_table_wide(c->d_gtab, c->d_gtab16, small, bits, st0)) != hipSuccess ||
-                                  (e = hipStreamSynchronize(st0)) != hipSuccess))
-                rc = c->fail(VGEN_E_HIP, std::string("generator table: ") + hipGetErrorString(e));
+            if (e == hipSuccess && frame_stream(c, 0, &st0) != VGEN_OK) e = hipErrorUnknown;
+            if (e == hipSuccess) e = launch_gen_table_wide(c->d_gtab, wide_tab, small, bits, st0);
+            if (e == hipSuccess) e = hipStreamSynchronize(st0);
             lap("two kernels + sync");
-            (void)hipFree(small);
-            lap("hipFree scratch");
-            if (rc != VGEN_OK) return rc;
-            c->gtab_bits = bits;
-        } else if (bits != 8) {
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (wide_tab) (void)hipFree(wide_tab);
+                if (small) (void)hipFree(small);
+                c->gtab_wide_failed = true;
+                c->err = std::string("wide generator table unavailable (") + hipGetErrorString(e) + "): continuing on the 8-bit table";
+            } else {
+                c->d_gtab16 = wide_tab;
+                c->d_gtab_small = small;   // kept until vgen_destroy: freeing it here would synchronise the device under the other frames
+                c->gtab_bits = bits;
+            }
+        } else {
             return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22 or 24");
         }
     }
@@ -680,7 +609,9 @@ int ensure_keys_slab(vgen_ctx *c) {
 // Enqueues the arbitrary-scalar kernels on frame f (its bwd stream carries the whole chain): explicit keys
 // (keys_dev != nullptr) or base + i.
 int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
-    if (int rc = ensure_gtab(c)) return rc;
+    // worth the wide table: taproot contexts (their sequential path builds it anyway) and real arbitrary-scalar batches
+    // (an explicit VGEN_GTAB_BITS is honoured whatever the batch: the parity tests of every width rely on it)
+    if (int rc = ensure_gtab(c, c->format == VGF_P2TR || (keys_dev != nullptr && n >= 4096) || getenv("VGEN_GTAB_BITS") != nullptr)) return rc;
     if (int rc = ensure_keys_slab(c)) return rc;
     KeysArgs a;
     memset(&a, 0, sizeof a);
@@ -701,7 +632,8 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     const bool dump = dump_mode(c);
     if (dump) {
         if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
-        if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.s_bwd));
+        if (!f.d_dump) return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
+        if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.s));
         a.dump = f.d_dump;
     } else {
         a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
@@ -713,8 +645,8 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
             a.dfa_bytes = c->h_filter.dfa_bytes;
         }
     }
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s_bwd));
-    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.s_bwd, c->timing ? f.ev_mid : nullptr));
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s));
+    HIP_TRY(c, launch_keys_scan((int)c->format, a, f.s, c->timing ? f.ev_mid : nullptr));
     return finish_dispatch(c, f, dump, n);
 }
 
@@ -762,7 +694,6 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     a.pre = f.d_scratch;
     a.tree = a.pre + (size_t)S * 9 * c->lanes;
     a.root = a.tree + (size_t)c->groups * 9 * SEQ_WG;
-    a.arrive = c->fused_inv ? a.root + (size_t)9 * c->groups : nullptr;
     a.lanes = c->lanes;
     a.groups = c->groups;
     a.n = c->batch;
@@ -770,6 +701,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     const bool dump = dump_mode(c);
     if (dump) {
         if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
+        if (!f.d_dump) return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
         a.dump = f.d_dump;
     } else {
         a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
@@ -782,11 +714,14 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         }
     }
     a.fmt = c->format;
-    // six images per point (every format but P2TR: c->endo is never set there), whatever the filter
-    const bool endo_now = c->endo;
+    // six images per point (every format but P2TR: c->endo is never set there), whatever the filter — unless the
+    // pattern's automaton leaves no room in a workgroup's 64 KiB of LDS for the y coordinate the uncompressed / Ethereum
+    // formats park beside the product tree (2 x 9 KiB static + the blob): such a dispatch tests the plain keys
+    const bool parks_y = c->format == VGF_P2PKH_UNCOMPRESSED || c->format == VGF_ETHEREUM;
+    const bool endo_now = c->endo && !(a.dfa_bytes && parks_y && a.dfa_bytes + 2u * 9u * SEQ_WG * 4u > 64u * 1024u);
     a.endo = endo_now ? 1u : 0u;
     if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
-        if (int rc = ensure_gtab(c)) return rc;
+        if (int rc = ensure_gtab(c, true)) return rc;
         a.gtab = c->d_gtab;
         a.gtab16 = c->d_gtab16;
         a.gtab_bits = c->gtab_bits;
@@ -799,15 +734,11 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
         a.tree2 = a.tq_flag + flag_words;
         a.root2 = a.tree2 + tree_words;
     }
-    // first half on the frame's fwd stream, second half on its bwd stream behind an event
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s_fwd));
-    HIP_TRY(c, launch_seq_fwd(a, f.s_fwd));
-    if (f.s_fwd != f.s_bwd) {
-        HIP_TRY(c, hipEventRecord(f.ev_fwd, f.s_fwd));
-        HIP_TRY(c, hipStreamWaitEvent(f.s_bwd, f.ev_fwd, 0));
-    }
-    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_mid, f.s_bwd));
-    HIP_TRY(c, launch_seq_bwd((int)c->format, a, f.s_bwd));
+    // the whole chain (seq_fwd -> seq_inv -> seq_bwd [-> P2TR stages] -> result copy) on the frame's own stream
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s));
+    HIP_TRY(c, launch_seq_fwd(a, f.s));
+    if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_mid, f.s));
+    HIP_TRY(c, launch_seq_bwd((int)c->format, a, f.s));
     return finish_dispatch(c, f, dump, endo_now ? (uint64_t)c->batch * 6 : c->batch);
 }
 
@@ -819,7 +750,7 @@ int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = ensure_frame(c, frame)) return rc;
     if (int rc = ensure_keys_slab(c)) return rc;
-    HIP_TRY(c, hipMemcpyAsync(f.d_keys, keys_be, (size_t)n * 32, hipMemcpyHostToDevice, f.s_bwd));
+    HIP_TRY(c, hipMemcpyAsync(f.d_keys, keys_be, (size_t)n * 32, hipMemcpyHostToDevice, f.s));
     memset(&f.start, 0, sizeof f.start);
     return enqueue_keys(c, f, f.d_keys, nullptr, n);
 }
@@ -845,8 +776,8 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
         uint32_t stored = std::min(found, c->match_cap);
         if (stored > FIRST_COPY) {   // rare: the tail of a busy ring, fetched on the frame's own stream
             HIP_TRY(c, hipMemcpyAsync(f.h_match + match_bytes(FIRST_COPY), f.d_match + match_bytes(FIRST_COPY),
-                                      (size_t)(stored - FIRST_COPY) * sizeof(DevMatch), hipMemcpyDeviceToHost, f.s_bwd));
-            if (!frame_owns_stream(c)) HIP_TRY(c, hipEventRecord(f.ev_done, f.s_bwd));
+                                      (size_t)(stored - FIRST_COPY) * sizeof(DevMatch), hipMemcpyDeviceToHost, f.s));
+            if (!frame_owns_stream(c)) HIP_TRY(c, hipEventRecord(f.ev_done, f.s));
             if (int rc = wait_done(c, f)) return rc;
         }
         DevMatch *rec = reinterpret_cast<DevMatch *>(f.h_match + sizeof(DevMatchHeader));
@@ -871,7 +802,7 @@ int rt_frame_times(vgen_ctx *c, uint32_t frame, float *kernel_ms, float *total_m
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame still in flight");
     if (!c->timing) return c->fail(VGEN_E_STATE, "the context was created without VGEN_FLAG_TIMING");
-    if (!f.timing_fresh && f.s_bwd) {
+    if (!f.timing_fresh && f.s) {
         HIP_TRY(c, hipSetDevice(c->device));
         (void)hipEventElapsedTime(&f.last_ms, f.ev_mid, f.ev_stop);
         (void)hipEventElapsedTime(&f.last_total_ms, f.ev_start, f.ev_stop);

@@ -1,12 +1,9 @@
-// runtime.h — the HIP runtime object behind vgen_ctx: device binding, frames (buffers + events), stage
-// streams, offset table, dispatch and readback.  MI355X-native stand-in for the reference's GpuRunner /
-// Frame pair (src/gpu.rs:101-131): hipMalloc'ed buffers sized once, pinned host staging for the rare match
-// records (and the dumps of dump mode).  One launch of the per-key kernel is only one wave per SIMD and a
-// dispatch is a chain of dependent launches, so the device is filled by the frames in flight: by default every
-// frame drives its dispatches through a private stream that OWNS a hardware queue (see stage_stream() in
-// runtime.cpp — no GPU_MAX_HW_QUEUES needed).  Alternatively (VGEN_STREAMS=A,B) the first halves of all
-// dispatches (seq_fwd + root inversions) share A streams and the second halves (seq_bwd, result copies) share
-// B streams, joined by events: the layout for hosts where queues are scarce.
+// runtime.h — the HIP runtime object behind vgen_ctx: device binding, frames (buffers + events + stream), offset
+// table, dispatch and readback.  MI355X-native stand-in for the reference's GpuRunner / Frame pair
+// (src/gpu.rs:101-131): hipMalloc'ed buffers sized once, pinned host staging for the rare match records (and the dumps
+// of dump mode).  One launch of the per-key kernel is only one wave per SIMD and a dispatch is a chain of dependent
+// launches, so the device is filled by the frames in flight: every frame drives its dispatches through a private
+// stream that OWNS a hardware queue (see create_stream() in runtime.cpp — no GPU_MAX_HW_QUEUES needed).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -35,7 +32,9 @@ struct vgen_ctx {
     uint32_t *d_rtab = nullptr;          // [18][lanes]
     uint32_t *d_gtab = nullptr;          // 8-bit fixed-window generator table (arbitrary-scalar path, P2TR), built on first use
     uint32_t *d_gtab16 = nullptr;        // wide fixed-window generator table (gtab_bits bits), built on the device from d_gtab at first use
+    uint32_t *d_gtab_small = nullptr;    // the half-width table the wide one was combined from (scratch, freed with the context)
     uint32_t gtab_bits = 0;
+    bool gtab_wide_failed = false;       // the wide table could not be had (or VGEN_GTAB_BITS=8): stay on the 8-bit one
     vg::DevFilter *d_filter = nullptr;   // current device filter program
     uint32_t *d_dfa = nullptr;           // DEVF_DFA automaton of the current filter
     uint32_t *d_chk_lut = nullptr;       // Bech32 checksum tables of the current filter (when it tests the checksum)
@@ -43,9 +42,8 @@ struct vgen_ctx {
     vg::DevFilter h_filter{};
 
     struct Frame {
-        hipStream_t s_fwd = nullptr, s_bwd = nullptr;   // this frame's stage streams (owned by the context)
-        hipEvent_t ev_fwd = nullptr;     // first half done (s_fwd -> s_bwd), no timing
-        hipEvent_t ev_done = nullptr;    // dispatch complete incl. its copies: what vgen_wait waits on, no timing
+        hipStream_t s = nullptr;         // this frame's stream (owned by the context): carries the whole dispatch chain
+        hipEvent_t ev_done = nullptr;    // dispatch complete incl. its copies: what vgen_wait waits on when streams share queues, no timing
         hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;   // VGEN_FLAG_TIMING: before fwd / before bwd / after bwd
         uint32_t *d_dump = nullptr;      // dump mode: slice of d_dump_slab
         uint8_t *h_dump = nullptr;       // dump mode: pinned mirror, filled by the dispatch's own async copy
@@ -68,30 +66,25 @@ struct vgen_ctx {
         uint32_t last_clk_cycles = 0, last_clk_ticks = 0;   // ... and what the last dispatch added to them
     };
     std::vector<Frame> fr;
-    // stage streams: frame i uses fwd_streams[i % n_fwd] and bwd_streams[i % n_bwd]; n_fwd == 0: the first half
-    // runs on the frame's bwd stream as well (one serial chain per bwd stream); per_frame_streams: the round-1
-    // topology, one private stream per frame for both halves (needs GPU_MAX_HW_QUEUES >= frames to overlap)
-    uint32_t n_fwd = 0, n_bwd = 0;
-    bool per_frame_streams = true;
-    bool fused_inv = false;                      // root inversions in seq_fwd's tail instead of a seq_inv_kernel launch
-    std::vector<hipStream_t> fwd_streams, bwd_streams;
-    // Streams are created at first use (a hardware queue each, ~8 ms) or, once a scan has asked for them
+    // One stream per frame, created at first use (a hardware queue each, ~8 ms) or, once a scan has asked for them
     // (rt_prepare_streams), by a helper thread while the scan runs on the frames it already has.
-    std::mutex stream_mu;                        // guards the two pools' slots and the claims below
+    std::vector<hipStream_t> streams;            // [frames]
+    std::mutex stream_mu;                        // guards the slots and the claims below
     std::condition_variable stream_cv;
-    std::vector<char> bwd_claimed, fwd_claimed;  // slot is being created by somebody: wait for it instead of creating another
+    std::vector<char> claimed;                   // slot is being created by somebody: wait for it instead of creating another
     std::thread stream_maker;
     bool maker_started = false;
     std::atomic<bool> maker_cancel{false};
-    int stream_kind = 1;                         // vg::STREAMS_* (runtime.cpp: stage_stream)
-    uint32_t streams_created = 0;
     uint32_t cu_count = 0;
-    uint32_t hw_queues = 4;                      // GPU_MAX_HW_QUEUES in effect when the context was created
+    uint32_t hw_queues = 4;                      // GPU_MAX_HW_QUEUES in effect when the context was created (queues per priority level)
+    uint32_t prio_levels = 1;                    // stream priority levels the runtime reports (3 on ROCm 7.2) ...
+    int prio_least = 0, prio_greatest = 0;       // ... and their range (hipDeviceGetStreamPriorityRange)
     uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch [| P2TR scratch], per frame)
     uint8_t *d_match_slab = nullptr;             // match rings of all frames (rt_set_match_cap)
     uint8_t *h_slab = nullptr;                   // pinned mirrors of the match rings
     uint8_t *d_dump_slab = nullptr;              // dump mode: payload buffers of all frames (first vgen_set_filter(NULL))
     uint8_t *h_dump_slab = nullptr;              // ... and their pinned mirrors
+    uint32_t dump_frames = 0;                    // frames that have a dump buffer (all of them unless that would pin > ~1 GiB)
     uint8_t *d_keys_slab = nullptr;              // arbitrary-scalar path: keys + scratch of all frames (first use)
     hipStream_t probe_stream = nullptr;          // shader-clock probe (vgen_clock_probe_*)
     unsigned long long *d_probe = nullptr;
@@ -106,14 +99,8 @@ struct vgen_ctx {
 
 namespace vg {
 
-enum { STREAMS_PLAIN = 0, STREAMS_PRIORITY = 1, STREAMS_CUMASK = 2 };
-
-// More stage streams than hardware queues the stream kind provides (plain: GPU_MAX_HW_QUEUES, priority pools: three
-// times that, CU-masked: one each): streams then share queues.
-inline bool rt_oversubscribed(const vgen_ctx *c) {
-    const uint32_t own = c->stream_kind == STREAMS_CUMASK ? 1u << 30 : c->stream_kind == STREAMS_PRIORITY ? 3 * c->hw_queues : c->hw_queues;
-    return c->n_fwd + c->n_bwd > own;
-}
+// More frames than hardware queues the runtime provides (GPU_MAX_HW_QUEUES per priority level): streams then share queues.
+inline bool rt_oversubscribed(const vgen_ctx *c) { return c->frames > c->prio_levels * c->hw_queues; }
 
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
 // Starts (once) a helper thread that creates the stage streams no frame has used yet; rt_frame_ready tells without

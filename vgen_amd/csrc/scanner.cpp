@@ -422,8 +422,11 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         if (ck) batch_matches.push_back(g);
         return take || ck;
     };
-    const uint32_t nf = ctx->frames;
-    std::vector<Pending> pend(nf);
+    // frames this scan drives: all of them, or — filtering full dumps on the host — those that have a dump buffer
+    // (runtime.cpp: ensure_dump_slab bounds the pinned memory; the host filter is the bottleneck there anyway)
+    uint32_t nf = ctx->frames;
+    if (host_all && ctx->dump_frames) nf = std::min(nf, ctx->dump_frames);
+    std::vector<Pending> pend(ctx->frames);
     uint32_t in_flight = 0;
     int status = VGEN_OK;
 
@@ -526,7 +529,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                 // what is in flight, grow the ring (x4, at least twice what this batch produced) — or, once a ring
                 // would need more than half a record per key, switch to host filtering of full dumps, the
                 // reference's mode — and redo from this batch.
-                for (uint32_t f = 0; f < nf; f++)
+                for (uint32_t f = 0; f < ctx->frames; f++)
                     if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
                 const uint64_t want = next_pow2(std::max<uint64_t>((uint64_t)recs.size() * 4, (uint64_t)n_found * 2));
                 if (want <= N / 2) {
@@ -534,6 +537,8 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                     recs.resize(ctx->match_cap);
                 } else if ((status = vgen_set_filter(ctx, nullptr)) != VGEN_OK) {
                     break;
+                } else if (ctx->dump_frames) {
+                    nf = std::min(nf, ctx->dump_frames);
                 }
                 dispatched -= 1 + in_flight;
                 in_flight = 0;
@@ -583,7 +588,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
     const bool all_processed = order.empty() && !cut_any;   // no dispatched batch was left unread or cut short
-    for (uint32_t f = 0; f < nf; f++)
+    for (uint32_t f = 0; f < ctx->frames; f++)
         if (ctx->fr[f].in_flight) (void)vgen_wait(ctx, f, nullptr, 0, nullptr, nullptr);
     if (range_done) *range_done = status == VGEN_OK && !in_range() && all_processed;
     return status;
