@@ -65,8 +65,8 @@ W_FULL_IOP = {"p2pkh": 2 * 1450 + 400, "p2sh-p2wpkh": 2 * 1450 + 400, "p2pkh-unc
 def work_per_key(fmt_name, endo=False, full=False):
     """W of one key.  With VGEN_FLAG_ENDO a curve point serves six keys: its addition is shared by six, two field
     multiplications (beta x, beta^2 x) are added per point, and every key still pays its own hashes.  None for P2TR:
-    its tweak now runs on the 20-bit window table (13 mixed additions instead of 64) and no estimate of that
-    path's work was ever pinned by counters — the entry reports the rate only."""
+    no frozen yardstick describes its per-key scalar multiplication over the wide-window table; its entry carries the
+    issue-bound roofline from measured instructions per key instead (issue_roofline)."""
     if fmt_name == "p2tr":
         return None
     w = W_IMUL[fmt_name] * R_MUL + W_IOP[fmt_name] + (W_FULL_IOP.get(fmt_name, 0) if full else 0)
@@ -216,42 +216,96 @@ def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, labe
     out = {"config": label, "format": fmt_name, "pattern": pattern + (" -i" if ci else ""), "value": round(rate / 1e6, 1),
            "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": n, "device_filter_kind": pat.device_kind,
            "chip_frac": chip_frac(rate, fmt_name, endo, pat.device_kind == 4), "work_per_key": work_per_key(fmt_name, endo, pat.device_kind == 4)}
+    if fmt_name == "p2tr":
+        # no frozen yardstick describes the taproot path (a scalar multiplication per key over the wide-window table): its
+        # roofline is the issue bound the counters name, from the measured instructions per key
+        roof = issue_roofline(rate, ("seq_fwd_kernel", "seq_inv_kernel", "seq_bwd_kernel", "p2tr_finish_kernel"), "p2tr", "seq_bwd_kernel")
+        if roof:
+            out["chip_frac"], out["roofline"] = roof["frac"], roof
     if note:
         out["note"] = note
     return out
 
 
-def keys_mode_config(vg, batch, frames, device, seconds):
+def issue_roofline(rate_keys, kernels, pmc_mode, dominant):
+    """Roofline of a path whose counters (profiles/pmc_keys.json, tools/pmc_keys.sh) name VALU ISSUE as its bound: achieved =
+    keys per second x VALU instructions per key (summed over the path's kernels, from SQ_INSTS_VALU) against one wave64
+    VALU instruction per SIMD every 4 cycles at the nominal 2.4 GHz (the issue rate of the half-rate classes that make up
+    most of the multiplication code: v_mad_u64_u32, v_add3, v_alignbit).  traffic: memory-side bytes per launch of the
+    dominant kernel (FETCH_SIZE x 2 + WRITE_SIZE; for its 64-byte gathers the x2 over-corrects — see the note)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_keys.json")))[pmc_mode]
+    except (OSError, ValueError, KeyError):
+        return None
+    ipk = sum(v["valu_instr_per_key"] for k, v in pmc.items() if any(k.startswith(n) for n in kernels))
+    dom = next((v for k, v in pmc.items() if k.startswith(dominant)), {})
+    peak = N_SIMD * 2.4e9 / 4.0 * 64 / 1e12
+    ach = rate_keys * ipk / 1e12
+    return {"bound": "valu-issue", "achieved": round(ach, 2), "peak": round(peak, 2), "unit": "T lane-instr/s", "frac": round(ach / peak, 4),
+            "traffic": dom.get("fetch_bytes_x2", 0) + dom.get("write_bytes", 0) or None,
+            "valu_instr_per_key": round(ipk, 1), "kernel": dominant,
+            "kernel_valu_busy_alone": dom.get("valu_busy"), "kernel_simd_cycles_per_valu_instr": dom.get("simd_cycles_per_valu_instr"),
+            "kernel_lone_launch_us": dom.get("lone_launch_us_under_pmc"), "kernel_l2_hit_rate": dom.get("l2_hit_rate"),
+            "kernel_hbm_side_gb_per_s": dom.get("hbm_side_gb_per_s"),
+            "note": "bound named by the counters: the dominant kernel alone on the chip has VALU-busy ~1.0 (keys_fwd) / 0.76 (seq_bwd<P2TR>, two "
+                    "waves per SIMD) while its table gathers (one 64-byte sector per window from a multi-GB table, L2 hit ~10 %) stay "
+                    "at 1-2.3 TB/s of the memory side; narrower tables that fit the 256 MB Infinity Cache are SLOWER in proportion to "
+                    "their extra additions (profiles/pmc_keys.json: keys16 / keys20 / keys24) — the gather does not bind, the "
+                    "instruction count of the mixed additions does.  FETCH_SIZE x 2 is the guide's correction for wide streaming reads; "
+                    "for these gathers the uncorrected figure (half) matches the algorithmic 64 B per window."}
+
+
+def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False):
     """Arbitrary-scalar (KEYS) mode: the 'random 256-bit scalar' reading of north_star — a full fixed-base
-    multiplication per key; the 32 B/key are uploaded by every dispatch (the rate includes that PCIe traffic)."""
+    multiplication per key.  random_stream: the scalars are drawn on the device from the counter-based stream
+    (vgen_dispatch_random: nothing uploaded); otherwise 32 B/key are uploaded by every dispatch (vgen_dispatch_keys)."""
     import random
     fmt = vg.AddressFormat.P2pkh
     r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False)
     r.set_filter(vg.Pattern("^1Cat", False, fmt))
-    rng = random.Random(42)
-    blob = b"".join((rng.getrandbits(256) % (N_ORDER - 1) + 1).to_bytes(32, "big") for _ in range(4096)) * (batch // 4096)
+    if random_stream:
+        ctr = [0]
+
+        def go(f):
+            r.dispatch_random(42, 0, ctr[0] * batch, f)
+            ctr[0] += 1
+    else:
+        rng = random.Random(42)
+        blob = b"".join((rng.getrandbits(256) % (N_ORDER - 1) + 1).to_bytes(32, "big") for _ in range(4096)) * (batch // 4096)
+
+        def go(f):
+            r.dispatch_keys(blob, f)
     for f in range(frames):
-        r.dispatch_keys(blob, f)
+        go(f)
     for f in range(frames):
         r.wait(f)
     t0 = time.perf_counter()
     issued = done = fw = 0
     for f in range(frames):
-        r.dispatch_keys(blob, f)
+        go(f)
         issued += 1
     while done < issued:
         r.wait(fw)
         done += 1
         if time.perf_counter() - t0 < seconds:
-            r.dispatch_keys(blob, fw)
+            go(fw)
             issued += 1
         fw = (fw + 1) % frames
     dt = time.perf_counter() - t0
     r.close()
-    return {"config": "arbitrary-scalar (KEYS) mode, P2PKH '^1Cat'", "format": "p2pkh", "pattern": "^1Cat",
-            "value": round(issued * batch / dt / 1e6, 1), "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": issued,
-            "note": "vgen_dispatch_keys: 2^20 independent scalars per dispatch, full k*G each (8-bit fixed windows); "
-                    "includes the 32 MB host-to-device upload of every dispatch"}
+    rate = issued * batch / dt
+    roof = issue_roofline(rate, ("keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel"), "random" if random_stream else "keys", "keys_fwd_kernel") \
+        or (issue_roofline(rate, ("keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel"), "keys", "keys_fwd_kernel") if random_stream else None)
+    return {"config": ("independent random keys drawn on the device (vgen_dispatch_random), P2PKH '^1Cat'" if random_stream
+                       else "arbitrary-scalar (KEYS) mode, uploaded scalars (vgen_dispatch_keys), P2PKH '^1Cat'"),
+            "format": "p2pkh", "pattern": "^1Cat",
+            "value": round(rate / 1e6, 1), "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": issued,
+            "chip_frac": roof["frac"] if roof else None, "roofline": roof,
+            "note": ("the reference CPU loop's shape (rng.fill per candidate, src/scanner.rs:144-152): 2^20 independent scalars per dispatch "
+                     "from the counter-based stream SHA-256('vgen-mi355x-rand' || seed || stream || index), a full k*G each over the 22-bit "
+                     "window table (11 mixed additions); nothing is uploaded" if random_stream else
+                     "2^20 independent scalars per dispatch, a full k*G each over the 22-bit window table (11 mixed additions); includes the "
+                     "32 MB host-to-device upload of every dispatch")}
 
 
 def dump_mode_configs(vg, batch, device, seconds):
@@ -618,6 +672,7 @@ def main():
         oc += leg(timed_config, vg, "p2pkh", "1[Oo]ri", False, args.batch, F, local_rank, sec,
                   "unanchored pattern as a vanity search (VGEN_FLAG_ENDO): on-device Base58Check + DFA on six images per point", endo=True)
         oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec)
+        oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec, random_stream=True)
         oc += leg(dump_mode_configs, vg, args.batch, local_rank, sec)
         out["other_configs"] = oc
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -186,6 +186,16 @@ int vgen_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32])
  * tests keys_be[32*i], i < n <= batch_size, with a full fixed-base multiplication per key.
  * Invalid scalars (0 or >= n) yield no result (address.rs:93). */
 int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n);
+/* Independent random keys — the shape of the reference's CPU hot loop, which draws 32 fresh bytes per candidate
+ * (rng.fill, src/scanner.rs:144-152) — without any upload: lane i of the dispatch tests candidate first_index + i of
+ * the counter-based scalar stream
+ *     key(seed, stream, index) = SHA-256("vgen-mi355x-rand" || u64le(seed) || u32le(stream) || u64le(index)),
+ * computed on the device (one SHA-256 compression per lane); draws that are 0 or >= n yield no result, as the
+ * reference skips them (src/address.rs:93).  A match reports index i: vgen_random_key re-derives its key on the host.
+ * `stream` separates scanners that share a seed (one per GPU / shard).  Always batch_size candidates. */
+int vgen_dispatch_random(vgen_ctx *ctx, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index);
+/* The key vgen_dispatch_random's lane (index - first_index) tests; VGEN_E_RANGE when that draw is not a valid scalar. */
+int vgen_random_key(uint64_t seed, uint32_t stream, uint64_t index, uint8_t key_be[32]);
 /* GpuRunner::await_result(frame) (src/gpu.rs:602-658): blocks until the frame's dispatch is done.
  * Filter mode: copies up to cap records to out (ascending index), stores the number found in
  * *n_matches (may exceed cap: the surplus was dropped) and the number of keys tested in *keys_tested.
@@ -270,8 +280,16 @@ typedef struct vgen_scan_config {
      * VGEN_E_INVALID. */
     const char *checkpoint_path;
     uint32_t checkpoint_interval_ms;   /* 0 = 10 s */
-    uint32_t reserved;
+    uint32_t flags;                    /* VGEN_SCAN_* */
 } vgen_scan_config;
+
+/* vgen_scan_config.flags */
+#define VGEN_SCAN_RANDOM_KEYS 1u   /* scan_with_progress's shape (src/scanner.rs:118-169): every candidate an independent random key
+                                      (vgen_dispatch_random: batch b tests candidates b * batch_size .. of stream `shard` under
+                                      `seed`; seed 0 = OS entropy) instead of the reference GPU path's walk from one base key.
+                                      A full scalar multiplication per key: ~6x slower than the walk.  No start / end /
+                                      checkpoint; not on VGEN_FLAG_ENDO contexts.  With a fixed seed the matches are those of
+                                      the oracle's scan_random walk of the same stream, in the same order. */
 
 /* GeneratedAddress (src/address.rs:63-72). */
 typedef struct vgen_generated {

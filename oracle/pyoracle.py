@@ -167,6 +167,15 @@ def seed_key(seed, shard=0):
     return int.from_bytes(out.raw, "big")
 
 
+def random_key(seed, stream, index):
+    """The oracle's counter-based candidate stream (vo_scan.c: random_key, the keys vo_scan_random's worker `stream`
+    walks): SHA-256("vgen-mi355x-rand" || u64le(seed) || u32le(stream) || u64le(index)) as a big-endian integer.
+    Restated here with hashlib, independently of both C implementations.  Invalid draws (0, >= n) yield no key."""
+    import hashlib
+    return int.from_bytes(hashlib.sha256(b"vgen-mi355x-rand" + seed.to_bytes(8, "little") + stream.to_bytes(4, "little")
+                                         + index.to_bytes(8, "little")).digest(), "big")
+
+
 class Regex:
     """Pattern::new / Pattern::matches (reference src/pattern.rs:21-45)."""
 

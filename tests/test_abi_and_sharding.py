@@ -56,6 +56,26 @@ def test_key_variants_of_endomorphism_contexts_are_lambda_multiples_mod_n():
         vg.key_variant(5, 6)
 
 
+def test_random_key_stream_is_the_oracles():
+    """vgen_random_key (core/rnd.h compiled for the host: the function the kernels run per lane) against the oracle's
+    stream, restated with hashlib (oracle/pyoracle.py) and as walked by the C oracle's scan_random worker."""
+    import random
+    import vgen_amd as vg
+    from oracle import pyoracle as vo
+    n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    rng = random.Random(3)
+    cases = [(42, 0, 0), (42, 0, 1), (2**64 - 1, 2**32 - 1, 2**64 - 1), (0, 0, 0), (1, 2**31, 2**32), (7, 3, 2**40 + 5)]
+    cases += [(rng.getrandbits(64), rng.getrandbits(32), rng.getrandbits(64)) for _ in range(2000)]
+    for seed, stream, index in cases:
+        want = vo.random_key(seed, stream, index)
+        assert vg.random_key(seed, stream, index) == (want if 0 < want < n else None)
+    # the C oracle's single worker walks stream 0 in index order: its matches are candidates of that stream, ascending
+    res = vo.scan_random(0, "^1A", 42, count=4, threads=1)
+    keys = [m["key"] for m in res["matches"]]
+    idx = [i for i in range(2000) if vo.random_key(42, 0, i) in keys]
+    assert len(idx) == 4 and [vo.random_key(42, 0, i) for i in idx] == keys
+
+
 def test_host_side_helpers_match_oracle():
     import vgen_amd as vg
     from oracle import pyoracle as vo

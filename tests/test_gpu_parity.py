@@ -869,3 +869,81 @@ def test_endomorphism_scan_returns_keys_that_really_own_their_addresses(vg, vo):
     for m in res.matches:
         assert "CatS" in m.address and vo.generate(0, int(m.hex, 16))["address"] == m.address
     r.close()
+
+
+# ---- independent random keys drawn on the device (vgen_dispatch_random) ------------------------------------------------
+
+def test_random_dispatch_tests_exactly_the_oracles_candidates(vg, vo):
+    """Lane i of vgen_dispatch_random(seed, stream, first_index) must test candidate first_index + i of the oracle's
+    counter-based stream — the device draws its scalars itself (one SHA-256 per lane), nothing is uploaded.  3 000 lanes
+    and the edge lanes of several (seed, stream, first_index) corners against the oracle's payload of the oracle's key."""
+    batch = 8192
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2)
+    r.set_filter(None)
+    corners = [(42, 0, 0, range(0, 3000)), (42, 0, batch, [0, 1, batch - 1]), (2**64 - 1, 2**32 - 1, 2**64 - batch, [0, 1, 4095, batch - 2, batch - 1]),
+               (0, 0, 2**32 - 5, [0, 4, 5, 6, batch - 1]), (7, 3, 2**40 + 5, [0, 63, 64, 255, 256, batch - 1])]
+    for seed, stream, first, lanes in corners:
+        r.dispatch_random(seed, stream, first, 0)
+        blob, _, tested = r.await_result(0)
+        assert tested == batch and len(blob) == 20 * batch
+        for i in lanes:
+            k = vo.random_key(seed, stream, first + i)
+            want = vo.payload(0, k) if 0 < k < N else bytes(20)
+            assert blob[20 * i:20 * i + 20] == want, (seed, stream, first, i)
+            assert vg.random_key(seed, stream, first + i) == (k if 0 < k < N else None)
+    with pytest.raises(vg.VgenError):
+        r.dispatch_random(1, 0, 2**64 - batch + 1, 1)      # the index range would wrap
+    # the other formats run through the same kernels (keys_bwd_kernel<FMT>)
+    for fmt in (1, 2, 3, 4, 5):
+        rf = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=1)
+        rf.set_filter(None)
+        rf.dispatch_random(99, fmt, 123456789, 0)
+        blob, _, _ = rf.await_result(0)
+        pl = 32 if fmt == 3 else 20
+        for i in list(range(0, 200)) + [batch - 1]:
+            assert blob[pl * i:pl * i + pl] == vo.payload(fmt, vo.random_key(99, fmt, 123456789 + i)), (fmt, i)
+        rf.close()
+    # filter mode reports exactly the candidates the oracle's regex accepts
+    r.dispatch_random(5, 1, 0, 0)
+    blob, _, _ = r.await_result(0)
+    pat = vg.Pattern("^1[A-H]", False, vg.AddressFormat.P2pkh)
+    r.set_filter(pat)
+    r.dispatch_random(5, 1, 0, 1)
+    recs, n, tested = r.await_result(1)
+    ore = vo.Regex("^1[A-H]", False)
+    want = [i for i in range(batch) if ore.matches(vo.address_from_hash160(0, blob[20 * i:20 * i + 20]))]
+    assert [i for i, pl in recs if ore.matches(vo.address_from_hash160(0, pl))] == want and len(want) > 50
+    r.close()
+
+
+def test_random_key_scan_finds_what_the_oracles_random_walk_finds(vg, vo):
+    """VGEN_SCAN_RANDOM_KEYS is the reference CPU path's shape (an independent random key per candidate,
+    src/scanner.rs:118-169) on the device.  With a fixed seed the scan must return the matches of the oracle's
+    scan_random walk of stream 0 — same keys, same addresses and WIFs, same order —, operations counted per batch."""
+    r = vg.GpuRunner(batch_size=16384, fmt=vg.AddressFormat.P2pkh, frames=3)
+    ref = vo.scan_random(0, "^1Ab", 42, count=6, threads=1)
+    res = vg.scan_gpu_with_runner("^1Ab", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=6, seed=42, random_keys=True), r)
+    assert [(m.address, m.wif, int(m.hex, 16)) for m in res.matches] == [(x["address"], x["wif"], x["key"]) for x in ref["matches"]]
+    assert res.operations % 16384 == 0 and res.operations > 0
+    # every match is a candidate of the stream (and none of them a neighbour of another: the keys are independent)
+    keys = sorted(int(m.hex, 16) for m in res.matches)
+    assert all(b - a > 2**128 for a, b in zip(keys, keys[1:]))
+    # shards own streams of their own: shard 1 of 2 finds the oracle's stream-1 candidates
+    res1 = vg.scan_gpu_with_runner("^1Ab", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=2, seed=42, random_keys=True, shard=1, n_shards=2), r)
+    found = [int(m.hex, 16) for m in res1.matches]
+    idx = [i for i in range(res1.operations) if vo.random_key(42, 1, i) in found][:2] if res1.operations <= 200000 else None
+    if idx is not None:
+        assert [vo.random_key(42, 1, i) for i in idx] == found
+    for m in res1.matches:
+        assert vo.generate(0, int(m.hex, 16))["address"] == m.address and m.address.startswith("1Ab")
+    # unseeded: OS entropy, matches still re-derive on the oracle
+    res2 = vg.scan_gpu_with_runner("^1A", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=3, random_keys=True), r)
+    assert len(res2.matches) == 3
+    for m in res2.matches:
+        g = vo.generate(0, int(m.hex, 16))
+        assert (g["address"], g["wif"]) == (m.address, m.wif)
+    # refused combinations
+    for cfg in (vg.ScanConfig(count=1, random_keys=True, start=5), vg.ScanConfig(count=1, random_keys=True, end=2**64)):
+        with pytest.raises(vg.VgenError):
+            vg.scan_gpu_with_runner("^1A", cfg, r)
+    r.close()

@@ -6,10 +6,10 @@ bench.py; names mirror the reference (src/address.rs, src/scanner.rs, src/patter
 There is no CPU fallback: importing works anywhere, creating a GpuRunner needs an MI355X.
 """
 from .api import (AddressFormat, GeneratedAddress, GpuRunner, Pattern, ScanConfig, ScanResult, VgenError,
-                  abi_version, address_from_payload, derive, device_count, device_name, key_add, key_variant, key_to_wif,
+                  abi_version, address_from_payload, derive, device_count, device_name, key_add, key_variant, key_to_wif, random_key,
                   library_path, scan_gpu_with_runner, ProviderResult, provider_resolve, build_pattern, build_exact_pattern)
 
 __all__ = ["AddressFormat", "GeneratedAddress", "GpuRunner", "Pattern", "ScanConfig", "ScanResult", "VgenError",
            "abi_version", "address_from_payload", "derive", "device_count", "device_name", "key_add", "key_variant",
-           "key_to_wif", "library_path", "scan_gpu_with_runner", "ProviderResult", "provider_resolve", "build_pattern",
+           "key_to_wif", "random_key", "library_path", "scan_gpu_with_runner", "ProviderResult", "provider_resolve", "build_pattern",
            "build_exact_pattern"]

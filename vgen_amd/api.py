@@ -67,7 +67,10 @@ class _ScanConfig(ctypes.Structure):
                 ("has_end", ctypes.c_int32), ("end", ctypes.c_uint8 * 32), ("seed", ctypes.c_uint64),
                 ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("max_batches", ctypes.c_uint64),
                 ("checkpoint_path", ctypes.c_char_p), ("checkpoint_interval_ms", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32)]
+
+
+SCAN_RANDOM_KEYS = 1   # VGEN_SCAN_RANDOM_KEYS
 
 
 class _Generated(ctypes.Structure):
@@ -109,6 +112,8 @@ _L.vgen_clock_probe_start.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
 _L.vgen_clock_probe_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 _L.vgen_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
 _L.vgen_dispatch_keys.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
+_L.vgen_dispatch_random.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
+_L.vgen_random_key.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
 _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match), ctypes.c_uint32,
                          ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
 _L.vgen_read_dump.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
@@ -177,6 +182,17 @@ def key_add(key, amount):
     out = ctypes.create_string_buffer(32)
     rc = _L.vgen_key_add(_key(key), amount, out)
     return None if rc == E_RANGE else int.from_bytes(out.raw, "big")
+
+
+def random_key(seed, stream, index):
+    """vgen_random_key: candidate `index` of stream `stream` under `seed` of the counter-based scalar stream
+    (vgen_dispatch_random); None when that draw is not a valid scalar."""
+    out = ctypes.create_string_buffer(32)
+    rc = _L.vgen_random_key(seed, stream, index, out)
+    if rc == -7:
+        return None
+    _check(rc)
+    return int.from_bytes(out.raw, "big")
 
 
 def key_variant(key, variant):
@@ -301,6 +317,7 @@ class ScanConfig:
     max_batches: int = 0
     checkpoint_path: Optional[str] = None      # resumable scans (vgen_scan_config.checkpoint_path)
     checkpoint_interval_ms: int = 0
+    random_keys: bool = False       # VGEN_SCAN_RANDOM_KEYS: an independent random key per candidate (scanner.rs:118-169's shape)
 
 
 @dataclass
@@ -368,6 +385,11 @@ class GpuRunner:
         self._n_keys = n
         _check(_L.vgen_dispatch_keys(self._h, frame, blob, n), self._h)
 
+    def dispatch_random(self, seed: int, stream: int, first_index: int, frame: int):
+        """vgen_dispatch_random: batch_size independent random keys drawn on the device from the counter-based stream."""
+        self._n_keys = self.batch_size
+        _check(_L.vgen_dispatch_random(self._h, frame, seed, stream, first_index), self._h)
+
     def await_result(self, frame: int):
         """Filter mode: (list of (index, payload20), n_found, keys_tested).  Dump mode: (bytes, 0, keys_tested)."""
         recs = (_Match * self.match_cap)()
@@ -434,6 +456,7 @@ def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
     if config.checkpoint_path:
         c.checkpoint_path = os.fsencode(config.checkpoint_path)
         c.checkpoint_interval_ms = config.checkpoint_interval_ms
+    c.flags = SCAN_RANDOM_KEYS if config.random_keys else 0
     res = _ScanResult()
     cb = _PROGRESS(lambda ops, _u: progress_cb(ops)) if progress_cb else ctypes.cast(None, _PROGRESS)
     stop_p = ctypes.byref(stop) if stop is not None else None

@@ -180,6 +180,16 @@ int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, ui
     return vg::rt_dispatch_keys(ctx, frame, keys_be, n);
 }
 
+int vgen_dispatch_random(vgen_ctx *ctx, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
+    if (!ctx) return VGEN_E_INVALID;
+    return vg::rt_dispatch_random(ctx, frame, seed, stream, first_index);
+}
+
+int vgen_random_key(uint64_t seed, uint32_t stream, uint64_t index, uint8_t key_be[32]) {
+    if (!key_be) return VGEN_E_INVALID;
+    return vg::random_key_be(seed, stream, index, key_be) ? VGEN_OK : VGEN_E_RANGE;
+}
+
 int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
               uint64_t *keys_tested) {
     if (!ctx) return VGEN_E_INVALID;

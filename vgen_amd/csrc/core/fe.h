@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define VG_HD __host__ __device__ __forceinline__
 #else
 #define VG_HD inline

@@ -130,7 +130,11 @@ struct KeysArgs {
     const uint32_t *gtab;      // [32][255][20]: x limbs 0..8, y limbs 9..17 of d * 256^w * G (d = 1..255)
     const uint32_t *gtab16;    // wide windows: [windows][2^bits - 1][16 words] (core/ec.h: ec_mul_gen_wide); nullptr = use gtab
     uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22)
-    const uint8_t *keys_be;    // n * 32 bytes big-endian, or nullptr: key i = base + i
+    const uint8_t *keys_be;    // n * 32 bytes big-endian, or nullptr: key i = base + i, or (rnd) drawn from the scalar stream
+    uint32_t rnd;              // 1: key i = rnd_scalar(rnd_seed, rnd_stream, rnd_index + i) (core/rnd.h); keys_be and base unused
+    uint32_t rnd_stream;
+    uint32_t rnd_seed[2];      // lo, hi
+    uint32_t rnd_index[2];     // index of lane 0: lo, hi
     const DevFilter *filter;
     uint32_t *dump;            // dump mode: n * 5 words (zeroed for invalid keys)
     DevMatchHeader *mhdr;

@@ -40,6 +40,7 @@
 #include "../core/ec.h"
 #include "../core/filter_eval.h"
 #include "../core/hash.h"
+#include "../core/rnd.h"
 #include "../core/taproot.h"
 #include "device_types.h"
 #include "launch.h"
@@ -646,11 +647,16 @@ __global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
 constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                             0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
-// Scalar of lane `idx` as eight little-endian words; false (and k = 1, a harmless stand-in whose result is
-// discarded) unless 0 < k < n (SecretKey::from_slice, src/address.rs:93) and idx < n.
+// Scalar of lane `idx` as eight little-endian words — uploaded (keys_be), base + idx, or drawn from the counter-based
+// stream (rnd: the reference's rng.fill per candidate, src/scanner.rs:151-152) —; false (and k = 1, a harmless stand-in
+// whose result is discarded) unless 0 < k < n (SecretKey::from_slice, src/address.rs:93) and idx < n.
 __device__ __forceinline__ bool keys_load_scalar(const KeysArgs &args, u32 idx, u32 k[8]) {
     const bool in_range = idx < args.n;
-    if (args.keys_be) {
+    if (args.rnd) {
+        // the counter-based scalar stream (core/rnd.h): one SHA-256 compression per lane, no upload
+        const u64 index = ((u64)args.rnd_index[1] << 32 | args.rnd_index[0]) + idx;
+        rnd_scalar(args.rnd_seed[0], args.rnd_seed[1], args.rnd_stream, (u32)index, (u32)(index >> 32), k);
+    } else if (args.keys_be) {
         const u32 *src = reinterpret_cast<const u32 *>(args.keys_be) + (size_t)(in_range ? idx : 0) * 8;
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = bswap32(src[7 - i]);

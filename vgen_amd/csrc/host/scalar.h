@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "../core/rnd.h"
+
 namespace vg {
 
 struct Scalar {
@@ -153,6 +155,15 @@ inline void scalar_variant(Scalar &r, const Scalar &k, uint32_t v) {
         scalar_negate(t, r);
         r = t;
     }
+}
+
+// Candidate `index` of stream `stream` under `seed` of the counter-based scalar stream (core/rnd.h) as 32 big-endian
+// bytes; false when the draw is not a valid scalar (such candidates yield no key, as in the reference's CPU loop).
+inline bool random_key_be(uint64_t seed, uint32_t stream, uint64_t index, uint8_t be[32]) {
+    Scalar k;
+    rnd_scalar((uint32_t)seed, (uint32_t)(seed >> 32), stream, (uint32_t)index, (uint32_t)(index >> 32), k.w);
+    scalar_to_be(k, be);
+    return scalar_is_valid(k);
 }
 
 }  // namespace vg

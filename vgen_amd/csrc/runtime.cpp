@@ -608,10 +608,16 @@ int ensure_keys_slab(vgen_ctx *c) {
 
 // Enqueues the arbitrary-scalar kernels on frame f (its bwd stream carries the whole chain): explicit keys
 // (keys_dev != nullptr) or base + i.
-int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
+struct RandomStream {
+    uint64_t seed;
+    uint32_t stream;
+    uint64_t first_index;
+};
+
+int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n, const RandomStream *rnd = nullptr) {
     // worth the wide table: taproot contexts (their sequential path builds it anyway) and real arbitrary-scalar batches
     // (an explicit VGEN_GTAB_BITS is honoured whatever the batch: the parity tests of every width rely on it)
-    if (int rc = ensure_gtab(c, c->format == VGF_P2TR || (keys_dev != nullptr && n >= 4096) || getenv("VGEN_GTAB_BITS") != nullptr)) return rc;
+    if (int rc = ensure_gtab(c, c->format == VGF_P2TR || ((keys_dev != nullptr || rnd != nullptr) && n >= 4096) || getenv("VGEN_GTAB_BITS") != nullptr)) return rc;
     if (int rc = ensure_keys_slab(c)) return rc;
     KeysArgs a;
     memset(&a, 0, sizeof a);
@@ -621,6 +627,14 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     a.keys_be = keys_dev;
     if (base)
         for (int i = 0; i < 8; i++) a.base[i] = base->w[i];
+    if (rnd) {
+        a.rnd = 1;
+        a.rnd_stream = rnd->stream;
+        a.rnd_seed[0] = (uint32_t)rnd->seed;
+        a.rnd_seed[1] = (uint32_t)(rnd->seed >> 32);
+        a.rnd_index[0] = (uint32_t)rnd->first_index;
+        a.rnd_index[1] = (uint32_t)(rnd->first_index >> 32);
+    }
     a.filter = c->d_filter;
     a.n = n;
     a.fmt = c->format;
@@ -753,6 +767,20 @@ int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32
     HIP_TRY(c, hipMemcpyAsync(f.d_keys, keys_be, (size_t)n * 32, hipMemcpyHostToDevice, f.s));
     memset(&f.start, 0, sizeof f.start);
     return enqueue_keys(c, f, f.d_keys, nullptr, n);
+}
+
+// Independent random keys (the reference CPU path's shape, src/scanner.rs:144-155) with no upload: lane i draws
+// key(seed, stream, first_index + i) from the counter-based stream of core/rnd.h on the device.
+int rt_dispatch_random(vgen_ctx *c, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
+    if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
+    if (first_index + c->batch < first_index) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
+    vgen_ctx::Frame &f = c->fr[frame];
+    if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_frame(c, frame)) return rc;
+    memset(&f.start, 0, sizeof f.start);
+    const RandomStream rs{seed, stream, first_index};
+    return enqueue_keys(c, f, nullptr, nullptr, c->batch, &rs);
 }
 
 int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches, uint64_t *keys_tested) {

@@ -113,6 +113,7 @@ int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 int rt_set_match_cap(vgen_ctx *ctx, uint32_t cap);
 int rt_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]);
 int rt_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n);
+int rt_dispatch_random(vgen_ctx *ctx, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index);
 int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
             uint64_t *keys_tested);
 int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);

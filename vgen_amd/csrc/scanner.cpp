@@ -66,10 +66,6 @@ void seed_key(uint64_t seed, uint32_t shard, Scalar &out) {
 
 namespace {
 
-struct Pending {
-    Scalar start;
-    bool valid = false;
-};
 
 void random_valid_key(Scalar &k) {
     std::random_device rd;
@@ -81,14 +77,28 @@ void random_valid_key(Scalar &k) {
 
 // `images`: 1, or 6 when the dispatch tested the endomorphism / negation images of every point: index is then
 // variant * batch + i and the key is variant `index / batch` of batch_start + i (host/scalar.h).
-bool make_match(const vgen_filter &flt, uint32_t format, const Scalar &batch_start, uint32_t index,
+// How a batch's candidate index maps to its private key: batch_start + index (the walk), or the counter-based stream.
+struct BatchKeys {
+    Scalar start{};
+    bool random = false;
+    uint64_t seed = 0, first_index = 0;
+    uint32_t stream = 0;
+};
+
+bool make_match(const vgen_filter &flt, uint32_t format, const BatchKeys &bk, uint32_t index,
                 const uint8_t *payload, const Scalar *end, vgen_generated &g, uint32_t batch = 0, uint32_t images = 1) {
     std::string addr = address_from_payload(format, payload);
     if (addr.empty() || !flt.dfa.is_match(addr)) return false;          // pattern.matches, gpu.rs:1069
     Scalar k;
     const uint32_t variant = images > 1 ? index / batch : 0;
     if (images > 1) index %= batch;
-    if (scalar_add_u64(k, batch_start, index) || !scalar_is_valid(k)) return false;   // increment_key -> None
+    if (bk.random) {
+        uint8_t rk[32];
+        if (!random_key_be(bk.seed, bk.stream, bk.first_index + index, rk)) return false;   // not a valid draw: no key
+        scalar_from_be(k, rk);
+    } else if (scalar_add_u64(k, bk.start, index) || !scalar_is_valid(k)) {
+        return false;                                                   // increment_key -> None
+    }
     if (variant) {
         Scalar kv;
         scalar_variant(kv, k, variant);
@@ -346,6 +356,10 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     if (ctx->endo && (cfg->has_start || cfg->has_end || cfg->seed || cfg->n_shards > 1 || cfg->checkpoint_path))
         return ctx->fail(VGEN_E_INVALID, "a VGEN_FLAG_ENDO context tests six images of every point, not a contiguous key range: "
                                          "it serves unseeded random scans only (no start / end / seed / shards / checkpoint)");
+    const bool random_keys = (cfg->flags & VGEN_SCAN_RANDOM_KEYS) != 0;
+    if (random_keys && (ctx->endo || cfg->has_start || cfg->has_end || cfg->checkpoint_path))
+        return ctx->fail(VGEN_E_INVALID, "VGEN_SCAN_RANDOM_KEYS draws an independent key per candidate: no start / end / checkpoint, "
+                                         "and not on a VGEN_FLAG_ENDO context");
 
     const uint32_t N = ctx->batch;
     const size_t pbytes = (size_t)ctx->payload_words * 4;
@@ -377,8 +391,17 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     int rc = vgen_set_filter(ctx, host_all ? nullptr : &flt);
     if (rc != VGEN_OK) return rc;
 
+    // independent random keys: candidate index = batch number x N within stream `shard` of the seed
+    uint64_t rnd_seed = cfg->seed;
+    if (random_keys && !rnd_seed) {
+        std::random_device rd;
+        while (!rnd_seed) rnd_seed = ((uint64_t)rd() << 32) | rd();
+    }
     Scalar current;
-    if (cfg->has_start) {
+    if (random_keys) {
+        memset(&current, 0, sizeof current);
+        current.w[0] = 1;   // (unused: keeps the range bookkeeping below on valid ground)
+    } else if (cfg->has_start) {
         scalar_from_be(current, cfg->start);
     } else if (cfg->seed) {
         seed_key(cfg->seed, 0, current);   // one base; shards stripe it (deterministic multi-GPU)
@@ -394,7 +417,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     }
     // batch striping: this context takes global batches shard, shard + shards, ...
     bool exhausted = false;
-    if (shard) exhausted = scalar_add_u64(current, current, (uint64_t)shard * N) || !scalar_is_valid(current);
+    if (shard && !random_keys) exhausted = scalar_add_u64(current, current, (uint64_t)shard * N) || !scalar_is_valid(current);
     const uint64_t stride = (uint64_t)shards * N;
     if (ck && !exhausted) {   // resume: this shard's first `skip` batches are already in the checkpoint
         uint64_t skip = ck->done[ck_slot];
@@ -426,7 +449,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     // (runtime.cpp: ensure_dump_slab bounds the pinned memory; the host filter is the bottleneck there anyway)
     uint32_t nf = ctx->frames;
     if (host_all && ctx->dump_frames) nf = std::min(nf, ctx->dump_frames);
-    std::vector<Pending> pend(ctx->frames);
+    std::vector<BatchKeys> pend(ctx->frames);
     uint32_t in_flight = 0;
     int status = VGEN_OK;
 
@@ -434,12 +457,29 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     auto in_range = [&]() { return !exhausted && (!end || scalar_cmp(current, *end) <= 0); };
     auto can_dispatch = [&]() { return in_range() && (!cfg->max_batches || dispatched < cfg->max_batches); };
     auto dispatch = [&](uint32_t frame) -> int {
+        if (random_keys) {
+            // every shard owns a stream of its own and walks its candidates in order (the oracle's worker thread, oracle/vo_scan.c)
+            const uint64_t first = dispatched * (uint64_t)N;
+            if (first / N != dispatched || first + N < first) {
+                exhausted = true;
+                return ctx->fail(VGEN_E_RANGE, "random-key stream exhausted (2^64 candidates)");
+            }
+            int r = vgen_dispatch_random(ctx, frame, rnd_seed, shard, first);
+            if (r != VGEN_OK) return r;
+            pend[frame] = BatchKeys{};
+            pend[frame].random = true;
+            pend[frame].seed = rnd_seed;
+            pend[frame].stream = shard;
+            pend[frame].first_index = first;
+            dispatched++;
+            return VGEN_OK;
+        }
         uint8_t kb[32];
         scalar_to_be(current, kb);
         int r = vgen_dispatch(ctx, frame, kb);
         if (r != VGEN_OK) return r;
+        pend[frame] = BatchKeys{};
         pend[frame].start = current;
-        pend[frame].valid = true;
         dispatched++;
         Scalar nx;
         if (scalar_add_u64(nx, current, stride) || !scalar_is_valid(nx)) exhausted = true;   // key space exhausted
@@ -481,8 +521,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         uint64_t tested = 0;
         if ((status = vgen_wait(ctx, frame, recs.data(), (uint32_t)recs.size(), &n_found, &tested)) != VGEN_OK) break;
         in_flight--;
-        const Scalar batch_start = pend[frame].start;
-        pend[frame].valid = false;
+        const BatchKeys batch_start = pend[frame];
         const bool dumped = ctx->fr[frame].dumped;
         const uint32_t images = tested > N ? (uint32_t)(tested / N) : 1;   // 6 for an endomorphism dispatch
         bool cut = false;      // this batch: a confirmed (or unexamined) match was dropped because `count` was reached
@@ -544,7 +583,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                 in_flight = 0;
                 order.clear();
                 active = 0;
-                current = batch_start;
+                if (!random_keys) current = batch_start.start;
                 exhausted = false;
                 prime();
                 continue;
