@@ -166,6 +166,13 @@ int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
  * EVERY hash to the host (src/gpu.rs:602-658); here the ring grows to hold the expected candidates instead. */
 int vgen_set_match_cap(vgen_ctx *ctx, uint32_t match_cap);
 
+/* ---- fault injection (tests) --------------------------------------------------------------------------------- */
+
+/* Makes the context's dispatches fail with VGEN_E_HIP after `after_dispatches` more of them have been accepted (as a device
+ * that drops off the bus would); UINT64_MAX disarms.  The reference has no fault injection; the multi-device
+ * failure semantics above are tested through this. */
+int vgen_debug_fail_after(vgen_ctx *ctx, uint64_t after_dispatches);
+
 /* ---- measurement aid -------------------------------------------------------------------------------------- */
 
 /* Starts a one-wave probe on its own stream that, for duration_ms, compares the shader-clock counter with
@@ -308,7 +315,10 @@ typedef struct vgen_scan_result {
     double elapsed_secs;
     uint64_t resumed_operations;  /* operations recorded in the checkpoint this call resumed from (else 0) */
     int32_t complete;         /* 1: the key range ran out (every shard reached `end` / the end of the key space) */
-    int32_t reserved;
+    int32_t failed_shards;    /* contexts that failed during the scan (0 normally).  vgen_scan_multi with survivors: their
+                                 stripes were taken over and the call still returned VGEN_OK; a failing call (negative status)
+                                 fills this structure all the same, with the matches of every batch finished before the
+                                 failure and complete = 0 */
 } vgen_scan_result;
 
 typedef void (*vgen_progress_cb)(uint64_t operations, void *user); /* ProgressCallback, scanner.rs:71 */
@@ -323,7 +333,12 @@ int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, v
  * src/gpu.rs:161-165): one host thread per context, global batch b goes to context b mod n_ctx, a
  * shared match counter / stop flag, matches merged in ascending key order and truncated to count,
  * operations summed.  No device-to-device traffic.  All contexts must share batch_size
- * and format; cfg->shard / n_shards are ignored. */
+ * and format; cfg->shard / n_shards are ignored.
+ * A context whose device fails mid-scan retires; the matches of its finished batches are kept, and a context that has
+ * finished its own stripe takes the failed one over from its last finished batch (the reference's answer to a failing GPU
+ * is its CPU fallback, src/lib.rs:727-746,1185-1198; there is no CPU path here, the other GPUs are).  The call returns
+ * VGEN_OK with out->failed_shards > 0 when the survivors covered everything (or `count` / the stop flag ended the scan),
+ * and the first failure's status — with out still filled, complete = 0 — when no context was left to do so. */
 int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *pattern, const vgen_scan_config *cfg,
                     vgen_progress_cb cb, void *user, volatile int32_t *stop, vgen_scan_result *out);
 void vgen_scan_result_free(vgen_scan_result *r);

@@ -1,0 +1,366 @@
+// fake_driver.cpp — TEST-ONLY: drives the host side of libvgen_hip.so (cabi.cpp + scanner.cpp + host/*.cpp, linked
+// against the CPU stand-in of the runtime, fake_rt.cpp) through the C ABI and checks every result against the oracle.
+// Built twice, with -fsanitize=thread and with -fsanitize=address,undefined (tests/native/Makefile), and run by
+// tests/test_host_sanitizers.py in the build container: the scan loop's worker pool, helper-thread ramp, shared
+// counters, checkpoint lock, multi-context threads and failure take-over under the sanitizers.
+// usage: fake_driver [scenario ...]   (no argument: all);  exit status 0 = every check passed.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vgen_hip.h"
+#include "../../oracle/vgen_oracle.h"
+
+static int g_fail = 0;
+#define CHECK(cond, ...)                                                   \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            fprintf(stderr, "CHECK FAILED %s:%d: %s  ", __FILE__, __LINE__, #cond); \
+            fprintf(stderr, __VA_ARGS__);                                  \
+            fprintf(stderr, "\n");                                         \
+            g_fail++;                                                      \
+        }                                                                  \
+    } while (0)
+
+static const uint32_t BATCH = 8192;
+using Pairs = std::vector<std::pair<std::string, std::string>>;   // (address, wif)
+
+static void key_of(uint64_t v, uint8_t be[32]) {
+    memset(be, 0, 32);
+    for (int i = 0; i < 8; i++) be[31 - i] = (uint8_t)(v >> (8 * i));
+}
+
+static vgen_ctx *make_ctx(uint32_t fmt, uint32_t frames, uint32_t cap = 0, uint32_t flags = 0) {
+    vgen_params p;
+    memset(&p, 0, sizeof p);
+    p.struct_size = sizeof p;
+    p.batch_size = BATCH;
+    p.format = fmt;
+    p.frames = frames;
+    p.match_cap = cap;
+    p.flags = flags;
+    vgen_ctx *c = nullptr;
+    int rc = vgen_create(&p, &c);
+    if (rc != VGEN_OK) {
+        fprintf(stderr, "vgen_create failed: %d %s\n", rc, vgen_last_error(nullptr));
+        exit(2);
+    }
+    return c;
+}
+
+static vgen_scan_config range_cfg(uint32_t fmt, uint64_t lo, uint64_t hi, uint64_t count = UINT64_MAX) {
+    vgen_scan_config c;
+    memset(&c, 0, sizeof c);
+    c.struct_size = sizeof c;
+    c.format = fmt;
+    c.count = count;
+    c.has_start = 1;
+    key_of(lo, c.start);
+    c.has_end = 1;
+    key_of(hi, c.end);
+    return c;
+}
+
+// the oracle's matches of [lo, hi], sorted by key
+static Pairs oracle_range(int fmt, const char *pat, int ci, uint64_t lo, uint64_t hi) {
+    uint8_t a[32], b[32];
+    key_of(lo, a);
+    key_of(hi, b);
+    vo_scan_result r;
+    int rc = vo_scan_range(fmt, pat, ci, a, b, (size_t)-1, 0, &r);
+    Pairs out;
+    CHECK(rc == 0, "vo_scan_range rc=%d", rc);
+    for (size_t i = 0; i < r.n_matches; i++) out.emplace_back(r.matches[i].gen.address, r.matches[i].gen.wif);
+    vo_scan_free(&r);
+    return out;
+}
+
+static Pairs got_of(const vgen_scan_result &r) {
+    Pairs out;
+    for (uint64_t i = 0; i < r.n_matches; i++) out.emplace_back(r.matches[i].address, r.matches[i].wif);
+    return out;
+}
+
+struct CbLog {
+    std::vector<uint64_t> seen;   // written by the scanning thread(s) under the library's lock / single thread
+};
+static void cb_log(uint64_t ops, void *u) { static_cast<CbLog *>(u)->seen.push_back(ops); }
+
+// ---- scenarios ---------------------------------------------------------------------------------------------------
+
+static void sc_range_scan() {
+    const uint64_t lo = 0x30000, hi = lo + 10ull * BATCH - 1 - 77;   // the last batch is cut by `end`
+    auto want = oracle_range(0, "^1[A-C]", 0, lo, hi);
+    vgen_ctx *c = make_ctx(VGEN_FMT_P2PKH, 3);
+    vgen_scan_config cfg = range_cfg(0, lo, hi);
+    vgen_scan_result r;
+    CbLog log;
+    int rc = vgen_scan(c, "^1[A-C]", &cfg, cb_log, &log, nullptr, &r);
+    CHECK(rc == VGEN_OK, "rc=%d %s", rc, vgen_last_error(c));
+    CHECK(got_of(r) == want && want.size() > 100, "matches %zu vs %zu", (size_t)r.n_matches, want.size());
+    CHECK(r.complete == 1 && r.operations == 10ull * BATCH && r.failed_shards == 0, "ops %llu", (unsigned long long)r.operations);
+    CHECK(log.seen.size() == 10, "callbacks %zu", log.seen.size());
+    for (size_t i = 0; i < log.seen.size(); i++) CHECK(log.seen[i] == (i + 1) * (uint64_t)BATCH, "callback %zu = %llu", i, (unsigned long long)log.seen[i]);
+    vgen_scan_result_free(&r);
+    // count-limited: the first five matches, in key order
+    cfg.count = 5;
+    rc = vgen_scan(c, "^1[A-C]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.n_matches == 5, "rc=%d n=%llu", rc, (unsigned long long)r.n_matches);
+    auto g = got_of(r);
+    CHECK(Pairs(want.begin(), want.begin() + 5) == g, "first five");
+    vgen_scan_result_free(&r);
+    vgen_destroy(c);
+}
+
+static void sc_stop_flag() {
+    vgen_ctx *c = make_ctx(VGEN_FMT_P2PKH, 4);
+    vgen_scan_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.format = 0;
+    cfg.count = 1;
+    cfg.seed = 7;
+    volatile int32_t stop = 0;
+    std::thread stopper([&]() {
+        std::this_thread::sleep_for(std::chrono::milliseconds(150));
+        __atomic_store_n((int32_t *)&stop, 1, __ATOMIC_RELAXED);
+    });
+    vgen_scan_result r;
+    CbLog log;
+    int rc = vgen_scan(c, "^1ZZZZZZZZZZ", &cfg, cb_log, &log, &stop, &r);   // scanner.rs:413-440
+    stopper.join();
+    CHECK(rc == VGEN_OK && r.n_matches == 0 && r.operations > 0 && r.operations % BATCH == 0, "rc=%d ops=%llu", rc, (unsigned long long)r.operations);
+    CHECK(!log.seen.empty() && log.seen.back() == r.operations, "last callback");
+    vgen_scan_result_free(&r);
+    vgen_destroy(c);
+}
+
+static void sc_checkpoint() {
+    const uint64_t lo = 0x50000, hi = lo + 9ull * BATCH - 1;
+    auto want = oracle_range(0, "^1[D-F]", 0, lo, hi);
+    char path[] = "/tmp/vgen_fake_ck_XXXXXX";
+    int fd = mkstemp(path);
+    close(fd);
+    unlink(path);
+    vgen_ctx *c = make_ctx(VGEN_FMT_P2PKH, 3);
+    vgen_scan_config cfg = range_cfg(0, lo, hi);
+    cfg.checkpoint_path = path;
+    cfg.checkpoint_interval_ms = 1;
+    cfg.max_batches = 4;
+    vgen_scan_result r;
+    int rc = vgen_scan(c, "^1[D-F]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.complete == 0 && r.operations == 4ull * BATCH, "first leg rc=%d ops=%llu", rc, (unsigned long long)r.operations);
+    size_t first = (size_t)r.n_matches;
+    vgen_scan_result_free(&r);
+    cfg.max_batches = 0;
+    rc = vgen_scan(c, "^1[D-F]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.complete == 1 && r.resumed_operations == 4ull * BATCH && r.operations == 5ull * BATCH, "resume rc=%d", rc);
+    CHECK(got_of(r) == want && first > 0 && first < want.size(), "resumed matches %llu vs %zu", (unsigned long long)r.n_matches, want.size());
+    vgen_scan_result_free(&r);
+    // a finished checkpoint answers without touching the device
+    rc = vgen_scan(c, "^1[D-F]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.operations == 0 && got_of(r) == want, "finished checkpoint");
+    vgen_scan_result_free(&r);
+    unlink(path);
+    vgen_destroy(c);
+}
+
+static void sc_multi_context() {
+    const uint64_t lo = 0x70000, hi = lo + 15ull * BATCH - 1;
+    auto want = oracle_range(0, "^1[G-J]", 0, lo, hi);
+    vgen_ctx *cs[3] = {make_ctx(0, 2), make_ctx(0, 3), make_ctx(0, 2)};
+    vgen_scan_config cfg = range_cfg(0, lo, hi);
+    vgen_scan_result r;
+    CbLog log;
+    int rc = vgen_scan_multi(cs, 3, "^1[G-J]", &cfg, cb_log, &log, nullptr, &r);
+    CHECK(rc == VGEN_OK && got_of(r) == want && r.complete == 1 && r.operations == 15ull * BATCH, "multi rc=%d n=%llu/%zu", rc,
+          (unsigned long long)r.n_matches, want.size());
+    CHECK(log.seen.size() == 15, "callbacks %zu", log.seen.size());
+    for (size_t i = 0; i < log.seen.size(); i++) CHECK(log.seen[i] == (i + 1) * (uint64_t)BATCH, "callback %zu", i);
+    vgen_scan_result_free(&r);
+    // with a checkpoint shared by the three shards
+    char path[] = "/tmp/vgen_fake_mck_XXXXXX";
+    int fd = mkstemp(path);
+    close(fd);
+    unlink(path);
+    cfg.checkpoint_path = path;
+    cfg.checkpoint_interval_ms = 1;
+    cfg.max_batches = 2;
+    rc = vgen_scan_multi(cs, 3, "^1[G-J]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.complete == 0 && r.operations == 6ull * BATCH, "multi ck leg 1 rc=%d", rc);
+    vgen_scan_result_free(&r);
+    cfg.max_batches = 0;
+    rc = vgen_scan_multi(cs, 3, "^1[G-J]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.complete == 1 && got_of(r) == want, "multi ck leg 2 rc=%d", rc);
+    vgen_scan_result_free(&r);
+    unlink(path);
+    for (auto *c : cs) vgen_destroy(c);
+}
+
+static void sc_ring_growth_and_host_filter() {
+    const uint64_t lo = 1, hi = 4ull * BATCH;
+    vgen_ctx *c = make_ctx(0, 3, 256);
+    const char *pats[] = {"^1[A-F]", "^1[2-9A-Za-z]", "1[A-D][a-z]"};   // ring grows / dumps + host pool / on-device DFA with overflow
+    for (const char *p : pats) {
+        auto want = oracle_range(0, p, 0, lo, hi);
+        vgen_scan_config cfg = range_cfg(0, lo, hi);
+        vgen_scan_result r;
+        int rc = vgen_scan(c, p, &cfg, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_OK && got_of(r) == want && want.size() > 1000, "%s: rc=%d n=%llu/%zu", p, rc, (unsigned long long)r.n_matches, want.size());
+        vgen_scan_result_free(&r);
+    }
+    vgen_destroy(c);
+}
+
+static void sc_failure_takeover() {
+    const uint64_t lo = 0x90000, hi = lo + 18ull * BATCH - 1;
+    auto want = oracle_range(0, "^1[K-N]", 0, lo, hi);
+    vgen_scan_config cfg = range_cfg(0, lo, hi);
+    for (int victim = 0; victim < 3; victim++) {
+        vgen_ctx *cs[3] = {make_ctx(0, 2), make_ctx(0, 2), make_ctx(0, 3)};
+        vgen_debug_fail_after(cs[victim], (uint64_t)victim * 2);
+        vgen_scan_result r;
+        int rc = vgen_scan_multi(cs, 3, "^1[K-N]", &cfg, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_OK && got_of(r) == want && r.complete == 1 && r.failed_shards == 1, "victim %d: rc=%d n=%llu/%zu failed=%d", victim, rc,
+              (unsigned long long)r.n_matches, want.size(), r.failed_shards);
+        vgen_scan_result_free(&r);
+        for (auto *c : cs) vgen_destroy(c);
+    }
+    vgen_ctx *cs[3] = {make_ctx(0, 2), make_ctx(0, 2), make_ctx(0, 2)};
+    vgen_debug_fail_after(cs[0], 1);
+    vgen_debug_fail_after(cs[1], 4);
+    vgen_debug_fail_after(cs[2], 2);
+    vgen_scan_result r;
+    int rc = vgen_scan_multi(cs, 3, "^1[K-N]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_E_HIP && r.complete == 0 && r.failed_shards == 3, "all fail: rc=%d failed=%d", rc, r.failed_shards);
+    CHECK(strstr(vgen_last_error(cs[0]), "injected device failure") != nullptr, "message: %s", vgen_last_error(cs[0]));
+    auto g = got_of(r);
+    CHECK(!g.empty() && g.size() < want.size(), "partial %zu of %zu", g.size(), want.size());
+    for (auto &m : g) CHECK(std::find(want.begin(), want.end(), m) != want.end(), "partial match not in the oracle's set: %s", m.first.c_str());
+    vgen_scan_result_free(&r);
+    // single context: error + the finished batches' matches, a prefix of the oracle's list
+    for (auto *c : cs) vgen_debug_fail_after(c, UINT64_MAX);
+    vgen_debug_fail_after(cs[1], 5);
+    rc = vgen_scan(cs[1], "^1[K-N]", &cfg, nullptr, nullptr, nullptr, &r);
+    g = got_of(r);
+    CHECK(rc == VGEN_E_HIP && r.failed_shards == 1 && !g.empty() && g.size() < want.size(), "single: rc=%d n=%zu", rc, g.size());
+    CHECK(Pairs(want.begin(), want.begin() + g.size()) == g, "single: prefix");
+    vgen_scan_result_free(&r);
+    for (auto *c : cs) vgen_destroy(c);
+}
+
+static void sc_random_keys() {
+    vgen_ctx *c = make_ctx(0, 2);
+    vgen_scan_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.count = 4;
+    cfg.seed = 42;
+    cfg.flags = VGEN_SCAN_RANDOM_KEYS;
+    vgen_scan_result r;
+    int rc = vgen_scan(c, "^1A", &cfg, nullptr, nullptr, nullptr, &r);
+    vo_scan_result o;
+    vo_scan_random(0, "^1A", 0, 42, 4, 0, 1, &o);
+    CHECK(rc == VGEN_OK && r.n_matches == 4 && o.n_matches == 4, "random rc=%d", rc);
+    for (size_t i = 0; i < 4 && i < r.n_matches && i < o.n_matches; i++)
+        CHECK(!strcmp(r.matches[i].address, o.matches[i].gen.address) && !memcmp(r.matches[i].key, o.matches[i].key, 32), "random match %zu", i);
+    vo_scan_free(&o);
+    vgen_scan_result_free(&r);
+    vgen_destroy(c);
+}
+
+static void sc_endo_and_formats() {
+    // six images per point: every match must re-derive on the oracle from its reported key
+    vgen_ctx *c = make_ctx(0, 3, 0, VGEN_FLAG_ENDO);
+    vgen_scan_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.count = 12;
+    vgen_scan_result r;
+    int rc = vgen_scan(c, "^1B", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.n_matches == 12 && r.operations % (6ull * BATCH) == 0, "endo rc=%d", rc);
+    for (uint64_t i = 0; i < r.n_matches; i++) {
+        vo_generated g;
+        CHECK(vo_generate(0, r.matches[i].key, &g) && !strcmp(g.address, r.matches[i].address) && !strcmp(g.wif, r.matches[i].wif), "endo match %llu",
+              (unsigned long long)i);
+    }
+    vgen_scan_result_free(&r);
+    vgen_destroy(c);
+    // Bech32 suffix (checksum tables), Ethereum case-insensitive, P2SH: range scans against the oracle
+    struct { uint32_t fmt; const char *pat; int ci; } cases[] = {{1, "aa$", 0}, {5, "^0xab", 1}, {2, "^3[A-D]", 0}, {4, "^1[P-R]", 0}};
+    for (auto &k : cases) {
+        const uint64_t lo = 0xB0000 + k.fmt, hi = lo + 5ull * BATCH - 1;
+        auto want = oracle_range((int)k.fmt, k.pat, k.ci, lo, hi);
+        vgen_ctx *cc = make_ctx(k.fmt, 2);
+        vgen_scan_config cf = range_cfg(k.fmt, lo, hi);
+        cf.case_insensitive = k.ci;
+        int rc2 = vgen_scan(cc, k.pat, &cf, nullptr, nullptr, nullptr, &r);
+        CHECK(rc2 == VGEN_OK && got_of(r) == want && !want.empty(), "fmt %u %s: rc=%d n=%llu/%zu", k.fmt, k.pat, rc2, (unsigned long long)r.n_matches, want.size());
+        vgen_scan_result_free(&r);
+        vgen_destroy(cc);
+    }
+}
+
+static void sc_dispatch_api() {
+    // the frame-level API: dump mode, explicit keys, state errors
+    vgen_ctx *c = make_ctx(0, 2);
+    uint8_t k0[32];
+    key_of(12345, k0);
+    CHECK(vgen_set_filter(c, nullptr) == VGEN_OK, "dump mode");
+    CHECK(vgen_dispatch(c, 0, k0) == VGEN_OK && vgen_dispatch(c, 0, k0) == VGEN_E_STATE, "double dispatch");
+    uint64_t tested = 0;
+    CHECK(vgen_wait(c, 0, nullptr, 0, nullptr, &tested) == VGEN_OK && tested == BATCH, "wait");
+    CHECK(vgen_wait(c, 0, nullptr, 0, nullptr, nullptr) == VGEN_E_STATE, "wait twice");
+    std::vector<uint8_t> dump((size_t)BATCH * 20), ref((size_t)BATCH * 20);
+    CHECK(vgen_read_dump(c, 0, dump.data(), dump.size()) == VGEN_OK, "read dump");
+    vo_payload_seq(0, k0, BATCH, 0, ref.data());
+    CHECK(dump == ref, "dump parity");
+    std::vector<uint8_t> keys(64 * 32);
+    for (int i = 0; i < 64; i++) key_of(0x1000 + 977ull * i * i, keys.data() + 32 * i);
+    memset(keys.data() + 32 * 5, 0, 32);   // an invalid scalar yields nothing
+    CHECK(vgen_dispatch_keys(c, 1, keys.data(), 64) == VGEN_OK && vgen_wait(c, 1, nullptr, 0, nullptr, &tested) == VGEN_OK && tested == 64, "keys");
+    CHECK(vgen_read_dump(c, 1, dump.data(), dump.size()) == VGEN_OK, "read dump 2");
+    for (int i = 0; i < 64; i++) {
+        uint8_t pl[32] = {0};
+        int n = i == 5 ? 0 : vo_payload(0, keys.data() + 32 * i, pl);
+        CHECK((n == 20 || i == 5) && !memcmp(dump.data() + 20 * i, pl, 20), "key %d", i);
+    }
+    uint8_t bad[32] = {0};
+    CHECK(vgen_dispatch(c, 0, bad) == VGEN_E_RANGE && vgen_dispatch(c, 9, k0) == VGEN_E_INVALID, "bad arguments");
+    vgen_destroy(c);
+}
+
+int main(int argc, char **argv) {
+    const std::map<std::string, std::function<void()>> all = {
+        {"range_scan", sc_range_scan}, {"stop_flag", sc_stop_flag}, {"checkpoint", sc_checkpoint}, {"multi_context", sc_multi_context},
+        {"ring_growth", sc_ring_growth_and_host_filter}, {"failure_takeover", sc_failure_takeover}, {"random_keys", sc_random_keys},
+        {"endo_and_formats", sc_endo_and_formats}, {"dispatch_api", sc_dispatch_api}};
+    std::vector<std::string> run;
+    for (int i = 1; i < argc; i++) run.push_back(argv[i]);
+    if (run.empty())
+        for (auto &kv : all) run.push_back(kv.first);
+    for (auto &name : run) {
+        auto it = all.find(name);
+        if (it == all.end()) {
+            fprintf(stderr, "unknown scenario %s\n", name.c_str());
+            return 2;
+        }
+        const int before = g_fail;
+        const auto t0 = std::chrono::steady_clock::now();
+        it->second();
+        printf("%-18s %s  (%.1f s)\n", name.c_str(), g_fail == before ? "ok" : "FAILED",
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        fflush(stdout);
+    }
+    return g_fail ? 1 : 0;
+}

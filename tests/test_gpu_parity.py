@@ -947,3 +947,69 @@ def test_random_key_scan_finds_what_the_oracles_random_walk_finds(vg, vo):
         with pytest.raises(vg.VgenError):
             vg.scan_gpu_with_runner("^1A", cfg, r)
     r.close()
+
+
+# ---- a device that fails mid-scan (failure detection / recovery) -------------------------------------------
+
+def test_multi_context_scan_survives_a_failing_context(vg, vo, tmp_path):
+    """Three contexts stripe one range; one of them starts failing after a few dispatches (vgen_debug_fail_after: what a
+    device dropping off the bus looks like to the host loop).  The batches it had finished keep their matches, a surviving
+    context takes its stripe over from the last finished batch, and the result is the oracle's scan of the WHOLE range —
+    nothing lost, nothing twice.  The reference's answer to a failing GPU is its CPU fallback (src/lib.rs:727-746,1185-1198);
+    here the other GPUs are the fallback."""
+    batch = 8192
+    lo, hi = 0x20000, 0x20000 + 30 * batch - 1
+    want = [(x["address"], x["wif"]) for x in vo.scan_range(0, "^1[A-D]", lo, hi, count=10**9)["matches"]]
+    assert len(want) > 500
+    cfg = vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=lo, end=hi)
+    for victim, after in ((1, 3), (0, 0), (2, 7)):
+        rs = [vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2) for _ in range(3)]
+        rs[victim].fail_after(after)
+        res = vg.scan_gpu_with_runner("^1[A-D]", cfg, rs)
+        assert [(m.address, m.wif) for m in res.matches] == want, (victim, after)
+        assert res.failed_shards == 1 and res.complete and res.operations >= 30 * batch
+        for r in rs:
+            r.close()
+    # two of three fail: the last one standing finishes all three stripes
+    rs = [vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2) for _ in range(3)]
+    rs[0].fail_after(2)
+    rs[2].fail_after(5)
+    res = vg.scan_gpu_with_runner("^1[A-D]", cfg, rs)
+    assert [(m.address, m.wif) for m in res.matches] == want and res.failed_shards == 2 and res.complete
+    # all three fail: the call fails, and still hands over the matches of every batch that had finished
+    for r, n in zip(rs, (1, 4, 2)):
+        r.fail_after(n)
+    rs[1].fail_after(4)
+    with pytest.raises(vg.VgenError) as e:
+        vg.scan_gpu_with_runner("^1[A-D]", cfg, rs)
+    assert e.value.status == -3 and "injected device failure" in str(e.value)
+    part = e.value.partial
+    got = [(m.address, m.wif) for m in part.matches]
+    assert not part.complete and part.failed_shards == 3 and 0 < len(got) < len(want)
+    assert set(got) <= set(want) and part.operations % batch == 0 and 0 < part.operations < 30 * batch
+    # a failed context is not poisoned: disarmed, the same contexts complete the scan
+    for r in rs:
+        r.fail_after(2**64 - 1)
+    res = vg.scan_gpu_with_runner("^1[A-D]", cfg, rs)
+    assert [(m.address, m.wif) for m in res.matches] == want and res.failed_shards == 0
+    # a count-limited scan absorbs the failure as well
+    rs[1].fail_after(1)
+    cfg5 = vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=7, start=lo, end=hi)
+    res = vg.scan_gpu_with_runner("^1[A-D]", cfg5, rs)
+    assert len(res.matches) == 7 and set((m.address, m.wif) for m in res.matches) <= set(want)
+    # with a checkpoint the ledger carries the failed stripe's progress: the survivors finish it and the file says complete
+    rs[1].fail_after(2)
+    ck = str(tmp_path / "multi.ck")
+    cfgk = vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=lo, end=hi, checkpoint_path=ck)
+    res = vg.scan_gpu_with_runner("^1[A-D]", cfgk, rs)
+    assert [(m.address, m.wif) for m in res.matches] == want and res.complete and res.failed_shards == 1
+    assert "complete=1" in open(ck).read()
+    # single-context scan: the error comes with the finished batches' matches
+    rs[0].fail_after(6)
+    with pytest.raises(vg.VgenError) as e:
+        vg.scan_gpu_with_runner("^1[A-D]", cfg, rs[0])
+    part = e.value.partial
+    assert part.failed_shards == 1 and not part.complete and 0 < len(part.matches) < len(want)
+    assert [(m.address, m.wif) for m in part.matches] == want[:len(part.matches)]     # a prefix: batches finish in order
+    for r in rs:
+        r.close()

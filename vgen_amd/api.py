@@ -81,7 +81,7 @@ class _Generated(ctypes.Structure):
 class _ScanResult(ctypes.Structure):
     _fields_ = [("matches", ctypes.POINTER(_Generated)), ("n_matches", ctypes.c_uint64),
                 ("operations", ctypes.c_uint64), ("elapsed_secs", ctypes.c_double),
-                ("resumed_operations", ctypes.c_uint64), ("complete", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("resumed_operations", ctypes.c_uint64), ("complete", ctypes.c_int32), ("failed_shards", ctypes.c_int32)]
 
 
 _PROGRESS = ctypes.CFUNCTYPE(None, ctypes.c_uint64, ctypes.c_void_p)
@@ -112,6 +112,7 @@ _L.vgen_clock_probe_start.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
 _L.vgen_clock_probe_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 _L.vgen_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
 _L.vgen_dispatch_keys.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
+_L.vgen_debug_fail_after.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
 _L.vgen_dispatch_random.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
 _L.vgen_random_key.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
 _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match), ctypes.c_uint32,
@@ -327,6 +328,7 @@ class ScanResult:
     elapsed_secs: float = 0.0
     resumed_operations: int = 0     # operations recorded in the checkpoint this call resumed from
     complete: bool = False          # the key range ran out
+    failed_shards: int = 0          # contexts that failed during the scan (their stripes were taken over by the others)
 
     def rate(self) -> float:   # src/scanner.rs:61-67
         return self.operations / self.elapsed_secs if self.elapsed_secs > 0 else 0.0
@@ -384,6 +386,10 @@ class GpuRunner:
             blob, n = b"".join(_key(k) for k in keys), len(keys)
         self._n_keys = n
         _check(_L.vgen_dispatch_keys(self._h, frame, blob, n), self._h)
+
+    def fail_after(self, dispatches: int):
+        """vgen_debug_fail_after: fault injection — dispatches fail with VGEN_E_HIP once `dispatches` more were accepted."""
+        _check(_L.vgen_debug_fail_after(self._h, dispatches), self._h)
 
     def dispatch_random(self, seed: int, stream: int, first_index: int, frame: int):
         """vgen_dispatch_random: batch_size independent random keys drawn on the device from the counter-based stream."""
@@ -465,11 +471,16 @@ def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
     else:
         arr = (ctypes.c_void_p * len(runners))(*[r._h for r in runners])
         rc = _L.vgen_scan_multi(arr, len(runners), pattern.encode(), ctypes.byref(c), cb, None, stop_p, ctypes.byref(res))
-    _check(rc, runner._h)
     out = ScanResult(operations=res.operations, elapsed_secs=res.elapsed_secs,
-                     resumed_operations=res.resumed_operations, complete=bool(res.complete))
+                     resumed_operations=res.resumed_operations, complete=bool(res.complete), failed_shards=res.failed_shards)
     for i in range(res.n_matches):
         g = res.matches[i]
         out.matches.append(GeneratedAddress(g.address.decode(), g.wif.decode(), g.hex.decode(), AddressFormat(g.format)))
     _L.vgen_scan_result_free(ctypes.byref(res))
+    if rc < 0:
+        # a failing scan still hands over what its finished batches found (vgen_scan_result is filled, complete = 0)
+        msg = _L.vgen_last_error(runner._h)
+        err = VgenError(rc, msg.decode() if msg else "")
+        err.partial = out
+        raise err
     return out

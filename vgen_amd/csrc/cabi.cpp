@@ -1,5 +1,4 @@
 // cabi.cpp — the extern "C" surface declared in include/vgen_hip.h.
-#include <hip/hip_runtime_api.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -33,26 +32,13 @@ int vgen_abi_version(void) { return VGEN_ABI_VERSION; }
 
 int vgen_device_count(int *n) {
     if (!n) return VGEN_E_INVALID;
-    int c = 0;
-    hipError_t e = hipGetDeviceCount(&c);
-    if (e != hipSuccess) {
-        *n = 0;
-        g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
-        return e == hipErrorNoDevice ? VGEN_OK : VGEN_E_HIP;
-    }
-    *n = c;
-    return VGEN_OK;
+    return vg::rt_device_count(n, g_last_error);
 }
 
 int vgen_device_name(int device, char *buf, size_t cap) {
     if (!buf || cap == 0) return VGEN_E_INVALID;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) {
-        g_last_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
-        return VGEN_E_NODEVICE;
-    }
-    std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
+    std::string s;
+    if (int rc = vg::rt_device_name(device, s, g_last_error)) return rc;
     strncpy(buf, s.c_str(), cap - 1);
     buf[cap - 1] = 0;
     return VGEN_OK;
@@ -178,6 +164,12 @@ int vgen_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32])
 int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n) {
     if (!ctx) return VGEN_E_INVALID;
     return vg::rt_dispatch_keys(ctx, frame, keys_be, n);
+}
+
+int vgen_debug_fail_after(vgen_ctx *ctx, uint64_t after_dispatches) {
+    if (!ctx) return VGEN_E_INVALID;
+    ctx->fail_after = after_dispatches;
+    return VGEN_OK;
 }
 
 int vgen_dispatch_random(vgen_ctx *ctx, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {

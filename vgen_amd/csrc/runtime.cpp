@@ -184,6 +184,29 @@ int upload(vgen_ctx *c, void *dst, const void *src, size_t bytes) {
 
 }  // namespace
 
+int rt_device_count(int *n, std::string &err) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return e == hipErrorNoDevice ? VGEN_OK : VGEN_E_HIP;
+    }
+    *n = c;
+    return VGEN_OK;
+}
+
+int rt_device_name(int device, std::string &name, std::string &err) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return VGEN_E_NODEVICE;
+    }
+    name = std::string(prop.name) + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
+    return VGEN_OK;
+}
+
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     if (!p || !out || p->struct_size != sizeof(vgen_params)) {
         err = "vgen_create: bad parameter block";
@@ -670,6 +693,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     if (frame >= c->frames || !start_key_be) return c->fail(VGEN_E_INVALID, "bad frame index / key");
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
+    if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");
     Scalar k0;
     scalar_from_be(k0, start_key_be);
     if (!scalar_is_valid(k0)) return c->fail(VGEN_E_RANGE, "start key is not a valid secp256k1 scalar");
@@ -761,6 +785,7 @@ int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32
     if (n == 0 || n > c->batch) return c->fail(VGEN_E_INVALID, "vgen_dispatch_keys: n must be in [1, batch_size]");
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
+    if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = ensure_frame(c, frame)) return rc;
     if (int rc = ensure_keys_slab(c)) return rc;
@@ -776,6 +801,7 @@ int rt_dispatch_random(vgen_ctx *c, uint32_t frame, uint64_t seed, uint32_t stre
     if (first_index + c->batch < first_index) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
+    if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = ensure_frame(c, frame)) return rc;
     memset(&f.start, 0, sizeof f.start);

@@ -89,7 +89,16 @@ struct vgen_ctx {
     hipStream_t probe_stream = nullptr;          // shader-clock probe (vgen_clock_probe_*)
     unsigned long long *d_probe = nullptr;
     bool probe_running = false;
+    uint64_t fail_after = UINT64_MAX;            // fault injection (vgen_debug_fail_after): dispatches still accepted
     std::string err;
+
+    // false once the injected fault has struck: every later dispatch fails
+    bool injected_fault() {
+        if (fail_after == UINT64_MAX) return false;
+        if (fail_after == 0) return true;
+        fail_after--;
+        return false;
+    }
 
     int fail(int status, const std::string &msg) {
         err = msg;
@@ -102,6 +111,11 @@ namespace vg {
 // More frames than hardware queues the runtime provides (GPU_MAX_HW_QUEUES per priority level): streams then share queues.
 inline bool rt_oversubscribed(const vgen_ctx *c) { return c->frames > c->prio_levels * c->hw_queues; }
 
+// Everything the C ABI (cabi.cpp) and the scan loop (scanner.cpp) need of the device goes through these functions; the
+// two files make no HIP call of their own — which is also what lets the host-side sanitizer builds link them against a
+// CPU stand-in of this interface (tests/native/fake_rt.cpp).
+int rt_device_count(int *n, std::string &err);
+int rt_device_name(int device, std::string &name, std::string &err);
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
 // Starts (once) a helper thread that creates the stage streams no frame has used yet; rt_frame_ready tells without
 // blocking whether `frame` could be dispatched to without creating a stream first.  Used by the scan loop to grow its

@@ -344,14 +344,23 @@ using namespace vg;
 
 namespace {
 
+// Where a shard (slot of the batch striping) stands: batches committed so far, in dispatch order.  A multi-device scan
+// keeps one per slot so that a surviving context can take over the slot of a failed one exactly where it stopped
+// (with a checkpoint the ledger's done[] is the same number and wins).
+struct SlotProgress {
+    std::atomic<uint64_t> done{0};
+};
+
 // One shard of a scan on one context.  `shared_found` (optional) is the match counter shared by the
 // shards of a multi-device scan; without it the shard counts its own matches.  `ck` (optional): the
 // scan's checkpoint; this shard is its slot `ck_slot`, skips the batches already recorded there and
-// commits each batch it finishes.  *range_done: the shard stopped because its range ran out.
+// commits each batch it finishes.  `slot` (optional): the slot's progress — the first slot->done batches are skipped
+// (another context committed them before it failed) and every batch committed here is counted in.
+// *range_done: the shard stopped because its range ran out.
 int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cfg, vgen_progress_cb cb, void *user,
                volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
                std::vector<vgen_generated> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
-               bool *range_done = nullptr) {
+               bool *range_done = nullptr, SlotProgress *slot = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
     if (ctx->endo && (cfg->has_start || cfg->has_end || cfg->seed || cfg->n_shards > 1 || cfg->checkpoint_path))
         return ctx->fail(VGEN_E_INVALID, "a VGEN_FLAG_ENDO context tests six images of every point, not a contiguous key range: "
@@ -419,8 +428,12 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     bool exhausted = false;
     if (shard && !random_keys) exhausted = scalar_add_u64(current, current, (uint64_t)shard * N) || !scalar_is_valid(current);
     const uint64_t stride = (uint64_t)shards * N;
-    if (ck && !exhausted) {   // resume: this shard's first `skip` batches are already in the checkpoint
-        uint64_t skip = ck->done[ck_slot];
+    // resume / take-over: this shard's first `skipped` batches are already in the checkpoint, or were committed by the
+    // context that owned the slot before it failed
+    const uint64_t skipped = ck ? ck->done[ck_slot] : slot ? slot->done.load() : 0;
+    const uint64_t taken_over = slot && !ck ? skipped : 0;   // counts against max_batches: the slot's budget, not the context's
+    if (skipped && !exhausted && !random_keys) {
+        uint64_t skip = skipped;
         while (skip && !exhausted) {
             const uint64_t step = std::min<uint64_t>(skip, UINT64_MAX / stride);
             exhausted = scalar_add_u64(current, current, step * stride) || !scalar_is_valid(current);
@@ -436,10 +449,12 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     // A confirmed match: into the result while `count` is not reached; with a checkpoint ALWAYS into the batch's
     // ledger entry, so that a committed batch is recorded with all of its matches and a later run with a larger
     // count loses none.  Returns false when the match was dropped (no checkpoint, count reached).
+    uint64_t taken_uncommitted = 0;   // matches taken from the batch in hand, not yet committed (rolled back if the scan fails first)
     auto push = [&](const vgen_generated &g) -> bool {
         const bool take = found() < count;
         if (take) {
             matches.push_back(g);
+            taken_uncommitted++;
             if (shared_found) shared_found->fetch_add(1, std::memory_order_relaxed);
         }
         if (ck) batch_matches.push_back(g);
@@ -453,14 +468,16 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     uint32_t in_flight = 0;
     int status = VGEN_OK;
 
-    auto stopped = [&]() { return stop && *stop; };
+    // (the host's stop flag is written by another thread: an atomic read, src/gpu.rs:980-984 reads its AtomicBool Relaxed)
+    auto stopped = [&]() { return stop && __atomic_load_n(const_cast<const int32_t *>(stop), __ATOMIC_RELAXED) != 0; };
     auto in_range = [&]() { return !exhausted && (!end || scalar_cmp(current, *end) <= 0); };
-    auto can_dispatch = [&]() { return in_range() && (!cfg->max_batches || dispatched < cfg->max_batches); };
+    auto can_dispatch = [&]() { return in_range() && (!cfg->max_batches || dispatched + taken_over < cfg->max_batches); };
     auto dispatch = [&](uint32_t frame) -> int {
         if (random_keys) {
             // every shard owns a stream of its own and walks its candidates in order (the oracle's worker thread, oracle/vo_scan.c)
-            const uint64_t first = dispatched * (uint64_t)N;
-            if (first / N != dispatched || first + N < first) {
+            const uint64_t batch_no = skipped + dispatched;
+            const uint64_t first = batch_no * (uint64_t)N;
+            if (first / N != batch_no || first + N < first) {
                 exhausted = true;
                 return ctx->fail(VGEN_E_RANGE, "random-key stream exhausted (2^64 candidates)");
             }
@@ -616,6 +633,8 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         // `count`: the file stays a consistent prefix of the scan whatever count a later run asks for.
         cut_any = cut_any || cut;
         if (ck) ck->commit(ck_slot, batch_matches, tested);
+        if (slot) slot->done.fetch_add(1);
+        taken_uncommitted = 0;
         batch_matches.clear();
         if (cb) cb(shared_ops ? tested : total_ops, user);   // multi-device: the wrapper adds N to the shared count under its lock
         if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
@@ -624,6 +643,13 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             if (!rt_frame_ready(ctx, active) && rt_prepare_streams(ctx)) continue;
             if (!launch(active++)) break;
         }
+    }
+    // A scan that fails between examining a batch and committing it (in dump mode the host filter runs BEFORE the frame is
+    // dispatched again, and that dispatch is where a dead device shows) must not keep that batch's matches: the batch is not
+    // counted as done, so whoever resumes or takes over the slot will produce them again.
+    if (status != VGEN_OK && taken_uncommitted) {
+        matches.resize(matches.size() - (size_t)taken_uncommitted);
+        if (shared_found) shared_found->fetch_sub(taken_uncommitted, std::memory_order_relaxed);
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
     const bool all_processed = order.empty() && !cut_any;   // no dispatched batch was left unread or cut short
@@ -695,7 +721,15 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     bool range_done = false;
     if (!cfg->checkpoint_path) {
         int rc = scan_shard(ctx, flt, cfg, cb, user, stop, nullptr, nullptr, matches, ops, nullptr, 0, &range_done);
-        if (rc != VGEN_OK) return rc;
+        if (rc != VGEN_OK) {
+            // the error, AND what the batches finished before it had found (complete = 0): a host that falls back to
+            // another backend (the reference's run_search does, src/lib.rs:727-746,1185-1198) keeps those matches
+            const std::string why = ctx->err;
+            (void)finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+            out->failed_shards = 1;
+            ctx->err = why;
+            return rc;
+        }
         out->complete = range_done;
         return finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
     }
@@ -713,7 +747,20 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
         ck.complete = ck.complete || (rc == VGEN_OK && range_done);
         if (!ck.write_locked() && rc == VGEN_OK) rc = ctx->fail(VGEN_E_INVALID, "cannot write checkpoint file '" + ck.path + "'");
     }
-    if (rc != VGEN_OK) return rc;
+    if (rc != VGEN_OK) {
+        const std::string why = ctx->err;
+        std::vector<vgen_generated> all;
+        {
+            std::lock_guard<std::mutex> g(ck.mu);
+            all = ck.ledger;   // every batch committed before the failure, earlier runs included (the file holds the same)
+        }
+        if (all.size() > c.count) all.resize((size_t)c.count);
+        (void)finish_result(ctx, all, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+        out->resumed_operations = ck.resumed_operations;
+        out->failed_shards = 1;
+        ctx->err = why;
+        return rc;
+    }
     out->complete = ck.complete;
     out->resumed_operations = ck.resumed_operations;
     return finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
@@ -754,14 +801,24 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
         resolve_base(base);   // all shards must walk the same base key
     }
     std::atomic<uint64_t> found{0}, ops_shared{0};
-    std::vector<char> range_done(n_ctx, 0);
     if (ckp) found = ck.ledger.size();
     const bool skip_all = ckp && (ck.complete || ck.ledger.size() >= cfg->count);
+    // Per SLOT of the striping (slot i starts on context i): matches, operations, progress, whether its range ran out.
+    // Per CONTEXT: the status of its last scan_shard.  A context that fails retires; its slot is left where its last
+    // committed batch put it, and a context that has finished its own slot takes it over from there (the reference has one
+    // adapter and falls back to its CPU path instead, src/lib.rs:727-746,1185-1198; SURVEY.md 5: "per-GPU worker failure =>
+    // re-queue its range on surviving GPUs").  Batches in flight on the failed context were never committed: the adopter
+    // redoes them.  Contexts that finish while others are still running wait for a possible orphan instead of exiting.
     std::vector<std::vector<vgen_generated>> part(n_ctx);
     std::vector<uint64_t> ops(n_ctx, 0);
     std::vector<int> rcs(n_ctx, VGEN_OK);
-    std::vector<std::thread> th;
-    std::mutex cb_mu;
+    std::vector<char> range_done(n_ctx, 0), slot_finished(n_ctx, 0);
+    std::vector<SlotProgress> progress(n_ctx);
+    std::mutex cb_mu, q_mu;
+    std::condition_variable q_cv;
+    std::deque<uint32_t> orphans;
+    uint32_t running = skip_all ? 0 : n_ctx;   // threads still inside a scan_shard call
+    uint32_t failed_ctx = 0;
     // one callback per finished batch of any shard, with the cumulative count of all shards: the increment and
     // the call share a lock, so the host sees strictly increasing multiples of the batch size (gpu.rs:1106-1109)
     struct CbCtx { vgen_progress_cb cb; void *user; std::mutex *mu; std::atomic<uint64_t> *ops; } cbc{cb, user, &cb_mu, &ops_shared};
@@ -770,29 +827,74 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
         std::lock_guard<std::mutex> g(*c->mu);
         c->cb(c->ops->fetch_add(delta) + delta, c->user);
     };
+    auto scan_over = [&]() {
+        return (stop && __atomic_load_n(const_cast<const int32_t *>(stop), __ATOMIC_RELAXED) != 0) || found.load() >= cfg->count;
+    };
+    std::vector<std::thread> th;
     for (uint32_t i = 0; i < n_ctx && !skip_all; i++)
         th.emplace_back([&, i]() {
-            vgen_scan_config c = base;
-            c.shard = endo ? 0 : i;
-            c.n_shards = endo ? 0 : n_ctx;
-            bool rd = false;
-            rcs[i] = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
-                                part[i], ops[i], ckp, i, &rd);
-            range_done[i] = rd;
+            uint32_t slot = i;
+            for (;;) {
+                vgen_scan_config c = base;
+                c.shard = endo ? 0 : slot;
+                c.n_shards = endo ? 0 : n_ctx;
+                bool rd = false;
+                std::vector<vgen_generated> got;
+                uint64_t o = 0;
+                const int rc = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
+                                          got, o, ckp, slot, &rd, endo ? nullptr : &progress[slot]);
+                std::unique_lock<std::mutex> lk(q_mu);
+                part[slot].insert(part[slot].end(), got.begin(), got.end());
+                ops[slot] += o;
+                if (rc != VGEN_OK) {
+                    // this context retires; the slot it was working on is up for adoption (never for endomorphism contexts:
+                    // they walk from random bases of their own, there is no range to complete)
+                    rcs[i] = rc;
+                    failed_ctx++;
+                    running--;
+                    if (!endo) orphans.push_back(slot);
+                    q_cv.notify_all();
+                    return;
+                }
+                range_done[slot] = rd;
+                slot_finished[slot] = 1;
+                // finished a slot: adopt an orphan if the scan still wants keys, else wait while anybody may still fail
+                running--;
+                q_cv.notify_all();
+                q_cv.wait(lk, [&]() { return !orphans.empty() || running == 0 || scan_over(); });
+                if (orphans.empty() || scan_over()) return;
+                slot = orphans.front();
+                orphans.pop_front();
+                running++;
+            }
         });
     for (auto &x : th) x.join();
     bool all_done = !skip_all;
-    for (uint32_t i = 0; i < n_ctx; i++) all_done = all_done && rcs[i] == VGEN_OK && range_done[i];
+    for (uint32_t i = 0; i < n_ctx; i++) all_done = all_done && slot_finished[i] && range_done[i];
+    int first_err = VGEN_OK;
+    uint32_t first_err_ctx = 0;
+    for (uint32_t i = 0; i < n_ctx; i++)
+        if (rcs[i] != VGEN_OK && first_err == VGEN_OK) {
+            first_err = rcs[i];
+            first_err_ctx = i;
+        }
+    // Every slot covered (by its own context or an adopter), or the scan ended because `count` / the stop flag said so:
+    // the failures were absorbed.  Otherwise (no context left to adopt a slot) the scan is incomplete and the call fails —
+    // still handing over everything the committed batches found.
+    bool uncovered = false;
+    for (uint32_t i = 0; i < n_ctx && !skip_all; i++) uncovered = uncovered || !slot_finished[i];
+    const bool absorbed = first_err != VGEN_OK && (!uncovered || scan_over() || endo) && failed_ctx < n_ctx;
     if (ckp) {
         std::lock_guard<std::mutex> g(ck.mu);
         ck.complete = ck.complete || all_done;
-        if (!ck.write_locked() && rcs[0] == VGEN_OK)
-            rcs[0] = ctxs[0]->fail(VGEN_E_INVALID, "cannot write checkpoint file '" + ck.path + "'");
+        if (!ck.write_locked() && first_err == VGEN_OK) {
+            first_err = ctxs[0]->fail(VGEN_E_INVALID, "cannot write checkpoint file '" + ck.path + "'");
+            first_err_ctx = 0;
+        }
         out->resumed_operations = ck.resumed_operations;
     }
-    for (uint32_t i = 0; i < n_ctx; i++)
-        if (rcs[i] != VGEN_OK) return rcs[i];
     out->complete = ckp ? ck.complete : all_done;
+    out->failed_shards = (int32_t)failed_ctx;
     std::vector<vgen_generated> all;
     uint64_t total = 0;
     if (ckp) all = ck.ledger;   // earlier runs' matches + every batch committed by this one
@@ -802,7 +904,16 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     }
     std::sort(all.begin(), all.end(), [](const vgen_generated &a, const vgen_generated &b) { return memcmp(a.key, b.key, 32) < 0; });
     if (all.size() > cfg->count) all.resize((size_t)cfg->count);
-    return finish_result(ctxs[0], all, total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+    const std::string why = first_err != VGEN_OK ? ctxs[first_err_ctx]->err : std::string();
+    const int frc = finish_result(ctxs[0], all, total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+    if (first_err != VGEN_OK && !absorbed) {
+        out->complete = 0;
+        ctxs[first_err_ctx]->err = why;
+        if (first_err_ctx != 0) ctxs[0]->err = "context " + std::to_string(first_err_ctx) + ": " + why;
+        return first_err;
+    }
+    if (first_err != VGEN_OK) ctxs[first_err_ctx]->err = why;   // absorbed: still readable through vgen_last_error(ctxs[i])
+    return frc;
 }
 
 extern "C" void vgen_scan_result_free(vgen_scan_result *r) {
