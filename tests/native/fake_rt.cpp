@@ -364,7 +364,7 @@ int rt_dispatch_keys(vgen_ctx *c0, uint32_t frame, const uint8_t *keys_be, uint3
 int rt_dispatch_random(vgen_ctx *c0, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
     FakeCtx *c = fc(c0);
     if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
-    if (first_index + c->batch < first_index) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
+    if (first_index > UINT64_MAX - (c->batch - 1)) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
     if (c->fr[frame].in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
     if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");
     if (int rc = ensure_frame(c, frame)) return rc;

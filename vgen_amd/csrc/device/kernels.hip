@@ -285,9 +285,20 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 // Register budget: 4 waves per SIMD (128 VGPRs) for the 20-byte formats — four launches of different frames
 // then share a SIMD; Keccak (50 state registers) runs better at 3 waves without spills (6.16 vs 5.85 Gkeys/s),
 // the taproot path (a full scalar multiplication per key) keeps its ~240 registers (217 vs 197 Mkeys/s).
-template <int FMT>
+#ifndef VG_SEQ_WAVES_P2SH
+#define VG_SEQ_WAVES_P2SH 4
+#endif
+#ifndef VG_SEQ_WAVES_UNCOMP
+#define VG_SEQ_WAVES_UNCOMP 4
+#endif
+#ifndef VG_SEQ_WAVES_FULL20
+#define VG_SEQ_WAVES_FULL20 4
+#endif
+template <int FMT, bool FULL>
 struct SeqWaves {
-    static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH : 4;
+    static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH
+                                 : FULL ? VG_SEQ_WAVES_FULL20 : FMT == VGF_P2SH_P2WPKH ? VG_SEQ_WAVES_P2SH
+                                 : FMT == VGF_P2PKH_UNCOMPRESSED ? VG_SEQ_WAVES_UNCOMP : 4;
 };
 
 // ENDO (vanity searches; every format but P2TR, with a prefilter, the on-device DFA or in dump mode): every point is tested under its six
@@ -295,7 +306,7 @@ struct SeqWaves {
 // their negations — so six keys are hashed for one point's arithmetic plus two multiplications by beta.  Image `variant`
 // = s * 3 + e (e = power of beta, s = negated) of key index i is reported / dumped at variant * n + i.
 template <int FMT, bool FULL, bool ENDO = false>
-__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SeqWaves<FMT>::value, SeqWaves<FMT>::value)))
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SeqWaves<FMT, FULL>::value, SeqWaves<FMT, FULL>::value)))
 seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 tree[9 * WG];
     __shared__ u32 ypark[ENDO && (FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM) ? 9 * WG : 1];   // ENDO: the point's y
@@ -696,16 +707,18 @@ __global__ void __launch_bounds__(KEYS_WG) keys_fwd_kernel(const KeysArgs args) 
     const u32 idx = blockIdx.x * KEYS_WG + tid;
     const u32 lanes = args.groups * KEYS_WG;
     u32 k[8];
-    (void)keys_load_scalar(args, idx, k);
+    const bool valid = keys_load_scalar(args, idx, k);
 
     gej acc;
     ec_mul_gen_tables(acc, k, GenTables{args.gtab, args.gtab16, args.gtab_bits});
 
+    // "no key here" travels to keys_bwd_kernel as Y = 0 (all limbs): no finite point of this odd-order group has y = 0, so
+    // the scalar (an upload, or a SHA-256 in the random-stream mode) is not loaded / drawn and range-checked a second time
     u32 *o = args.xyz + idx;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         o[(size_t)i * lanes] = acc.x.n[i];
-        o[(size_t)(9 + i) * lanes] = acc.y.n[i];
+        o[(size_t)(9 + i) * lanes] = valid ? acc.y.n[i] : 0u;
         o[(size_t)(18 + i) * lanes] = acc.z.n[i];
     }
     // product tree of the Z's (never zero: 0 < k < n); the leaf level is exchanged by a lane shuffle
@@ -775,6 +788,10 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
         Y.n[i] = in[(size_t)(9 + i) * lanes];
         zs.n[i] = ins[(size_t)(18 + i) * lanes];
     }
+    u32 ynz = 0;     // keys_fwd_kernel parked Y = 0 for "no key" (scalar 0 or >= n, lane beyond n)
+#pragma unroll
+    for (int i = 0; i < 9; i++) ynz |= Y.n[i];
+    const bool valid = ynz != 0 && idx < args.n;
     fe_mul(zi, ip, zs);
     fe_sqr(zi2, zi);
     fe_mul(zi3, zi2, zi);
@@ -783,8 +800,6 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
     fe_canonicalize_product(x);
     fe_canonicalize_product(y);
 
-    u32 k[8];
-    const bool valid = keys_load_scalar(args, idx, k);
     u32 pl[NW];
     const bool ok = payload_from_point<FMT>(x, y, GenTables{args.gtab, args.gtab16, args.gtab_bits}, tree, pl) && valid;   // P2TR: workgroup-wide
 

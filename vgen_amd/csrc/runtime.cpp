@@ -798,7 +798,7 @@ int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32
 // key(seed, stream, first_index + i) from the counter-based stream of core/rnd.h on the device.
 int rt_dispatch_random(vgen_ctx *c, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
     if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
-    if (first_index + c->batch < first_index) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
+    if (first_index > UINT64_MAX - (c->batch - 1)) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
     vgen_ctx::Frame &f = c->fr[frame];
     if (f.in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
     if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");

@@ -477,7 +477,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             // every shard owns a stream of its own and walks its candidates in order (the oracle's worker thread, oracle/vo_scan.c)
             const uint64_t batch_no = skipped + dispatched;
             const uint64_t first = batch_no * (uint64_t)N;
-            if (first / N != batch_no || first + N < first) {
+            if (first / N != batch_no || first > UINT64_MAX - (N - 1)) {
                 exhausted = true;
                 return ctx->fail(VGEN_E_RANGE, "random-key stream exhausted (2^64 candidates)");
             }
