@@ -11,7 +11,6 @@ mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2>> $OUT/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-export VGEN_DESTROY_STREAMS_AT_EXIT=1   # rocprofv3's exit handlers crash on hardware queues that outlive it
 Q="--no-cpu-baseline --no-other-configs --sustained-seconds 0.5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o t -- python3 $GRAFT_REPO_ROOT/bench.py --frames 1 --steps 256 --warmup 16 $Q > $OUT/trace_frames1_bench.json 2> $OUT/trace1.err
 cp $(find $OUT/trace1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
