@@ -31,6 +31,7 @@ struct Opts {
     bool has_pattern = false, ignore_case = false, quiet = false, json = false, no_gpu = false;
     uint64_t count = 1, repeat = 1, seed = 0;
     bool no_endo = false;
+    bool random_keys = false;
     uint32_t batch = 1u << 20, frames = 12;   // twelve frames own twelve hardware queues (runtime.cpp)
     int puzzle = 0;
     long prefix_length = -1;   // -l / --prefix-length (provider patterns)
@@ -151,6 +152,8 @@ void usage() {
             "                    [--checkpoint FILE]   (resume an interrupted scan from FILE; written as the scan runs)\n"
             "                    [--no-endo]           (unseeded searches, any format but P2TR, test six keys per curve\n"
             "                                           point — k, lambda k, lambda^2 k and their negations; this walks k0 + i only)\n"
+            "                    [--random-keys]       (an independent random key per candidate, drawn on the device — the shape of\n"
+            "                                           the reference's CPU path, src/scanner.rs:118-169; ~8x slower than the walk)\n"
             "                    PATTERN may be a provider pattern boha:b1000:N [-l PREFIX_LENGTH] [--provider-table CSV]\n"
             "  vgen-hip range (--range START:END | --puzzle P) [-p PATTERN] [-f FORMAT] [-c COUNT (0 = whole range)] ...\n"
             "  vgen-hip estimate -p PATTERN [-f FORMAT] [-i]\n"
@@ -192,6 +195,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "--json") o.json = true;
         else if (a == "--no-gpu") o.no_gpu = true;
         else if (a == "--no-endo") o.no_endo = true;
+        else if (a == "--random-keys") o.random_keys = true;
         else if (a == "--no-tui" || a == "--tui") {}                                   // no TUI in this build
         else if (a == "-l" || a == "--prefix-length") o.prefix_length = strtol(val().c_str(), nullptr, 10);
         else if (a == "--provider-table") o.provider_table = val();
@@ -339,7 +343,7 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         p.frames = o.frames;
         // a vanity search proper — random base, no range, no seed, no checkpoint — may test any keys it likes:
         // six images per curve point (VGEN_FLAG_ENDO, +30 % keys per second); everything else walks k0 + i
-        if (!o.no_endo && !has_range && !o.seed && o.checkpoint.empty() && fmt != 3) p.flags |= VGEN_FLAG_ENDO;
+        if (!o.no_endo && !o.random_keys && !has_range && !o.seed && o.checkpoint.empty() && fmt != 3) p.flags |= VGEN_FLAG_ENDO;
         vgen_ctx *c = nullptr;
         if (vgen_create(&p, &c) != VGEN_OK) die(std::string("GPU initialization failed: ") + vgen_last_error(nullptr));
         ctxs.push_back(c);
@@ -358,6 +362,10 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         memcpy(cfg.end, end, 32);
     }
     if (!o.checkpoint.empty()) cfg.checkpoint_path = o.checkpoint.c_str();   // resumable scan (not in the reference)
+    if (o.random_keys) {
+        if (has_range || !o.checkpoint.empty()) die("--random-keys draws an independent key per candidate: no range, no checkpoint");
+        cfg.flags |= VGEN_SCAN_RANDOM_KEYS;
+    }
 
     std::vector<vgen_generated> all;
     uint64_t total_ops = 0;
