@@ -219,7 +219,7 @@ def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, labe
     if fmt_name == "p2tr":
         # no frozen yardstick describes the taproot path (a scalar multiplication per key over the wide-window table): its
         # roofline is the issue bound the counters name, from the measured instructions per key
-        roof = issue_roofline(rate, ("seq_fwd_kernel", "seq_inv_kernel", "seq_bwd_kernel", "p2tr_finish_kernel"), "p2tr", "seq_bwd_kernel")
+        roof = issue_roofline(rate, ("seq_fwd_kernel", "seq_inv_kernel", "seq_bwd_kernel", "p2tr_tweak_kernel", "p2tr_out_kernel"), "p2tr", "p2tr_tweak_kernel")
         if roof:
             out["chip_frac"], out["roofline"] = roof["frac"], roof
     if note:
@@ -247,7 +247,7 @@ def issue_roofline(rate_keys, kernels, pmc_mode, dominant):
             "kernel_valu_busy_alone": dom.get("valu_busy"), "kernel_simd_cycles_per_valu_instr": dom.get("simd_cycles_per_valu_instr"),
             "kernel_lone_launch_us": dom.get("lone_launch_us_under_pmc"), "kernel_l2_hit_rate": dom.get("l2_hit_rate"),
             "kernel_hbm_side_gb_per_s": dom.get("hbm_side_gb_per_s"),
-            "note": "bound named by the counters: the dominant kernel alone on the chip has VALU-busy ~1.0 (keys_fwd) / 0.76 (seq_bwd<P2TR>, two "
+            "note": "bound named by the counters: the dominant kernel alone on the chip has VALU-busy ~1.0 (keys_fwd_kernel, p2tr_tweak_kernel: three "
                     "waves per SIMD) while its table gathers (one 64-byte sector per window from a multi-GB table, L2 hit ~10 %) stay "
                     "at 1-2.3 TB/s of the memory side; narrower tables that fit the 256 MB Infinity Cache are SLOWER in proportion to "
                     "their extra additions (profiles/pmc_keys.json: keys16 / keys20 / keys24) — the gather does not bind, the "
@@ -270,8 +270,10 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False):
             r.dispatch_random(42, 0, ctr[0] * batch, f)
             ctr[0] += 1
     else:
-        rng = random.Random(42)
-        blob = b"".join((rng.getrandbits(256) % (N_ORDER - 1) + 1).to_bytes(32, "big") for _ in range(4096)) * (batch // 4096)
+        # `batch` DISTINCT random scalars: a short block repeated would make the table gathers cache hits and flatter the rate
+        # (round 2's 4 096 keys x 256: 1.44 Gkeys/s where distinct scalars give ~1.3); 32 random bytes are a valid scalar
+        # except with probability 2^-128
+        blob = random.Random(42).randbytes(32 * batch)
 
         def go(f):
             r.dispatch_keys(blob, f)

@@ -15,14 +15,15 @@ fmt = vg.AddressFormat.P2tr if mode == "p2tr" else vg.AddressFormat.P2pkh
 r = vg.GpuRunner(batch_size=batch, fmt=fmt, frames=1)
 r.set_filter(vg.Pattern("^bc1pqqq" if mode == "p2tr" else "^1Cat", False, fmt))
 if mode == "keys":
-    rng = random.Random(42)
-    blob = b"".join((rng.getrandbits(256) % (N_ORDER - 1) + 1).to_bytes(32, "big") for _ in range(65536)) * (batch // 65536)
+    # 2^20 DISTINCT random scalars (a block of keys repeated would turn the table gathers into cache hits; 32 random bytes are
+    # a valid scalar except with probability 2^-128)
+    blob = random.Random(42).randbytes(32 * batch)
 k0 = int.from_bytes(__import__("hashlib").sha256(b"pmc").digest(), "big") % N_ORDER
 for i in range(steps):
     if mode == "keys":
         r.dispatch_keys(blob, 0)
     elif mode == "random":
-        r.dispatch_random(bytes(range(32)), i, 0)
+        r.dispatch_random(42, 0, i * batch, 0)
     else:
         r.dispatch(k0 + i * batch, 0)
     r.wait(0)

@@ -24,12 +24,12 @@ for m in $MODES; do
   run ${m}_tcc TCC_HIT_sum TCC_MISS_sum -- $m
   run ${m}_wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VALU -- $m
 done
-# the gather question: the same KEYS kernel over tables that fit the 256 MB Infinity Cache (16 bits: 67 MB) or not (20: 872 MB; 24: 11.8 GB)
+# the gather question (2^20 distinct random scalars per launch: the random-stream mode): the same KEYS kernel over tables that fit the 256 MB Infinity Cache (16 bits: 67 MB) or not (20: 872 MB; 24: 11.8 GB)
 for bits in 16 20 24; do
   export VGEN_GTAB_BITS=$bits
-  run keys${bits}_sq $SQ -- keys
-  run keys${bits}_fetch FETCH_SIZE -- keys
-  run keys${bits}_tcc TCC_HIT_sum TCC_MISS_sum -- keys
+  run keys${bits}_sq $SQ -- random
+  run keys${bits}_fetch FETCH_SIZE -- random
+  run keys${bits}_tcc TCC_HIT_sum TCC_MISS_sum -- random
 done
 unset VGEN_GTAB_BITS
 python3 $GRAFT_REPO_ROOT/tools/pmc_keys_summarize.py $OUT > $OUT/pmc_keys.json

@@ -14,13 +14,11 @@ namespace vg {
 constexpr u32 TAP_ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                                 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
-// x, y: canonical affine internal key; tabs: the generator tables (ec.h).  q = lift_x(x) + TapTweak(x)*G in Jacobian
-// coordinates.  Returns false when the tweak is not a valid scalar (t == 0 or t >= n: probability ~2^-128;
-// q is then some other valid point) — such keys yield no address (Address::p2tr would fail there).
-// q.z == 0 (t*G == -P) is the caller's to check.
-VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const GenTables &tabs, gej &q) {
-    u32 xw[8], tb[8], k[8];
-    fe_to_words(x, xw);
+// t = TapTweak(x) as eight little-endian words; xw: x as eight words, xw[0] least significant.  Returns false (and t = 1, a
+// harmless stand-in) when the tweak is not a valid scalar (t == 0 or t >= n: probability ~2^-128) — such keys yield no
+// address (Address::p2tr would fail there).
+VG_HD bool taproot_tweak_scalar(const u32 xw[8], u32 k[8]) {
+    u32 tb[8];
     sha256_taptweak(xw, tb);
 #pragma unroll
     for (int i = 0; i < 8; i++) k[i] = tb[7 - i];   // little-endian words
@@ -38,10 +36,11 @@ VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const GenTables &tabs, 
         for (int i = 0; i < 8; i++) k[i] = 0;
         k[0] = 1;
     }
-    gej tg;
-    ec_mul_gen_tables(tg, k, tabs);
-    // P with even Y
-    ge p;
+    return ok;
+}
+
+// lift_x: the point with this x and EVEN y (y canonical).
+VG_HD void taproot_lift_even(ge &p, const fe &x, const fe &y) {
     p.x = x;
     fe ny;
     fe_neg(ny, y, 1);
@@ -49,6 +48,19 @@ VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const GenTables &tabs, 
     const bool odd = (y.n[0] & 1u) != 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) p.y.n[i] = odd ? ny.n[i] : y.n[i];
+}
+
+// x, y: canonical affine internal key; tabs: the generator tables (ec.h).  q = lift_x(x) + TapTweak(x)*G in Jacobian
+// coordinates.  Returns false when the tweak is not a valid scalar (q is then some other valid point).
+// q.z == 0 (t*G == -P) is the caller's to check.
+VG_HD bool taproot_tweak_point(const fe &x, const fe &y, const GenTables &tabs, gej &q) {
+    u32 xw[8], k[8];
+    fe_to_words(x, xw);
+    const bool ok = taproot_tweak_scalar(xw, k);
+    gej tg;
+    ec_mul_gen_tables(tg, k, tabs);
+    ge p;
+    taproot_lift_even(p, x, y);
     gej_add_ge_nz(q, tg, p);              // t*G == +/-P would need t = +/-d: negligible; Z = 0 then
     return ok;
 }

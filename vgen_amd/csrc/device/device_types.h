@@ -105,18 +105,12 @@ struct SeqArgs {
     uint32_t match_base;       // value of mhdr->count when this dispatch was enqueued
     uint32_t match_cap;
     const uint32_t *dfa_blob;  // DEVF_DFA: the automaton (device memory), staged into LDS by the kernel
-    const uint32_t *gtab;      // P2TR: 8-bit fixed-window generator table (global memory) for the tweak multiplication
-    const uint32_t *gtab16;    // ... and the wide-window one (built on the device at first use); nullptr = use gtab
-    uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22)
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
     uint32_t reserved0;
     uint32_t endo;             // seq_bwd: test the six endomorphism / negation images of every point (kernels.hip: ENDO)
-    // P2TR only: the tweaked points Q = P + t*G of a dispatch wait for a second shared inversion.
-    uint32_t *tq;              // [2S key steps][27][lanes]: X(Q), Z(Q), running product of the lane's Z's
-    uint32_t *tq_flag;         // [2S][lanes]: 1 = the key has an address (valid tweak, Q finite)
-    uint32_t *tree2;           // product tree / roots of the lanes' final products, laid out like tree / root
-    uint32_t *root2;
+    uint32_t *pts;             // P2TR only: the affine internal keys of the dispatch in key order, [N][16] words (x then y as
+                               // eight little-endian words each), handed to p2tr_tweak_kernel
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 
@@ -130,11 +124,7 @@ struct KeysArgs {
     const uint32_t *gtab;      // [32][255][20]: x limbs 0..8, y limbs 9..17 of d * 256^w * G (d = 1..255)
     const uint32_t *gtab16;    // wide windows: [windows][2^bits - 1][16 words] (core/ec.h: ec_mul_gen_wide); nullptr = use gtab
     uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22)
-    const uint8_t *keys_be;    // n * 32 bytes big-endian, or nullptr: key i = base + i, or (rnd) drawn from the scalar stream
-    uint32_t rnd;              // 1: key i = rnd_scalar(rnd_seed, rnd_stream, rnd_index + i) (core/rnd.h); keys_be and base unused
-    uint32_t rnd_stream;
-    uint32_t rnd_seed[2];      // lo, hi
-    uint32_t rnd_index[2];     // index of lane 0: lo, hi
+    const uint8_t *keys_be;    // n * 32 bytes big-endian (uploaded, or drawn on the device by rnd_fill_kernel), or nullptr: key i = base + i
     const DevFilter *filter;
     uint32_t *dump;            // dump mode: n * 5 words (zeroed for invalid keys)
     DevMatchHeader *mhdr;
@@ -147,7 +137,9 @@ struct KeysArgs {
     const uint32_t *dfa_blob;  // DEVF_DFA (see SeqArgs)
     uint32_t dfa_bytes;
     uint32_t groups;           // workgroups = ceil(n / KEYS_WG)
-    uint32_t *xyz;             // scratch: Jacobian results, limb-major [27][groups * KEYS_WG] (X, Y, Z limbs)
+    uint32_t *pts;             // P2TR: affine internal keys in key order, [n][16] words (written by keys_bwd_kernel<P2TR> / seq_bwd_kernel<P2TR>,
+                               // read by p2tr_tweak_kernel); y = 0 marks "no key"
+    uint32_t *xyz;             // scratch: Jacobian results, limb-major [27][groups * KEYS_WG] (X, Y, Z limbs; the taproot stage: X, validity word, Z)
     uint32_t *tree;            // scratch: product-tree nodes [groups][9][KEYS_WG]
     uint32_t *root;            // scratch: tree roots / their inverses [9][groups]
 };

@@ -26,8 +26,9 @@
 //     only candidate records through a wave-aggregated atomic slot counter.
 //   * The same staging (per-lane work -> product tree -> one root per lane inverted -> finish) carries the two
 //     paths that need a scalar multiplication per key: arbitrary scalars (keys_fwd / keys_bwd) and the taproot
-//     tweak (seq_bwd<P2TR> parks Q = P + t*G, p2tr_finish_kernel completes it).  Fused forms with the inversion
-//     inside one kernel were measured first and lost a third to a half to the lone inverting wave.
+//     tweak (the sequential and the arbitrary-scalar path hand the affine internal keys to p2tr_tweak_kernel, which
+//     parks Q = P + t*G, and p2tr_out_kernel completes it).  Fused forms with the inversion inside one kernel were
+//     measured first and lost a third to a half to the lone inverting wave.
 //   * One launch is ~1 wave per SIMD at the default batch, so the device is filled by frames in flight (twelve by
 //     default, one stream each: runtime.cpp); seq_bwd is capped at 128 VGPRs so that four launches share a SIMD.
 //   * The waves of the short, latency-bound first half of a dispatch (seq_fwd_kernel, seq_inv_kernel) raise their issue
@@ -50,7 +51,7 @@ namespace vg {
 constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 
 #ifndef VG_SEQ_WAVES_P2TR
-#define VG_SEQ_WAVES_P2TR 2
+#define VG_SEQ_WAVES_P2TR 4
 #endif
 #ifndef VG_SEQ_WAVES_ETH
 #define VG_SEQ_WAVES_ETH 3
@@ -97,56 +98,6 @@ __device__ __forceinline__ void shfl_xor_fe(fe &r, const fe &a, int mask) {
     for (int i = 0; i < 9; i++) r.n[i] = (u32)__shfl_xor((int)a.n[i], mask);
 }
 
-// 1/z for every lane of the workgroup through ONE Fermat inversion: product tree in LDS (leaf pairs by lane
-// shuffle), the root inverted by lane 0, the tree walked back down (the same tree as seq_fwd / seq_bwd, inside
-// one kernel).  z != 0 in every lane; all WG lanes must call it; `tree` is 9*WG words of LDS.
-__device__ __forceinline__ void wg_batch_inverse(fe &zi, const fe &z, u32 *tree) {
-    const int tid = threadIdx.x;
-    fe sib, pair;
-    shfl_xor_fe(sib, z, 1);
-    fe_mul(pair, z, sib);
-    __syncthreads();   // earlier readers of the tree are done
-    if ((tid & 1) == 0) lds_store_fe(tree, WG, WG / 2 + (tid >> 1), pair);
-    __syncthreads();
-#pragma unroll 1
-    for (int width = WG / 4; width >= 1; width >>= 1) {
-        if (tid < width) {
-            const int k = width + tid;
-            fe a, b, p;
-            lds_load_fe(tree, WG, 2 * k, a);
-            lds_load_fe(tree, WG, 2 * k + 1, b);
-            fe_mul(p, a, b);
-            lds_store_fe(tree, WG, k, p);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        fe r, ri;
-        lds_load_fe(tree, WG, 1, r);
-        fe_inv(ri, r);
-        lds_store_fe(tree, WG, 1, ri);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int width = 1; width <= WG / 4; width <<= 1) {
-        if (tid < width) {
-            const int k = width + tid;
-            fe ik, a, b, ia, ib;
-            lds_load_fe(tree, WG, k, ik);
-            lds_load_fe(tree, WG, 2 * k, a);
-            lds_load_fe(tree, WG, 2 * k + 1, b);
-            fe_mul(ia, ik, b);
-            fe_mul(ib, ik, a);
-            lds_store_fe(tree, WG, 2 * k, ia);
-            lds_store_fe(tree, WG, 2 * k + 1, ib);
-        }
-        __syncthreads();
-    }
-    fe ip;
-    lds_load_fe(tree, WG, WG / 2 + (tid >> 1), ip);
-    fe_mul(zi, ip, sib);
-}
-
 // ---- payload per format -----------------------------------------------------------------------------
 
 template <int FMT>
@@ -154,27 +105,13 @@ struct PayloadWords {
     static constexpr int value = (FMT == VGF_P2TR) ? 8 : 5;
 };
 
-// x, y: canonical affine public key.  out: the payload words in memory order (PayloadWords<FMT>).
-// tabs: the fixed-window generator tables in global memory, tree: 9*WG words of LDS (both P2TR only: the
-// arbitrary-scalar path's taproot keys; the sequential path parks its tweaked points instead, see seq_bwd_kernel).
-// Returns false when the key yields no address (P2TR tweak not a valid scalar — probability ~2^-128).
+// x, y: canonical affine public key.  out: the payload words in memory order (PayloadWords<FMT>), for the five formats
+// whose payload is a hash of the key itself (the taproot output key needs a scalar multiplication and a shared inversion
+// of its own: p2tr_tweak_kernel / p2tr_out_kernel below).
 template <int FMT>
-__device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, const GenTables &tabs, u32 *tree, u32 *out) {
+__device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, u32 *out) {
+    static_assert(FMT != VGF_P2TR, "taproot payloads come from p2tr_tweak_kernel / p2tr_out_kernel");
     u32 xw[8];
-    if (FMT == VGF_P2TR) {
-        // Q = lift_x(x) + t*G per lane (8-bit fixed windows over the global table), then ONE inversion for the
-        // whole workgroup: every lane of the workgroup must be here (the callers' loops are uniform).
-        gej q;
-        bool ok = taproot_tweak_point(x, y_canon, tabs, q);
-        const bool zero = taproot_z_is_zero(q.z);     // t*G == -P: no address; keep the shared product invertible
-        if (zero) fe_set_one(q.z);
-        fe zi;
-        wg_batch_inverse(zi, q.z, tree);
-        taproot_affine_x(q, zi, xw);
-#pragma unroll
-        for (int i = 0; i < 8; i++) out[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
-        return ok && !zero;
-    }
     fe_to_words(x, xw);
     if (FMT == VGF_P2PKH || FMT == VGF_P2WPKH) {
         u32 sha[8];
@@ -313,7 +250,6 @@ seq_bwd_kernel(const SeqArgs args) {
     extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
-    const GenTables gtab{args.gtab, args.gtab16, args.gtab_bits};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache)
     u32 *dfa_lds = dyn_lds;
     if (FULL) {
         for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
@@ -370,8 +306,6 @@ seq_bwd_kernel(const SeqArgs args) {
 
     const u32 half = args.n >> 1;
     const bool dump = args.dump != nullptr;
-    fe zrun;            // P2TR: running product of this lane's Z(Q)
-    u32 step = 0;       // P2TR: key step 0 .. 2S-1 in loop order
 
 #pragma unroll 1
     for (int j = (int)S - 1; j >= 0; j--) {
@@ -422,28 +356,22 @@ seq_bwd_kernel(const SeqArgs args) {
             else
                 fe_canonicalize_product(y3);
 
+            const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (FMT == VGF_P2TR) {
-                // Taproot, stage A: the tweaked point Q = lift_x(x) + t*G stays Jacobian; X, Z and the lane's
-                // running product of Z's are parked for the second shared inversion (p2tr_finish_kernel).
-                gej qq;
-                const bool okq = taproot_tweak_point(x3, y3, gtab, qq);
-                const bool zero = taproot_z_is_zero(qq.z);   // t*G == -P: no address; keep the products invertible
-                if (zero) fe_set_one(qq.z);
-                if (step == 0) zrun = qq.z;
-                else fe_mul(zrun, zrun, qq.z);
-                u32 *o = args.tq + (size_t)step * 27 * lanes + u;
-#pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    o[(size_t)i * lanes] = qq.x.n[i];
-                    o[(size_t)(9 + i) * lanes] = qq.z.n[i];
-                    o[(size_t)(18 + i) * lanes] = zrun.n[i];
-                }
-                args.tq_flag[(size_t)step * lanes + u] = (okq && !zero) ? 1u : 0u;
-                step++;
+                // Taproot: this kernel only produces the affine internal key P of every key, in key order (64 bytes per key:
+                // x then y as eight words each); the tweak t*G, the addition and the shared inversion of the results are
+                // p2tr_tweak_kernel / p2tr_out_kernel's (one key per lane there: the 150-register multiplication does not share
+                // a kernel — and its occupancy — with this loop's state any more).
+                u32 xw[8], yw[8];
+                fe_to_words(x3, xw);
+                fe_to_words(y3, yw);
+                ec_u4 *o = reinterpret_cast<ec_u4 *>(args.pts + (size_t)index * 16);
+                o[0] = ec_u4{{xw[0], xw[1], xw[2], xw[3]}};
+                o[1] = ec_u4{{xw[4], xw[5], xw[6], xw[7]}};
+                o[2] = ec_u4{{yw[0], yw[1], yw[2], yw[3]}};
+                o[3] = ec_u4{{yw[4], yw[5], yw[6], yw[7]}};
                 continue;
             }
-
-            const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (ENDO) {
                 // compressed-key formats need only the parity of y (flipped for the negations); the others the canonical
                 // y itself, parked beside x, and p - y for the negations
@@ -475,7 +403,7 @@ seq_bwd_kernel(const SeqArgs args) {
                         ye.n[0] = ypar ^ sneg;     // all a compressed key reads of y
                     }
                     u32 ple[NW];
-                    (void)payload_from_point<FMT>(xe, ye, gtab, tree, ple);
+                    (void)payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(xe, ye, ple);
                     const u32 vindex = (sneg * 3u + e) * args.n + index;
                     if (dump) {
                         u32 *o = args.dump + (size_t)vindex * NW;
@@ -496,7 +424,7 @@ seq_bwd_kernel(const SeqArgs args) {
             }
 
             u32 pl[NW];
-            const bool ok = payload_from_point<FMT>(x3, y3, gtab, tree, pl);
+            const bool ok = payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(x3, y3, pl);   // (never reached for P2TR: see above)
 
             if (dump) {
                 u32 *o = args.dump + (size_t)index * NW;
@@ -519,125 +447,190 @@ seq_bwd_kernel(const SeqArgs args) {
         args.mhdr->clk_cycles += (u32)(clock64() - stamp_c0);
         args.mhdr->clk_ticks += (u32)(wall_clock64() - stamp_w0);
     }
-    if (FMT == VGF_P2TR) {
-        // product tree of the lanes' final products (as seq_fwd_kernel does for the denominators)
-        __syncthreads();
-        fe sib, pair;
-        shfl_xor_fe(sib, zrun, 1);
-        fe_mul(pair, zrun, sib);
-        if ((tid & 1) == 0) lds_store_fe(tree, WG, WG / 2 + (tid >> 1), pair);
-        __syncthreads();
+}
+
+// ---- taproot: tweak, shared inversion, output key -------------------------------------------------------------------------
+//
+// What the reference leaves to the HOST for every key of a P2TR batch (XOnlyPublicKey::from_slice + Address::p2tr,
+// src/gpu.rs:1287-1291, "CPU bound by design" src/shaders/search_p2tr.wgsl:112).  Both scan paths hand over the affine
+// internal keys P in key order (`pts`, 64 bytes per key; y = 0 marks "no key"), then:
+//   p2tr_tweak_kernel  one key per lane: t = TapTweak(x(P)), Q = lift_x(P) + t*G over the wide-window table (core/taproot.h);
+//                      X(Q), Z(Q) and a validity word are parked, the Z's of the workgroup go into a product tree, its root out;
+//   seq_inv_kernel     the roots of all workgroups, one per lane;
+//   p2tr_out_kernel    tree down-sweep, 1/Z per lane, x(Q) = X / Z^2, the usual dump / prefilter / DFA output.
+// Exactly the staging of keys_fwd / keys_bwd — the multiplication is the same code with the same ~145 registers, so it runs
+// at three waves per SIMD with the VALU busy, where round 2's seq_bwd_kernel<P2TR> carried it inside the sequential loop
+// at 255 registers, two waves per SIMD and VALU-busy 0.76 (profiles/pmc_keys.json).
+
+// Product tree over the KEYS_WG lanes of a workgroup (leaf pairs by lane shuffle), tree and root written out.
+__device__ __forceinline__ void keys_tree_up(u32 *tree, const fe &z, u32 *tree_out, u32 *root, u32 groups) {
+    const int tid = threadIdx.x;
+    fe sib, pair;
+    shfl_xor_fe(sib, z, 1);
+    fe_mul(pair, z, sib);
+    if ((tid & 1) == 0) lds_store_fe(tree, KEYS_WG, KEYS_WG / 2 + (tid >> 1), pair);
+    __syncthreads();
 #pragma unroll 1
-        for (int width = WG / 4; width >= 1; width >>= 1) {
-            if (tid < width) {
-                const int k = width + tid;
-                fe a, b, p;
-                lds_load_fe(tree, WG, 2 * k, a);
-                lds_load_fe(tree, WG, 2 * k + 1, b);
-                fe_mul(p, a, b);
-                lds_store_fe(tree, WG, k, p);
-            }
-            __syncthreads();
+    for (int width = KEYS_WG / 4; width >= 1; width >>= 1) {
+        if (tid < width) {
+            const int kk = width + tid;
+            fe a, b, p;
+            lds_load_fe(tree, KEYS_WG, 2 * kk, a);
+            lds_load_fe(tree, KEYS_WG, 2 * kk + 1, b);
+            fe_mul(p, a, b);
+            lds_store_fe(tree, KEYS_WG, kk, p);
         }
-        u32 *t2 = args.tree2 + (size_t)blockIdx.x * 9 * WG;
+        __syncthreads();
+    }
+    u32 *tg = tree_out + (size_t)blockIdx.x * 9 * KEYS_WG;
 #pragma unroll
-        for (int i = 0; i < 9; i++) t2[i * WG + tid] = tree[i * WG + tid];
-        if (tid < 9) args.root2[(size_t)tid * args.groups + blockIdx.x] = tree[tid * WG + 1];
+    for (int i = 0; i < 9; i++) tg[i * KEYS_WG + tid] = tree[i * KEYS_WG + tid];
+    if (tid < 9) root[(size_t)tid * groups + blockIdx.x] = tree[tid * KEYS_WG + 1];
+}
+
+// The way back: tree (with the inverted root) walked down in LDS; returns 1 / (z * z_sibling) of the caller's lane pair.
+__device__ __forceinline__ void keys_tree_down(u32 *tree, const u32 *tree_in, const u32 *root, u32 groups, fe &ip) {
+    const int tid = threadIdx.x;
+    const u32 *tg = tree_in + (size_t)blockIdx.x * 9 * KEYS_WG;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tree[i * KEYS_WG + tid] = tg[i * KEYS_WG + tid];
+    __syncthreads();
+    if (tid < 9) tree[tid * KEYS_WG + 1] = root[(size_t)tid * groups + blockIdx.x];   // root^-1
+    __syncthreads();
+#pragma unroll 1
+    for (int width = 1; width <= KEYS_WG / 4; width <<= 1) {
+        if (tid < width) {
+            const int kk = width + tid;
+            fe ik, a, b, ia, ib;
+            lds_load_fe(tree, KEYS_WG, kk, ik);
+            lds_load_fe(tree, KEYS_WG, 2 * kk, a);
+            lds_load_fe(tree, KEYS_WG, 2 * kk + 1, b);
+            fe_mul(ia, ik, b);
+            fe_mul(ib, ik, a);
+            lds_store_fe(tree, KEYS_WG, 2 * kk, ia);
+            lds_store_fe(tree, KEYS_WG, 2 * kk + 1, ib);
+        }
+        __syncthreads();
+    }
+    lds_load_fe(tree, KEYS_WG, KEYS_WG / 2 + (tid >> 1), ip);
+}
+
+__global__ void __launch_bounds__(KEYS_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) p2tr_tweak_kernel(const KeysArgs args) {
+    __shared__ u32 tree[9 * KEYS_WG];
+    const u32 idx = blockIdx.x * KEYS_WG + threadIdx.x;
+    const u32 lanes = args.groups * KEYS_WG;
+    // the tweak needs x only: the internal key is loaded again for the addition that follows the multiplication, so that its
+    // eighteen limbs are not live across the ~145-register window loop (three waves per SIMD instead of two)
+    const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(args.pts + (size_t)(idx < args.n ? idx : 0) * 16);
+    u32 xw[8], k[8];
+#pragma unroll
+    for (int q4 = 0; q4 < 2; q4++) {
+        const ec_u4 t4 = e4[q4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) xw[4 * q4 + i] = t4.v[i];
+    }
+    const bool okq = taproot_tweak_scalar(xw, k);
+    gej tg;
+    ec_mul_gen_tables(tg, k, GenTables{args.gtab, args.gtab16, args.gtab_bits});
+    u32 w[16];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+        const ec_u4 t4 = e4[q4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[4 * q4 + i] = t4.v[i];
+    }
+    u32 ynz = 0;
+#pragma unroll
+    for (int i = 8; i < 16; i++) ynz |= w[i];
+    const bool have = idx < args.n && ynz != 0;
+    ge p;
+    {
+        fe px, py;
+        fe_from_words(px, w);
+        fe_from_words(py, w + 8);
+        taproot_lift_even(p, px, py);
+        ge g;
+        ge_generator(g);      // "no key here": a harmless stand-in keeps the workgroup's product invertible; the result is discarded
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            p.x.n[i] = have ? p.x.n[i] : g.x.n[i];
+            p.y.n[i] = have ? p.y.n[i] : g.y.n[i];
+        }
+    }
+    gej q;
+    gej_add_ge_nz(q, tg, p);                      // t*G == +/-P would need t = +/-d: negligible; Z = 0 then
+    const bool zero = taproot_z_is_zero(q.z);     // t*G == -P: no address; keep the shared product invertible
+    if (zero) fe_set_one(q.z);
+    u32 *o = args.xyz + idx;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        o[(size_t)i * lanes] = q.x.n[i];
+        o[(size_t)(18 + i) * lanes] = q.z.n[i];
+    }
+    o[(size_t)9 * lanes] = (have && okq && !zero) ? 1u : 0u;
+    keys_tree_up(tree, q.z, args.tree, args.root, args.groups);
+}
+
+template <bool FULL>
+__global__ void __launch_bounds__(KEYS_WG) p2tr_out_kernel(const KeysArgs args) {
+    __shared__ u32 tree[9 * KEYS_WG];
+    extern __shared__ u32 dfa_lds[];    // FULL: the DFA blob
+    const int tid = threadIdx.x;
+    if (FULL)
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += KEYS_WG) dfa_lds[i] = args.dfa_blob[i];
+    const u32 idx = blockIdx.x * KEYS_WG + tid;
+    const u32 lanes = args.groups * KEYS_WG;
+    fe ip;
+    keys_tree_down(tree, args.tree, args.root, args.groups, ip);
+    // 1/Z = 1/(Z * Z_sib) * Z_sib
+    const u32 *in = args.xyz + idx;
+    const u32 *ins = args.xyz + (idx ^ 1u);
+    gej q;
+    fe zs, zi;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        q.x.n[i] = in[(size_t)i * lanes];
+        zs.n[i] = ins[(size_t)(18 + i) * lanes];
+    }
+    const bool ok = in[(size_t)9 * lanes] != 0 && idx < args.n;
+    fe_mul(zi, ip, zs);
+    u32 xw[8], pl[8];
+    taproot_affine_x(q, zi, xw);
+#pragma unroll
+    for (int i = 0; i < 8; i++) pl[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
+    if (idx >= args.n) return;
+    if (args.dump) {
+        u32 *o = args.dump + (size_t)idx * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
+    } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
+        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+        if (slot < args.match_cap) {
+            DevMatch *m = args.mrec + slot;
+            m->index = idx;
+            m->reserved = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) m->payload[i] = pl[i];
+        }
     }
 }
 
-// ---- taproot, stage C: second shared inversion walked back, x(Q), filter ---------------------------------------
-//
-// After seq_bwd_kernel<P2TR> (stage A) and seq_inv_kernel on root2: every lane recovers 1/(product of its 2S
-// Z's) from the tree, then peels 1/Z of each key step off it in reverse order (two multiplications per key, as
-// seq_bwd does for the denominators), x(Q) = X / Z^2, and the usual dump / prefilter / DFA output.
-template <bool FULL>
-__global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
-    __shared__ u32 tree[9 * WG];
-    extern __shared__ u32 dfa_lds[];
-    const int tid = threadIdx.x;
-    if (FULL)
-        for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
-    const u32 S = args.s, lanes = args.lanes;
-    const u32 u = blockIdx.x * WG + tid;
-    const u32 steps = 2 * S;
-
-    const u32 *t2 = args.tree2 + (size_t)blockIdx.x * 9 * WG;
-#pragma unroll
-    for (int i = 0; i < 9; i++) tree[i * WG + tid] = t2[i * WG + tid];
-    __syncthreads();
-    if (tid < 9) tree[tid * WG + 1] = args.root2[(size_t)tid * args.groups + blockIdx.x];   // root^-1
-    __syncthreads();
-#pragma unroll 1
-    for (int width = 1; width <= WG / 4; width <<= 1) {
-        if (tid < width) {
-            const int k = width + tid;
-            fe ik, a, b, ia, ib;
-            lds_load_fe(tree, WG, k, ik);
-            lds_load_fe(tree, WG, 2 * k, a);
-            lds_load_fe(tree, WG, 2 * k + 1, b);
-            fe_mul(ia, ik, b);
-            fe_mul(ib, ik, a);
-            lds_store_fe(tree, WG, 2 * k, ia);
-            lds_store_fe(tree, WG, 2 * k + 1, ib);
-        }
-        __syncthreads();
-    }
-    fe inv;   // 1 / (product of this lane's Z's up to the step being peeled)
-    {
-        fe ip, sib;
-        lds_load_fe(tree, WG, WG / 2 + (tid >> 1), ip);
-#pragma unroll
-        for (int i = 0; i < 9; i++) sib.n[i] = args.tq[((size_t)(steps - 1) * 27 + 18 + i) * lanes + (u ^ 1u)];
-        fe_mul(inv, ip, sib);
-    }
-    const u32 half = args.n >> 1;
-    const bool dump = args.dump != nullptr;
-#pragma unroll 1
-    for (int step = (int)steps - 1; step >= 0; step--) {
-        const u32 *in = args.tq + (size_t)step * 27 * lanes + u;
-        fe X, Z, zi;
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            X.n[i] = in[(size_t)i * lanes];
-            Z.n[i] = in[(size_t)(9 + i) * lanes];
-        }
-        if (step > 0) {
-            fe pprev;   // the lane's running product up to the previous step
-            const u32 *prev = args.tq + (size_t)(step - 1) * 27 * lanes + u;
-#pragma unroll
-            for (int i = 0; i < 9; i++) pprev.n[i] = prev[(size_t)(18 + i) * lanes];
-            fe_mul(zi, inv, pprev);
-            fe_mul(inv, inv, Z);
-        } else {
-            zi = inv;
-        }
-        gej qq;
-        qq.x = X;
-        u32 xw[8], pl[8];
-        taproot_affine_x(qq, zi, xw);
-#pragma unroll
-        for (int i = 0; i < 8; i++) pl[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
-        const bool ok = args.tq_flag[(size_t)step * lanes + u] != 0;
-
-        // stage A walks j = S-1 .. 0 and, within j, +R then -R
-        const u32 j = S - 1 - ((u32)step >> 1), sgn = (u32)step & 1u;
-        const u32 index = sgn ? (half - (u + 1) * S + j) : (half + u * S + j);
-        if (dump) {
-            u32 *o = args.dump + (size_t)index * 8;
-#pragma unroll
-            for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
-        } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
-            const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-            if (slot < args.match_cap) {
-                DevMatch *m = args.mrec + slot;
-                m->index = index;
-                m->reserved = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) m->payload[i] = pl[i];
-            }
-        }
-    }
+// a: the context's output / filter / table fields, n keys whose internal keys lie in a.pts; a.xyz / a.tree / a.root: scratch
+// for a.groups = ceil(n / 256) workgroups.
+hipError_t launch_p2tr_tweak(const KeysArgs &a, hipStream_t stream) {
+    if (a.n == 0) return hipSuccess;
+    const bool full = a.dfa_bytes && !a.dump;
+    if (full && a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
+    if (!a.pts || !a.gtab || !a.xyz || !a.tree || !a.root || a.groups != (a.n + KEYS_WG - 1) / KEYS_WG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(p2tr_tweak_kernel, dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root, a.groups);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (full) hipLaunchKernelGGL((p2tr_out_kernel<true>), dim3(a.groups), dim3(KEYS_WG), a.dfa_bytes, stream, a);
+    else hipLaunchKernelGGL((p2tr_out_kernel<false>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
+    return hipGetLastError();
 }
 
 // ---- arbitrary scalars: full fixed-base multiplication per key ------------------------------------------------
@@ -658,16 +651,12 @@ __global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
 constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                             0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
-// Scalar of lane `idx` as eight little-endian words — uploaded (keys_be), base + idx, or drawn from the counter-based
-// stream (rnd: the reference's rng.fill per candidate, src/scanner.rs:151-152) —; false (and k = 1, a harmless stand-in
-// whose result is discarded) unless 0 < k < n (SecretKey::from_slice, src/address.rs:93) and idx < n.
+// Scalar of lane `idx` as eight little-endian words — from the key buffer (uploaded by vgen_dispatch_keys, or filled on the
+// device by rnd_fill_kernel for vgen_dispatch_random) or base + idx —; false (and k = 1, a harmless stand-in whose result
+// is discarded) unless 0 < k < n (SecretKey::from_slice, src/address.rs:93) and idx < n.
 __device__ __forceinline__ bool keys_load_scalar(const KeysArgs &args, u32 idx, u32 k[8]) {
     const bool in_range = idx < args.n;
-    if (args.rnd) {
-        // the counter-based scalar stream (core/rnd.h): one SHA-256 compression per lane, no upload
-        const u64 index = ((u64)args.rnd_index[1] << 32 | args.rnd_index[0]) + idx;
-        rnd_scalar(args.rnd_seed[0], args.rnd_seed[1], args.rnd_stream, (u32)index, (u32)(index >> 32), k);
-    } else if (args.keys_be) {
+    if (args.keys_be) {
         const u32 *src = reinterpret_cast<const u32 *>(args.keys_be) + (size_t)(in_range ? idx : 0) * 8;
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = bswap32(src[7 - i]);
@@ -699,6 +688,29 @@ __device__ __forceinline__ bool keys_load_scalar(const KeysArgs &args, u32 idx, 
         k[0] = 1;
     }
     return valid;
+}
+
+// The random-key mode's scalars (the reference's rng.fill per candidate, src/scanner.rs:151-152): lane i draws candidate
+// first_index + i of the counter-based stream (core/rnd.h: one SHA-256 compression) into the frame's key buffer, in the
+// 32-byte big-endian layout vgen_dispatch_keys uploads — so that the multiplication kernels are the very same code for both
+// (drawing the scalar inside keys_fwd_kernel kept the eight words live across its window loop and cost 15 %: 1.23 instead of
+// 1.44 Gkeys/s; this fill is 700 instructions and 32 B per key, ~3 % of the dispatch).
+__global__ void __launch_bounds__(256) rnd_fill_kernel(u32 *keys_be, u32 n, u32 seed_lo, u32 seed_hi, u32 stream, u32 index_lo, u32 index_hi) {
+    const u32 idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const u64 index = ((u64)index_hi << 32 | index_lo) + idx;
+    u32 k[8];
+    rnd_scalar(seed_lo, seed_hi, stream, (u32)index, (u32)(index >> 32), k);
+    ec_u4 *o = reinterpret_cast<ec_u4 *>(keys_be + (size_t)idx * 8);
+    o[0] = ec_u4{{bswap32(k[7]), bswap32(k[6]), bswap32(k[5]), bswap32(k[4])}};
+    o[1] = ec_u4{{bswap32(k[3]), bswap32(k[2]), bswap32(k[1]), bswap32(k[0])}};
+}
+
+hipError_t launch_rnd_fill(uint8_t *keys_be, u32 n, unsigned long long seed, u32 stream, unsigned long long first_index, hipStream_t st) {
+    if (!keys_be || n == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rnd_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<u32 *>(keys_be), n, (u32)seed, (u32)(seed >> 32),
+                       stream, (u32)first_index, (u32)(first_index >> 32));
+    return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(KEYS_WG) keys_fwd_kernel(const KeysArgs args) {
@@ -800,8 +812,21 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
     fe_canonicalize_product(x);
     fe_canonicalize_product(y);
 
+    if (FMT == VGF_P2TR) {
+        // taproot: hand the affine internal key over to p2tr_tweak_kernel (y = 0: no key here)
+        if (idx >= args.n) return;
+        u32 xw[8], yw[8];
+        fe_to_words(x, xw);
+        fe_to_words(y, yw);
+        ec_u4 *o = reinterpret_cast<ec_u4 *>(args.pts + (size_t)idx * 16);
+        o[0] = ec_u4{{xw[0], xw[1], xw[2], xw[3]}};
+        o[1] = ec_u4{{xw[4], xw[5], xw[6], xw[7]}};
+        o[2] = valid ? ec_u4{{yw[0], yw[1], yw[2], yw[3]}} : ec_u4{{0u, 0u, 0u, 0u}};
+        o[3] = valid ? ec_u4{{yw[4], yw[5], yw[6], yw[7]}} : ec_u4{{0u, 0u, 0u, 0u}};
+        return;
+    }
     u32 pl[NW];
-    const bool ok = payload_from_point<FMT>(x, y, GenTables{args.gtab, args.gtab16, args.gtab_bits}, tree, pl) && valid;   // P2TR: workgroup-wide
+    const bool ok = payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(x, y, pl) && valid;
 
     if (idx >= args.n) return;
     if (args.dump) {
@@ -832,6 +857,12 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEven
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (before_bwd && (e = hipEventRecord(before_bwd, stream)) != hipSuccess) return e;
+    if (FMT == VGF_P2TR) {
+        // the affine internal keys go to `pts`; tweak, second shared inversion and output are the taproot stage's
+        if (!a.pts) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((keys_bwd_kernel<FMT, false>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
+        return hipGetLastError();   // (runtime.cpp follows with launch_p2tr_tweak over the frame's taproot scratch)
+    }
     if (full) hipLaunchKernelGGL((keys_bwd_kernel<FMT, true>), dim3(a.groups), dim3(KEYS_WG), a.dfa_bytes, stream, a);
     else hipLaunchKernelGGL((keys_bwd_kernel<FMT, false>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
     return hipGetLastError();
@@ -1117,16 +1148,9 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
     const bool full = a.dfa_bytes && !a.dump;
     if (full && a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
     if (FMT == VGF_P2TR) {
-        // stage A (tweaked points parked) -> second root inversion -> stage C (finish + filter)
-        if (!a.gtab || !a.tq || !a.tq_flag || !a.tree2 || !a.root2) return hipErrorInvalidValue;
+        // this kernel parks the affine internal keys; runtime.cpp follows it with launch_p2tr_tweak
+        if (!a.pts) return hipErrorInvalidValue;
         hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root2, a.groups);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        if (full) hipLaunchKernelGGL((p2tr_finish_kernel<true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
-        else hipLaunchKernelGGL((p2tr_finish_kernel<false>), dim3(a.groups), dim3(WG), 0, stream, a);
         return hipGetLastError();
     }
     if (full && a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), true, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);

@@ -40,10 +40,13 @@ size_t scratch_words(const vgen_ctx *c) {
     return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
 }
 
-// P2TR: tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
+// P2TR (the taproot stage behind either scan path, one key per lane, G = ceil(batch / 256) workgroups):
+//   pts [batch][16] | xz [27][G * 256] | tree [G][9][256] | root [9][G]
+size_t p2tr_groups(const vgen_ctx *c) { return ((size_t)c->batch + KEYS_WG - 1) / KEYS_WG; }
 size_t p2tr_words(const vgen_ctx *c) {
     if (c->format != VGF_P2TR) return 0;
-    return (size_t)2 * c->S * 27 * c->lanes + (size_t)2 * c->S * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
+    const size_t g = p2tr_groups(c);
+    return (size_t)c->batch * 16 + (size_t)27 * g * KEYS_WG + g * 9 * KEYS_WG + (size_t)9 * g;
 }
 
 void fe_canon_neg(fe &r, const fe &a) {
@@ -613,6 +616,24 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
     return VGEN_OK;
 }
 
+// The taproot stage of frame f for n keys whose internal keys the preceding kernels parked in the frame's `pts`: output /
+// filter fields as the dispatch has them (`proto`), scratch from the frame's P2TR slice.
+int enqueue_p2tr_stage(vgen_ctx *c, vgen_ctx::Frame &f, const KeysArgs &proto, uint32_t n) {
+    KeysArgs t = proto;
+    const size_t g = p2tr_groups(c);
+    t.keys_be = nullptr;
+    t.n = n;
+    t.groups = (n + KEYS_WG - 1) / KEYS_WG;
+    t.pts = f.d_p2tr_scratch;
+    t.xyz = t.pts + (size_t)c->batch * 16;
+    t.tree = t.xyz + (size_t)27 * g * KEYS_WG;
+    t.root = t.tree + g * 9 * KEYS_WG;
+    // (the scratch is laid out for the full batch; a shorter dispatch uses its first t.groups workgroups' worth — the
+    //  limb-major xz array is indexed with t.groups * 256 lanes by the kernels, which fits inside the full-batch region)
+    HIP_TRY(c, launch_p2tr_tweak(t, f.s));
+    return VGEN_OK;
+}
+
 // Keys and scratch of the arbitrary-scalar path for all frames (keys [batch][32 B] | xyz | tree | root per
 // frame), one allocation when the path is first used: it serves vgen_dispatch_keys and the rare sequential
 // batches that touch the group order, so most contexts never pay its ~155 MB per frame.
@@ -631,16 +652,10 @@ int ensure_keys_slab(vgen_ctx *c) {
 
 // Enqueues the arbitrary-scalar kernels on frame f (its bwd stream carries the whole chain): explicit keys
 // (keys_dev != nullptr) or base + i.
-struct RandomStream {
-    uint64_t seed;
-    uint32_t stream;
-    uint64_t first_index;
-};
-
-int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n, const RandomStream *rnd = nullptr) {
+int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
     // worth the wide table: taproot contexts (their sequential path builds it anyway) and real arbitrary-scalar batches
     // (an explicit VGEN_GTAB_BITS is honoured whatever the batch: the parity tests of every width rely on it)
-    if (int rc = ensure_gtab(c, c->format == VGF_P2TR || ((keys_dev != nullptr || rnd != nullptr) && n >= 4096) || getenv("VGEN_GTAB_BITS") != nullptr)) return rc;
+    if (int rc = ensure_gtab(c, c->format == VGF_P2TR || (keys_dev != nullptr && n >= 4096) || getenv("VGEN_GTAB_BITS") != nullptr)) return rc;
     if (int rc = ensure_keys_slab(c)) return rc;
     KeysArgs a;
     memset(&a, 0, sizeof a);
@@ -650,14 +665,6 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     a.keys_be = keys_dev;
     if (base)
         for (int i = 0; i < 8; i++) a.base[i] = base->w[i];
-    if (rnd) {
-        a.rnd = 1;
-        a.rnd_stream = rnd->stream;
-        a.rnd_seed[0] = (uint32_t)rnd->seed;
-        a.rnd_seed[1] = (uint32_t)(rnd->seed >> 32);
-        a.rnd_index[0] = (uint32_t)rnd->first_index;
-        a.rnd_index[1] = (uint32_t)(rnd->first_index >> 32);
-    }
     a.filter = c->d_filter;
     a.n = n;
     a.fmt = c->format;
@@ -682,8 +689,11 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
             a.dfa_bytes = c->h_filter.dfa_bytes;
         }
     }
+    if (c->format == VGF_P2TR) a.pts = f.d_p2tr_scratch;   // keys_bwd_kernel<P2TR> parks the affine internal keys there
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s));
     HIP_TRY(c, launch_keys_scan((int)c->format, a, f.s, c->timing ? f.ev_mid : nullptr));
+    if (c->format == VGF_P2TR)
+        if (int rc = enqueue_p2tr_stage(c, f, a, n)) return rc;
     return finish_dispatch(c, f, dump, n);
 }
 
@@ -758,25 +768,33 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     const bool parks_y = c->format == VGF_P2PKH_UNCOMPRESSED || c->format == VGF_ETHEREUM;
     const bool endo_now = c->endo && !(a.dfa_bytes && parks_y && a.dfa_bytes + 2u * 9u * SEQ_WG * 4u > 64u * 1024u);
     a.endo = endo_now ? 1u : 0u;
-    if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
+    if (c->format == VGF_P2TR) {   // the taproot stage multiplies t*G over the fixed-window table (built at first use) ...
         if (int rc = ensure_gtab(c, true)) return rc;
-        a.gtab = c->d_gtab;
-        a.gtab16 = c->d_gtab16;
-        a.gtab_bits = c->gtab_bits;
-        // ... and the tweaked points of the dispatch wait in scratch for their shared inversion:
-        // tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
-        const size_t tq_words = (size_t)2 * S * 27 * c->lanes, flag_words = (size_t)2 * S * c->lanes;
-        const size_t tree_words = (size_t)c->groups * 9 * SEQ_WG;
-        a.tq = f.d_p2tr_scratch;
-        a.tq_flag = a.tq + tq_words;
-        a.tree2 = a.tq_flag + flag_words;
-        a.root2 = a.tree2 + tree_words;
+        a.pts = f.d_p2tr_scratch;  // ... and seq_bwd_kernel<P2TR> hands it the affine internal keys in key order
     }
     // the whole chain (seq_fwd -> seq_inv -> seq_bwd [-> P2TR stages] -> result copy) on the frame's own stream
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s));
     HIP_TRY(c, launch_seq_fwd(a, f.s));
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_mid, f.s));
     HIP_TRY(c, launch_seq_bwd((int)c->format, a, f.s));
+    if (c->format == VGF_P2TR) {
+        // tweak, second shared inversion and output keys: the same stage the arbitrary-scalar path ends with
+        KeysArgs t;
+        memset(&t, 0, sizeof t);
+        t.gtab = c->d_gtab;
+        t.gtab16 = c->d_gtab16;
+        t.gtab_bits = c->gtab_bits;
+        t.filter = c->d_filter;
+        t.dump = a.dump;
+        t.mhdr = a.mhdr;
+        t.mrec = a.mrec;
+        t.match_base = a.match_base;
+        t.match_cap = a.match_cap;
+        t.fmt = c->format;
+        t.dfa_blob = a.dfa_blob;
+        t.dfa_bytes = a.dfa_bytes;
+        if (int rc = enqueue_p2tr_stage(c, f, t, c->batch)) return rc;
+    }
     return finish_dispatch(c, f, dump, endo_now ? (uint64_t)c->batch * 6 : c->batch);
 }
 
@@ -804,9 +822,11 @@ int rt_dispatch_random(vgen_ctx *c, uint32_t frame, uint64_t seed, uint32_t stre
     if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = ensure_frame(c, frame)) return rc;
+    if (int rc = ensure_keys_slab(c)) return rc;
     memset(&f.start, 0, sizeof f.start);
-    const RandomStream rs{seed, stream, first_index};
-    return enqueue_keys(c, f, nullptr, nullptr, c->batch, &rs);
+    // the scalars are drawn into the frame's key buffer by a small kernel; from there on the dispatch is vgen_dispatch_keys'
+    HIP_TRY(c, launch_rnd_fill(f.d_keys, c->batch, seed, stream, first_index, f.s));
+    return enqueue_keys(c, f, f.d_keys, nullptr, c->batch);
 }
 
 int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches, uint64_t *keys_tested) {
