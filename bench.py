@@ -219,7 +219,7 @@ def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, labe
     if fmt_name == "p2tr":
         # no frozen yardstick describes the taproot path (a scalar multiplication per key over the wide-window table): its
         # roofline is the issue bound the counters name, from the measured instructions per key
-        roof = issue_roofline(rate, ("seq_fwd_kernel", "seq_inv_kernel", "seq_bwd_kernel", "p2tr_tweak_kernel", "p2tr_out_kernel"), "p2tr", "p2tr_tweak_kernel")
+        roof = issue_roofline(rate, ("seq_fwd_kernel", "seq_inv_kernel", "seq_bwd_kernel", "p2tr_finish_kernel"), "p2tr", "seq_bwd_kernel")
         if roof:
             out["chip_frac"], out["roofline"] = roof["frac"], roof
     if note:
@@ -247,12 +247,14 @@ def issue_roofline(rate_keys, kernels, pmc_mode, dominant):
             "kernel_valu_busy_alone": dom.get("valu_busy"), "kernel_simd_cycles_per_valu_instr": dom.get("simd_cycles_per_valu_instr"),
             "kernel_lone_launch_us": dom.get("lone_launch_us_under_pmc"), "kernel_l2_hit_rate": dom.get("l2_hit_rate"),
             "kernel_hbm_side_gb_per_s": dom.get("hbm_side_gb_per_s"),
-            "note": "bound named by the counters: the dominant kernel alone on the chip has VALU-busy ~1.0 (keys_fwd_kernel, p2tr_tweak_kernel: three "
-                    "waves per SIMD) while its table gathers (one 64-byte sector per window from a multi-GB table, L2 hit ~10 %) stay "
-                    "at 1-2.3 TB/s of the memory side; narrower tables that fit the 256 MB Infinity Cache are SLOWER in proportion to "
-                    "their extra additions (profiles/pmc_keys.json: keys16 / keys20 / keys24) — the gather does not bind, the "
-                    "instruction count of the mixed additions does.  FETCH_SIZE x 2 is the guide's correction for wide streaming reads; "
-                    "for these gathers the uncorrected figure (half) matches the algorithmic 64 B per window."}
+            "note": "bound named by the counters: the dominant kernel alone on the chip has VALU-busy 1.00 (keys_fwd_kernel) / 0.76 (seq_bwd_kernel<P2TR>, "
+                    "two waves per SIMD; ~0.88 with twelve frames overlapped) at 3.97-4.0 SIMD cycles per instruction, while its table gathers (one "
+                    "64-byte sector per window from a multi-GB table, L2 hit ~10 %, 2^20 DISTINCT random scalars per launch) stay at 1.2 TB/s of "
+                    "useful bytes; a table that fits the 256 MB Infinity Cache (16 bits) is slower in proportion to its extra additions "
+                    "(profiles/pmc_keys.json: keys16 / keys20 / keys24) — the gather does not bind, the instruction count of the mixed additions "
+                    "does.  frac is priced at the NOMINAL 2.4 GHz: under this multiplier-dense code (60 % v_mad_u64_u32) the chip holds ~2.07 GHz "
+                    "(GRBM_GUI_ACTIVE / launch duration), so ~0.86 is what VALU-busy 1.0 delivers.  FETCH_SIZE x 2 is the guide's correction for "
+                    "wide streaming reads; for these gathers the uncorrected figure (half) matches the algorithmic 64 B per window."}
 
 
 def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False):

@@ -105,12 +105,18 @@ struct SeqArgs {
     uint32_t match_base;       // value of mhdr->count when this dispatch was enqueued
     uint32_t match_cap;
     const uint32_t *dfa_blob;  // DEVF_DFA: the automaton (device memory), staged into LDS by the kernel
+    const uint32_t *gtab;      // P2TR: 8-bit fixed-window generator table (global memory) for the tweak multiplication
+    const uint32_t *gtab16;    // ... and the wide-window one (built on the device at first use); nullptr = use gtab
+    uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22 | 24)
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
     uint32_t reserved0;
     uint32_t endo;             // seq_bwd: test the six endomorphism / negation images of every point (kernels.hip: ENDO)
-    uint32_t *pts;             // P2TR only: the affine internal keys of the dispatch in key order, [N][16] words (x then y as
-                               // eight little-endian words each), handed to p2tr_tweak_kernel
+    // P2TR only: the tweaked points Q = P + t*G of a dispatch wait for a second shared inversion.
+    uint32_t *tq;              // [2S key steps][27][lanes]: X(Q), Z(Q), running product of the lane's Z's
+    uint32_t *tq_flag;         // [2S][lanes]: 1 = the key has an address (valid tweak, Q finite)
+    uint32_t *tree2;           // product tree / roots of the lanes' final products, laid out like tree / root
+    uint32_t *root2;
     DevSeqQ q[SEQ_MAX_S];      // per-dispatch uniform points, by value (scalar loads from the kernarg segment)
 };
 
@@ -137,7 +143,7 @@ struct KeysArgs {
     const uint32_t *dfa_blob;  // DEVF_DFA (see SeqArgs)
     uint32_t dfa_bytes;
     uint32_t groups;           // workgroups = ceil(n / KEYS_WG)
-    uint32_t *pts;             // P2TR: affine internal keys in key order, [n][16] words (written by keys_bwd_kernel<P2TR> / seq_bwd_kernel<P2TR>,
+    uint32_t *pts;             // P2TR: affine internal keys in key order, [n][16] words (written by keys_bwd_kernel<P2TR>,
                                // read by p2tr_tweak_kernel); y = 0 marks "no key"
     uint32_t *xyz;             // scratch: Jacobian results, limb-major [27][groups * KEYS_WG] (X, Y, Z limbs; the taproot stage: X, validity word, Z)
     uint32_t *tree;            // scratch: product-tree nodes [groups][9][KEYS_WG]

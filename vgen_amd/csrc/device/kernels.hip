@@ -26,8 +26,8 @@
 //     only candidate records through a wave-aggregated atomic slot counter.
 //   * The same staging (per-lane work -> product tree -> one root per lane inverted -> finish) carries the two
 //     paths that need a scalar multiplication per key: arbitrary scalars (keys_fwd / keys_bwd) and the taproot
-//     tweak (the sequential and the arbitrary-scalar path hand the affine internal keys to p2tr_tweak_kernel, which
-//     parks Q = P + t*G, and p2tr_out_kernel completes it).  Fused forms with the inversion inside one kernel were
+//     tweak (seq_bwd<P2TR> parks Q = P + t*G, p2tr_finish_kernel completes it; behind arbitrary scalars the same work
+//     runs one key per lane: p2tr_tweak_kernel / p2tr_out_kernel).  Fused forms with the inversion inside one kernel were
 //     measured first and lost a third to a half to the lone inverting wave.
 //   * One launch is ~1 wave per SIMD at the default batch, so the device is filled by frames in flight (twelve by
 //     default, one stream each: runtime.cpp); seq_bwd is capped at 128 VGPRs so that four launches share a SIMD.
@@ -51,7 +51,7 @@ namespace vg {
 constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 
 #ifndef VG_SEQ_WAVES_P2TR
-#define VG_SEQ_WAVES_P2TR 4
+#define VG_SEQ_WAVES_P2TR 2
 #endif
 #ifndef VG_SEQ_WAVES_ETH
 #define VG_SEQ_WAVES_ETH 3
@@ -250,6 +250,7 @@ seq_bwd_kernel(const SeqArgs args) {
     extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
+    const GenTables gtab{args.gtab, args.gtab16, args.gtab_bits};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache / HBM)
     u32 *dfa_lds = dyn_lds;
     if (FULL) {
         for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
@@ -306,6 +307,8 @@ seq_bwd_kernel(const SeqArgs args) {
 
     const u32 half = args.n >> 1;
     const bool dump = args.dump != nullptr;
+    fe zrun;            // P2TR: running product of this lane's Z(Q)
+    u32 step = 0;       // P2TR: key step 0 .. 2S-1 in loop order
 
 #pragma unroll 1
     for (int j = (int)S - 1; j >= 0; j--) {
@@ -356,22 +359,32 @@ seq_bwd_kernel(const SeqArgs args) {
             else
                 fe_canonicalize_product(y3);
 
-            const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (FMT == VGF_P2TR) {
-                // Taproot: this kernel only produces the affine internal key P of every key, in key order (64 bytes per key:
-                // x then y as eight words each); the tweak t*G, the addition and the shared inversion of the results are
-                // p2tr_tweak_kernel / p2tr_out_kernel's (one key per lane there: the 150-register multiplication does not share
-                // a kernel — and its occupancy — with this loop's state any more).
-                u32 xw[8], yw[8];
-                fe_to_words(x3, xw);
-                fe_to_words(y3, yw);
-                ec_u4 *o = reinterpret_cast<ec_u4 *>(args.pts + (size_t)index * 16);
-                o[0] = ec_u4{{xw[0], xw[1], xw[2], xw[3]}};
-                o[1] = ec_u4{{xw[4], xw[5], xw[6], xw[7]}};
-                o[2] = ec_u4{{yw[0], yw[1], yw[2], yw[3]}};
-                o[3] = ec_u4{{yw[4], yw[5], yw[6], yw[7]}};
+                // Taproot, stage A: the tweaked point Q = lift_x(x) + t*G stays Jacobian; X, Z and the lane's
+                // running product of Z's are parked for the second shared inversion (p2tr_finish_kernel).  [The same stage as kernels
+                // of its own — p2tr_tweak_kernel at three waves per SIMD instead of this kernel's two — measured SLOWER here
+                // (1.21 vs 1.26 Gkeys/s): the chip holds ~2.07 GHz under this multiplier-dense code whatever the occupancy, so only
+                // the instruction count matters, and one key per lane pays the workgroup's product tree per key instead of per
+                // 2S keys; that form serves the arbitrary-scalar path, which has one key per lane anyway.]
+                gej qq;
+                const bool okq = taproot_tweak_point(x3, y3, gtab, qq);
+                const bool zero = taproot_z_is_zero(qq.z);   // t*G == -P: no address; keep the products invertible
+                if (zero) fe_set_one(qq.z);
+                if (step == 0) zrun = qq.z;
+                else fe_mul(zrun, zrun, qq.z);
+                u32 *o = args.tq + (size_t)step * 27 * lanes + u;
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    o[(size_t)i * lanes] = qq.x.n[i];
+                    o[(size_t)(9 + i) * lanes] = qq.z.n[i];
+                    o[(size_t)(18 + i) * lanes] = zrun.n[i];
+                }
+                args.tq_flag[(size_t)step * lanes + u] = (okq && !zero) ? 1u : 0u;
+                step++;
                 continue;
             }
+
+            const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (ENDO) {
                 // compressed-key formats need only the parity of y (flipped for the negations); the others the canonical
                 // y itself, parked beside x, and p - y for the negations
@@ -447,20 +460,138 @@ seq_bwd_kernel(const SeqArgs args) {
         args.mhdr->clk_cycles += (u32)(clock64() - stamp_c0);
         args.mhdr->clk_ticks += (u32)(wall_clock64() - stamp_w0);
     }
+    if (FMT == VGF_P2TR) {
+        // product tree of the lanes' final products (as seq_fwd_kernel does for the denominators)
+        __syncthreads();
+        fe sib, pair;
+        shfl_xor_fe(sib, zrun, 1);
+        fe_mul(pair, zrun, sib);
+        if ((tid & 1) == 0) lds_store_fe(tree, WG, WG / 2 + (tid >> 1), pair);
+        __syncthreads();
+#pragma unroll 1
+        for (int width = WG / 4; width >= 1; width >>= 1) {
+            if (tid < width) {
+                const int k = width + tid;
+                fe a, b, p;
+                lds_load_fe(tree, WG, 2 * k, a);
+                lds_load_fe(tree, WG, 2 * k + 1, b);
+                fe_mul(p, a, b);
+                lds_store_fe(tree, WG, k, p);
+            }
+            __syncthreads();
+        }
+        u32 *t2 = args.tree2 + (size_t)blockIdx.x * 9 * WG;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t2[i * WG + tid] = tree[i * WG + tid];
+        if (tid < 9) args.root2[(size_t)tid * args.groups + blockIdx.x] = tree[tid * WG + 1];
+    }
 }
 
-// ---- taproot: tweak, shared inversion, output key -------------------------------------------------------------------------
+// ---- taproot, stage C: second shared inversion walked back, x(Q), filter ---------------------------------------
+//
+// After seq_bwd_kernel<P2TR> (stage A) and seq_inv_kernel on root2: every lane recovers 1/(product of its 2S
+// Z's) from the tree, then peels 1/Z of each key step off it in reverse order (two multiplications per key, as
+// seq_bwd does for the denominators), x(Q) = X / Z^2, and the usual dump / prefilter / DFA output.
+template <bool FULL>
+__global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
+    __shared__ u32 tree[9 * WG];
+    extern __shared__ u32 dfa_lds[];
+    const int tid = threadIdx.x;
+    if (FULL)
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
+    const u32 S = args.s, lanes = args.lanes;
+    const u32 u = blockIdx.x * WG + tid;
+    const u32 steps = 2 * S;
+
+    const u32 *t2 = args.tree2 + (size_t)blockIdx.x * 9 * WG;
+#pragma unroll
+    for (int i = 0; i < 9; i++) tree[i * WG + tid] = t2[i * WG + tid];
+    __syncthreads();
+    if (tid < 9) tree[tid * WG + 1] = args.root2[(size_t)tid * args.groups + blockIdx.x];   // root^-1
+    __syncthreads();
+#pragma unroll 1
+    for (int width = 1; width <= WG / 4; width <<= 1) {
+        if (tid < width) {
+            const int k = width + tid;
+            fe ik, a, b, ia, ib;
+            lds_load_fe(tree, WG, k, ik);
+            lds_load_fe(tree, WG, 2 * k, a);
+            lds_load_fe(tree, WG, 2 * k + 1, b);
+            fe_mul(ia, ik, b);
+            fe_mul(ib, ik, a);
+            lds_store_fe(tree, WG, 2 * k, ia);
+            lds_store_fe(tree, WG, 2 * k + 1, ib);
+        }
+        __syncthreads();
+    }
+    fe inv;   // 1 / (product of this lane's Z's up to the step being peeled)
+    {
+        fe ip, sib;
+        lds_load_fe(tree, WG, WG / 2 + (tid >> 1), ip);
+#pragma unroll
+        for (int i = 0; i < 9; i++) sib.n[i] = args.tq[((size_t)(steps - 1) * 27 + 18 + i) * lanes + (u ^ 1u)];
+        fe_mul(inv, ip, sib);
+    }
+    const u32 half = args.n >> 1;
+    const bool dump = args.dump != nullptr;
+#pragma unroll 1
+    for (int step = (int)steps - 1; step >= 0; step--) {
+        const u32 *in = args.tq + (size_t)step * 27 * lanes + u;
+        fe X, Z, zi;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            X.n[i] = in[(size_t)i * lanes];
+            Z.n[i] = in[(size_t)(9 + i) * lanes];
+        }
+        if (step > 0) {
+            fe pprev;   // the lane's running product up to the previous step
+            const u32 *prev = args.tq + (size_t)(step - 1) * 27 * lanes + u;
+#pragma unroll
+            for (int i = 0; i < 9; i++) pprev.n[i] = prev[(size_t)(18 + i) * lanes];
+            fe_mul(zi, inv, pprev);
+            fe_mul(inv, inv, Z);
+        } else {
+            zi = inv;
+        }
+        gej qq;
+        qq.x = X;
+        u32 xw[8], pl[8];
+        taproot_affine_x(qq, zi, xw);
+#pragma unroll
+        for (int i = 0; i < 8; i++) pl[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
+        const bool ok = args.tq_flag[(size_t)step * lanes + u] != 0;
+
+        // stage A walks j = S-1 .. 0 and, within j, +R then -R
+        const u32 j = S - 1 - ((u32)step >> 1), sgn = (u32)step & 1u;
+        const u32 index = sgn ? (half - (u + 1) * S + j) : (half + u * S + j);
+        if (dump) {
+            u32 *o = args.dump + (size_t)index * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
+        } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
+            const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+            if (slot < args.match_cap) {
+                DevMatch *m = args.mrec + slot;
+                m->index = index;
+                m->reserved = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) m->payload[i] = pl[i];
+            }
+        }
+    }
+}
+
+// ---- taproot behind the arbitrary-scalar path: tweak, shared inversion, output key -----------------------------------------
 //
 // What the reference leaves to the HOST for every key of a P2TR batch (XOnlyPublicKey::from_slice + Address::p2tr,
-// src/gpu.rs:1287-1291, "CPU bound by design" src/shaders/search_p2tr.wgsl:112).  Both scan paths hand over the affine
+// src/gpu.rs:1287-1291, "CPU bound by design" src/shaders/search_p2tr.wgsl:112).  keys_bwd_kernel<P2TR> hands over the affine
 // internal keys P in key order (`pts`, 64 bytes per key; y = 0 marks "no key"), then:
 //   p2tr_tweak_kernel  one key per lane: t = TapTweak(x(P)), Q = lift_x(P) + t*G over the wide-window table (core/taproot.h);
 //                      X(Q), Z(Q) and a validity word are parked, the Z's of the workgroup go into a product tree, its root out;
 //   seq_inv_kernel     the roots of all workgroups, one per lane;
 //   p2tr_out_kernel    tree down-sweep, 1/Z per lane, x(Q) = X / Z^2, the usual dump / prefilter / DFA output.
-// Exactly the staging of keys_fwd / keys_bwd — the multiplication is the same code with the same ~145 registers, so it runs
-// at three waves per SIMD with the VALU busy, where round 2's seq_bwd_kernel<P2TR> carried it inside the sequential loop
-// at 255 registers, two waves per SIMD and VALU-busy 0.76 (profiles/pmc_keys.json).
+// Exactly the staging of keys_fwd / keys_bwd (round 2 finished this path inside keys_bwd_kernel with one lane inverting for its
+// whole workgroup).  The sequential path keeps the tweak inside seq_bwd_kernel<P2TR> (see there): fewer instructions per key.
 
 // Product tree over the KEYS_WG lanes of a workgroup (leaf pairs by lane shuffle), tree and root written out.
 __device__ __forceinline__ void keys_tree_up(u32 *tree, const fe &z, u32 *tree_out, u32 *root, u32 groups) {
@@ -1148,9 +1279,16 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
     const bool full = a.dfa_bytes && !a.dump;
     if (full && a.dfa_bytes > DFA_MAX_BYTES) return hipErrorInvalidValue;
     if (FMT == VGF_P2TR) {
-        // this kernel parks the affine internal keys; runtime.cpp follows it with launch_p2tr_tweak
-        if (!a.pts) return hipErrorInvalidValue;
+        // stage A (tweaked points parked) -> second root inversion -> stage C (finish + filter)
+        if (!a.gtab || !a.tq || !a.tq_flag || !a.tree2 || !a.root2) return hipErrorInvalidValue;
         hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(seq_inv_kernel, dim3((a.groups + 63) / 64), dim3(64), 0, stream, a.root2, a.groups);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (full) hipLaunchKernelGGL((p2tr_finish_kernel<true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
+        else hipLaunchKernelGGL((p2tr_finish_kernel<false>), dim3(a.groups), dim3(WG), 0, stream, a);
         return hipGetLastError();
     }
     if (full && a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), true, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);

@@ -40,10 +40,16 @@ size_t scratch_words(const vgen_ctx *c) {
     return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
 }
 
-// P2TR (the taproot stage behind either scan path, one key per lane, G = ceil(batch / 256) workgroups):
+// P2TR: tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
+size_t p2tr_words(const vgen_ctx *c) {
+    if (c->format != VGF_P2TR) return 0;
+    return (size_t)2 * c->S * 27 * c->lanes + (size_t)2 * c->S * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
+}
+
+// P2TR behind the arbitrary-scalar path (one key per lane, G = ceil(batch / 256) workgroups), part of the keys slab:
 //   pts [batch][16] | xz [27][G * 256] | tree [G][9][256] | root [9][G]
 size_t p2tr_groups(const vgen_ctx *c) { return ((size_t)c->batch + KEYS_WG - 1) / KEYS_WG; }
-size_t p2tr_words(const vgen_ctx *c) {
+size_t p2tr_stage_words(const vgen_ctx *c) {
     if (c->format != VGF_P2TR) return 0;
     const size_t g = p2tr_groups(c);
     return (size_t)c->batch * 16 + (size_t)27 * g * KEYS_WG + g * 9 * KEYS_WG + (size_t)9 * g;
@@ -616,15 +622,15 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
     return VGEN_OK;
 }
 
-// The taproot stage of frame f for n keys whose internal keys the preceding kernels parked in the frame's `pts`: output /
-// filter fields as the dispatch has them (`proto`), scratch from the frame's P2TR slice.
+// The taproot stage of the arbitrary-scalar path on frame f, for n keys whose internal keys keys_bwd_kernel<P2TR> parked in the
+// frame's `pts`: output / filter fields as the dispatch has them (`proto`), scratch from the frame's slice of the keys slab.
 int enqueue_p2tr_stage(vgen_ctx *c, vgen_ctx::Frame &f, const KeysArgs &proto, uint32_t n) {
     KeysArgs t = proto;
     const size_t g = p2tr_groups(c);
     t.keys_be = nullptr;
     t.n = n;
     t.groups = (n + KEYS_WG - 1) / KEYS_WG;
-    t.pts = f.d_p2tr_scratch;
+    t.pts = f.d_keys_p2tr;
     t.xyz = t.pts + (size_t)c->batch * 16;
     t.tree = t.xyz + (size_t)27 * g * KEYS_WG;
     t.root = t.tree + g * 9 * KEYS_WG;
@@ -642,10 +648,13 @@ int ensure_keys_slab(vgen_ctx *c) {
     const uint32_t max_groups = (c->batch + KEYS_WG - 1) / KEYS_WG;
     const size_t keys_b = up256((size_t)c->batch * 32);
     const size_t scratch_b = up256(((size_t)27 * max_groups * KEYS_WG + (size_t)max_groups * 9 * KEYS_WG + (size_t)9 * max_groups) * sizeof(uint32_t));
-    HIP_TRY(c, hipMalloc((void **)&c->d_keys_slab, (keys_b + scratch_b) * c->frames));
+    const size_t stage_b = up256(p2tr_stage_words(c) * sizeof(uint32_t));   // taproot contexts: internal keys + the stage's own scratch
+    const size_t per = keys_b + scratch_b + stage_b;
+    HIP_TRY(c, hipMalloc((void **)&c->d_keys_slab, per * c->frames));
     for (uint32_t i = 0; i < c->frames; i++) {
-        c->fr[i].d_keys = c->d_keys_slab + (keys_b + scratch_b) * i;
-        c->fr[i].d_keys_scratch = reinterpret_cast<uint32_t *>(c->d_keys_slab + (keys_b + scratch_b) * i + keys_b);
+        c->fr[i].d_keys = c->d_keys_slab + per * i;
+        c->fr[i].d_keys_scratch = reinterpret_cast<uint32_t *>(c->d_keys_slab + per * i + keys_b);
+        c->fr[i].d_keys_p2tr = stage_b ? reinterpret_cast<uint32_t *>(c->d_keys_slab + per * i + keys_b + scratch_b) : nullptr;
     }
     return VGEN_OK;
 }
@@ -689,7 +698,7 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
             a.dfa_bytes = c->h_filter.dfa_bytes;
         }
     }
-    if (c->format == VGF_P2TR) a.pts = f.d_p2tr_scratch;   // keys_bwd_kernel<P2TR> parks the affine internal keys there
+    if (c->format == VGF_P2TR) a.pts = f.d_keys_p2tr;   // keys_bwd_kernel<P2TR> parks the affine internal keys there
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s));
     HIP_TRY(c, launch_keys_scan((int)c->format, a, f.s, c->timing ? f.ev_mid : nullptr));
     if (c->format == VGF_P2TR)
@@ -768,33 +777,25 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     const bool parks_y = c->format == VGF_P2PKH_UNCOMPRESSED || c->format == VGF_ETHEREUM;
     const bool endo_now = c->endo && !(a.dfa_bytes && parks_y && a.dfa_bytes + 2u * 9u * SEQ_WG * 4u > 64u * 1024u);
     a.endo = endo_now ? 1u : 0u;
-    if (c->format == VGF_P2TR) {   // the taproot stage multiplies t*G over the fixed-window table (built at first use) ...
+    if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
         if (int rc = ensure_gtab(c, true)) return rc;
-        a.pts = f.d_p2tr_scratch;  // ... and seq_bwd_kernel<P2TR> hands it the affine internal keys in key order
+        a.gtab = c->d_gtab;
+        a.gtab16 = c->d_gtab16;
+        a.gtab_bits = c->gtab_bits;
+        // ... and the tweaked points of the dispatch wait in scratch for their shared inversion:
+        // tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
+        const size_t tq_words = (size_t)2 * S * 27 * c->lanes, flag_words = (size_t)2 * S * c->lanes;
+        const size_t tree_words = (size_t)c->groups * 9 * SEQ_WG;
+        a.tq = f.d_p2tr_scratch;
+        a.tq_flag = a.tq + tq_words;
+        a.tree2 = a.tq_flag + flag_words;
+        a.root2 = a.tree2 + tree_words;
     }
     // the whole chain (seq_fwd -> seq_inv -> seq_bwd [-> P2TR stages] -> result copy) on the frame's own stream
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_start, f.s));
     HIP_TRY(c, launch_seq_fwd(a, f.s));
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_mid, f.s));
     HIP_TRY(c, launch_seq_bwd((int)c->format, a, f.s));
-    if (c->format == VGF_P2TR) {
-        // tweak, second shared inversion and output keys: the same stage the arbitrary-scalar path ends with
-        KeysArgs t;
-        memset(&t, 0, sizeof t);
-        t.gtab = c->d_gtab;
-        t.gtab16 = c->d_gtab16;
-        t.gtab_bits = c->gtab_bits;
-        t.filter = c->d_filter;
-        t.dump = a.dump;
-        t.mhdr = a.mhdr;
-        t.mrec = a.mrec;
-        t.match_base = a.match_base;
-        t.match_cap = a.match_cap;
-        t.fmt = c->format;
-        t.dfa_blob = a.dfa_blob;
-        t.dfa_bytes = a.dfa_bytes;
-        if (int rc = enqueue_p2tr_stage(c, f, t, c->batch)) return rc;
-    }
     return finish_dispatch(c, f, dump, endo_now ? (uint64_t)c->batch * 6 : c->batch);
 }
 

@@ -49,7 +49,8 @@ struct vgen_ctx {
         uint8_t *h_dump = nullptr;       // dump mode: pinned mirror, filled by the dispatch's own async copy
         uint8_t *d_keys = nullptr;       // explicit keys of vgen_dispatch_keys (slice of d_keys_slab)
         uint32_t *d_keys_scratch = nullptr;   // arbitrary-scalar path: Jacobian results | tree | roots (slice of d_keys_slab)
-        uint32_t *d_p2tr_scratch = nullptr;   // P2TR: tweaked points | flags | second tree | second roots (slice of d_slab)
+        uint32_t *d_p2tr_scratch = nullptr;   // P2TR, sequential path: tweaked points | flags | second tree | second roots (slice of d_slab)
+        uint32_t *d_keys_p2tr = nullptr;      // P2TR, arbitrary-scalar path: internal keys | X, Z | tree | roots of the taproot stage (slice of d_keys_slab)
         uint64_t keys_tested = 0;
         uint32_t *d_scratch = nullptr;   // pre | tree | root | arrive (device_types.h / kernels.hip)
         uint32_t match_base = 0;         // candidate counter value when the last dispatch was enqueued
