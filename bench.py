@@ -8,9 +8,10 @@ base points in the kernel arguments).  A "step" is one dispatch of the hot path 
 dispatches are kept in flight the way the reference's scan loop keeps 2 (src/gpu.rs:399) — 12 here, every frame on
 a stream with a hardware queue of its own (three priority pools of four queues: no GPU_MAX_HW_QUEUES involved),
 because one launch of the per-key kernel is only one wave per SIMD and a dispatch is a chain of dependent launches.
-For N>1 (python -m torch.distributed.run ... bench.py --gpus N) every rank drives its own GPU over batch-striped
-disjoint scalar ranges — no data-path collective; torch.distributed only provides the barriers and the
-max-over-ranks of the elapsed time.
+For N>1 every rank drives its own GPU over batch-striped disjoint scalar ranges — no data-path collective;
+torch.distributed only provides the barriers and the max-over-ranks of the elapsed time.  `--gpus N` IS the number of
+ranks: under a launcher (python -m torch.distributed.run ... bench.py --gpus N) WORLD_SIZE must agree with it; without
+one, `python bench.py --gpus N` starts its N ranks itself, as a child process, before anything here touches HIP.
 
 The JSON line: `value` is measured over EXACTLY --steps dispatches between two barrier+synchronize brackets (the
 contract).  Because a short region is mostly pipeline fill and drain (20 steps = 2 ms), the same loop is also run

@@ -508,7 +508,7 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
         if (int rc = upload(c, c->d_dfa, f->dfa_blob.data(), f->dfa_blob.size() * 4)) return rc;
         c->h_filter.dfa_blob = c->d_dfa;
     }
-    // (uploads are waited for: the other stage streams do not synchronise with the one that carried them)
+    // (uploads are waited for: the other frames' streams do not synchronise with the one that carried them)
     if (int rc = upload(c, c->d_filter, &c->h_filter, sizeof(DevFilter))) return rc;
     c->have_filter = true;
     if (dump_mode(c)) return ensure_dump_slab(c);
@@ -546,7 +546,7 @@ int wait_done(vgen_ctx *c, vgen_ctx::Frame &f) {
     return VGEN_OK;
 }
 
-// What follows the last kernel of a dispatch on the frame's bwd stream: the copy of the results and the event
+// What follows the last kernel of a dispatch on the frame's stream: the copy of the results and the event
 // vgen_wait waits on.
 int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys) {
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.s));
@@ -659,7 +659,7 @@ int ensure_keys_slab(vgen_ctx *c) {
     return VGEN_OK;
 }
 
-// Enqueues the arbitrary-scalar kernels on frame f (its bwd stream carries the whole chain): explicit keys
+// Enqueues the arbitrary-scalar kernels on frame f (its stream carries the whole chain): explicit keys
 // (keys_dev != nullptr) or base + i.
 int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
     // worth the wide table: taproot contexts (their sequential path builds it anyway) and real arbitrary-scalar batches

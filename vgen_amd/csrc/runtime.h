@@ -118,7 +118,7 @@ inline bool rt_oversubscribed(const vgen_ctx *c) { return c->frames > c->prio_le
 int rt_device_count(int *n, std::string &err);
 int rt_device_name(int device, std::string &name, std::string &err);
 int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err);
-// Starts (once) a helper thread that creates the stage streams no frame has used yet; rt_frame_ready tells without
+// Starts (once) a helper thread that creates the frame streams no frame has used yet; rt_frame_ready tells without
 // blocking whether `frame` could be dispatched to without creating a stream first.  Used by the scan loop to grow its
 // pipeline as queues become available instead of stalling ~8 ms per frame.  false: not supported for this stream kind.
 bool rt_prepare_streams(vgen_ctx *ctx);
