@@ -1093,3 +1093,32 @@ def test_frames_on_every_stream_priority_level_make_progress_beside_a_competitor
         assert blob[20 * i:20 * i + 20] == vo.payload(0, k0 + i)
     a.close()
     b.close()
+
+
+def test_dump_mode_pins_a_bounded_amount_of_host_memory(vg, vo):
+    """Dump mode mirrors every payload of a dispatch in pinned host memory; an endomorphism context dumps six images per key,
+    so at the CLI's defaults (2^20 keys, 12 frames) all frames together would pin 1.5 GB (24 GB at 2^24 keys per dispatch).
+    The context therefore gives dump buffers to as many frames as fit ~1 GiB, never fewer than two: the other frames refuse a
+    dump-mode dispatch with a state error naming the limit, filter-mode dispatches use all frames as before, and a scan that
+    falls back to host filtering keeps to the frames that have buffers."""
+    batch = 1 << 20
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=12, endo=True)
+    r.set_filter(None)
+    k0 = vo.seed_key(3, 3)
+    r.dispatch(k0, 0)
+    r.dispatch(k0 + batch, 7)                       # 8 frames x 6 x 2^20 x 20 B = 1.0 GB: frames 0..7 have buffers
+    with pytest.raises(vg.VgenError) as e:
+        r.dispatch(k0 + 2 * batch, 8)
+    assert e.value.status == -5 and "dump mode serves frames 0..7" in str(e.value)
+    blob, _, tested = r.await_result(0)
+    assert tested == 6 * batch and blob[:20 * 4096] == vo.payload_seq(0, k0, 4096)
+    r.await_result(7)
+    r.set_filter(vg.Pattern("^1Cat", False, vg.AddressFormat.P2pkh))
+    for f in (8, 11):                                # filter mode: every frame
+        r.dispatch(k0, f)
+        r.wait(f)
+    res = vg.scan_gpu_with_runner("^1[2-9A-Za-z]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=50), r)   # host filtering of full dumps
+    assert len(res.matches) == 50
+    for m in res.matches[:10]:
+        assert vo.generate(0, int(m.hex, 16))["address"] == m.address
+    r.close()
