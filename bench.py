@@ -258,13 +258,13 @@ def issue_roofline(rate_keys, kernels, pmc_mode, dominant):
                     "wide streaming reads; for these gathers the uncorrected figure (half) matches the algorithmic 64 B per window."}
 
 
-def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False):
+def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, endo=False):
     """Arbitrary-scalar (KEYS) mode: the 'random 256-bit scalar' reading of north_star — a full fixed-base
     multiplication per key.  random_stream: the scalars are drawn on the device from the counter-based stream
     (vgen_dispatch_random: nothing uploaded); otherwise 32 B/key are uploaded by every dispatch (vgen_dispatch_keys)."""
     import random
     fmt = vg.AddressFormat.P2pkh
-    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False)
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False, endo=endo)
     r.set_filter(vg.Pattern("^1Cat", False, fmt))
     if random_stream:
         ctr = [0]
@@ -298,9 +298,17 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False):
         fw = (fw + 1) % frames
     dt = time.perf_counter() - t0
     r.close()
-    rate = issued * batch / dt
-    roof = issue_roofline(rate, ("keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel"), "random" if random_stream else "keys", "keys_fwd_kernel") \
-        or (issue_roofline(rate, ("keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel"), "keys", "keys_fwd_kernel") if random_stream else None)
+    rate = issued * batch * (6 if endo else 1) / dt
+    kernels = ("rnd_fill_kernel", "keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel") if random_stream else ("keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel")
+    # (the counter passes are of the one-key-per-draw kernels: per multiplication, i.e. per draw, also for the six-image form)
+    roof = None if endo else issue_roofline(rate, kernels, "random" if random_stream else "keys", "keys_fwd_kernel")
+    if endo:
+        return {"config": "independent random draws on an endomorphism context (VGEN_FLAG_ENDO): six keys per draw — k, lambda k, lambda^2 k and their negations",
+                "format": "p2pkh", "pattern": "^1Cat", "value": round(rate / 1e6, 1), "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": issued,
+                "draws_per_sec_M": round(rate / 6e6, 1), "chip_frac": None,
+                "note": "vgen_dispatch_random on an endomorphism context (`vgen-hip generate --random-keys`): every scalar multiplication serves six keys "
+                        "(keys_bwd_kernel<FMT, FULL, ENDO> hashes the six images); keys per second = 6 x draws per second; the draws themselves run at the "
+                        "issue-bound rate of the entry above minus the five extra hash pairs per draw"}
     return {"config": ("independent random keys drawn on the device (vgen_dispatch_random), P2PKH '^1Cat'" if random_stream
                        else "arbitrary-scalar (KEYS) mode, uploaded scalars (vgen_dispatch_keys), P2PKH '^1Cat'"),
             "format": "p2pkh", "pattern": "^1Cat",
@@ -678,6 +686,7 @@ def main():
                   "unanchored pattern as a vanity search (VGEN_FLAG_ENDO): on-device Base58Check + DFA on six images per point", endo=True)
         oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec)
         oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec, random_stream=True)
+        oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec, random_stream=True, endo=True)
         oc += leg(dump_mode_configs, vg, args.batch, local_rank, sec)
         out["other_configs"] = oc
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -58,7 +58,9 @@ typedef enum vgen_format {
                                  one batch_size of point arithmetic (every format but P2TR, which runs as without the flag; with a
                                  prefilter pattern, an on-device DFA pattern or in dump mode).  The keys tested are NOT a contiguous range:
                                  vgen_scan refuses start / end / seed on such a context.  vgen_wait reports keys_tested
-                                 = 6 x batch_size and match indices variant * batch_size + i (vgen_key_variant). */
+                                 = 6 x batch_size and match indices variant * batch_size + i (vgen_key_variant).  The
+                                 arbitrary-scalar dispatches (vgen_dispatch_keys, vgen_dispatch_random) test the six images of
+                                 every scalar's point in the same way (keys_tested = 6 x n, same index convention). */
 #define VGEN_FLAG_TIMING 1u   /* record HIP events around every dispatch so that vgen_frame_kernel_ms /
                                  vgen_frame_dispatch_ms report durations (bench.py); without it a dispatch is
                                  three kernels and one copy, and the host loop is ~10 us per step cheaper */
@@ -294,9 +296,12 @@ typedef struct vgen_scan_config {
 #define VGEN_SCAN_RANDOM_KEYS 1u   /* scan_with_progress's shape (src/scanner.rs:118-169): every candidate an independent random key
                                       (vgen_dispatch_random: batch b tests candidates b * batch_size .. of stream `shard` under
                                       `seed`; seed 0 = OS entropy) instead of the reference GPU path's walk from one base key.
-                                      A full scalar multiplication per key: ~6x slower than the walk.  No start / end /
-                                      checkpoint; not on VGEN_FLAG_ENDO contexts.  With a fixed seed the matches are those of
-                                      the oracle's scan_random walk of the same stream, in the same order. */
+                                      A full scalar multiplication per key: ~10x slower than the walk.  No start / end /
+                                      checkpoint.  With a fixed seed (and without VGEN_FLAG_ENDO) the matches are those of
+                                      the oracle's scan_random walk of the same stream, in the same order.  On a VGEN_FLAG_ENDO
+                                      context every draw is tested as six keys (the candidate and its lambda / negation images,
+                                      one multiplication for the six: 5.3 instead of 1.25 Gkeys/s); seeds and shards keep their
+                                      meaning there (they name streams of candidates, not ranges). */
 
 /* GeneratedAddress (src/address.rs:63-72). */
 typedef struct vgen_generated {

@@ -277,6 +277,20 @@ static void sc_random_keys() {
     vo_scan_free(&o);
     vgen_scan_result_free(&r);
     vgen_destroy(c);
+    // three striped contexts, shard i walking stream i; and endomorphism contexts (six keys per draw): every match re-derives
+    for (uint32_t flags : {0u, (uint32_t)VGEN_FLAG_ENDO}) {
+        vgen_ctx *cs[3] = {make_ctx(0, 2, 0, flags), make_ctx(0, 2, 0, flags), make_ctx(0, 2, 0, flags)};
+        cfg.count = 9;
+        rc = vgen_scan_multi(cs, 3, "^1A", &cfg, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_OK && r.n_matches == 9, "multi random (flags %u) rc=%d n=%llu", flags, rc, (unsigned long long)r.n_matches);
+        for (uint64_t i = 0; i < r.n_matches; i++) {
+            vo_generated g;
+            CHECK(vo_generate(0, r.matches[i].key, &g) && !strcmp(g.address, r.matches[i].address), "multi random match %llu", (unsigned long long)i);
+            for (uint64_t j = 0; j < i; j++) CHECK(memcmp(r.matches[i].key, r.matches[j].key, 32) != 0, "duplicate key %llu/%llu", (unsigned long long)i, (unsigned long long)j);
+        }
+        vgen_scan_result_free(&r);
+        for (auto *x : cs) vgen_destroy(x);
+    }
 }
 
 static void sc_endo_and_formats() {

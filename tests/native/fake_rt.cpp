@@ -110,6 +110,41 @@ void emit_key(FakeCtx *c, FakeFrame &ff, bool dump, uint32_t index, const Scalar
     emit(c, ff, dump, index, pl, ok);
 }
 
+// a key of the arbitrary-scalar path: itself, or (endomorphism contexts) its six images at variant * batch + i — one
+// multiplication, then (beta^e x, +-y) as the kernels do
+void emit_images(FakeCtx *c, FakeFrame &ff, bool dump, uint32_t i, const Scalar &k, bool endo) {
+    if (!endo) {
+        emit_key(c, ff, dump, i, k);
+        return;
+    }
+    ge pt;
+    const bool ok = scalar_is_valid(k) && host_ec_mul_gen(k, pt);
+    fe x = pt.x, y = pt.y, beta;
+    if (ok) {
+        fe_normalize(x);
+        fe_normalize(y);
+    }
+    set_beta(beta);
+    for (uint32_t e = 0; e < 3; e++) {
+        if (ok && e) {
+            fe_mul(x, x, beta);
+            fe_normalize(x);
+        }
+        for (uint32_t sgn = 0; sgn < 2; sgn++) {
+            u32 pl[8] = {0};
+            if (ok) {
+                fe yy = y;
+                if (sgn) {
+                    fe_neg(yy, y, 1);
+                    fe_normalize(yy);
+                }
+                payload_words(c->format, x, yy, pl);
+            }
+            emit(c, ff, dump, (sgn * 3 + e) * c->batch + i, pl, ok);
+        }
+    }
+}
+
 // the sequential walk k0 + i: one mixed addition per key, affine conversion in chunks sharing an inversion
 void walk(FakeCtx *c, FakeFrame &ff, bool dump, Scalar k0, bool endo) {
     const uint32_t N = c->batch;
@@ -169,7 +204,7 @@ void walk(FakeCtx *c, FakeFrame &ff, bool dump, Scalar k0, bool endo) {
     }
 }
 
-int start_dispatch(FakeCtx *c, uint32_t frame, uint64_t keys, std::function<void(FakeFrame &, bool)> body) {
+int start_dispatch(FakeCtx *c, uint32_t frame, uint64_t keys, std::function<void(FakeFrame &, bool)> body, bool endo = false) {
     vgen_ctx::Frame &f = c->fr[frame];
     FakeFrame &ff = c->ff[frame];
     const bool dump = dump_mode(c);
@@ -177,13 +212,13 @@ int start_dispatch(FakeCtx *c, uint32_t frame, uint64_t keys, std::function<void
         return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
     ff.found.clear();
     if (dump) {
-        ff.dump.assign((size_t)std::max<uint64_t>(keys, c->batch) * c->payload_words * 4, 0);
+        ff.dump.assign((size_t)c->batch * (endo || keys > c->batch ? 6 : 1) * c->payload_words * 4, 0);
         if (!c->dump_frames) c->dump_frames = c->frames;
     }
     f.in_flight = true;
     f.dumped = dump;
     f.keys_tested = keys;
-    f.endo_applied = keys > c->batch;
+    f.endo_applied = endo || keys > c->batch;
     ff.worker = std::thread([body, &ff, dump]() { body(ff, dump); });
     return VGEN_OK;
 }
@@ -352,13 +387,14 @@ int rt_dispatch_keys(vgen_ctx *c0, uint32_t frame, const uint8_t *keys_be, uint3
     if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");
     if (int rc = ensure_frame(c, frame)) return rc;
     std::vector<uint8_t> keys(keys_be, keys_be + (size_t)n * 32);
-    return start_dispatch(c, frame, n, [c, keys, n](FakeFrame &ff, bool dump) {
+    const bool endo = c->endo;
+    return start_dispatch(c, frame, endo ? (uint64_t)n * 6 : n, [c, keys, n, endo](FakeFrame &ff, bool dump) {
         for (uint32_t i = 0; i < n; i++) {
             Scalar k;
             scalar_from_be(k, keys.data() + (size_t)i * 32);
-            emit_key(c, ff, dump, i, k);
+            emit_images(c, ff, dump, i, k, endo);
         }
-    });
+    }, endo);
 }
 
 int rt_dispatch_random(vgen_ctx *c0, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
@@ -368,14 +404,15 @@ int rt_dispatch_random(vgen_ctx *c0, uint32_t frame, uint64_t seed, uint32_t str
     if (c->fr[frame].in_flight) return c->fail(VGEN_E_STATE, "frame already has a dispatch in flight");
     if (c->injected_fault()) return c->fail(VGEN_E_HIP, "injected device failure (vgen_debug_fail_after)");
     if (int rc = ensure_frame(c, frame)) return rc;
-    return start_dispatch(c, frame, c->batch, [c, seed, stream, first_index](FakeFrame &ff, bool dump) {
+    const bool endo = c->endo;
+    return start_dispatch(c, frame, endo ? (uint64_t)c->batch * 6 : c->batch, [c, seed, stream, first_index, endo](FakeFrame &ff, bool dump) {
         for (uint32_t i = 0; i < c->batch; i++) {
             Scalar k;
             const uint64_t idx = first_index + i;
             rnd_scalar((uint32_t)seed, (uint32_t)(seed >> 32), stream, (uint32_t)idx, (uint32_t)(idx >> 32), k.w);
-            emit_key(c, ff, dump, i, k);
+            emit_images(c, ff, dump, i, k, endo);
         }
-    });
+    }, endo);
 }
 
 int rt_wait(vgen_ctx *c0, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches, uint64_t *keys_tested) {

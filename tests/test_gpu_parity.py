@@ -84,6 +84,21 @@ def test_dump_full_size_dispatch_p2pkh(vg, vo):
     r.close()
 
 
+@pytest.mark.parametrize("fmt", [2, 3, 4, 5])
+def test_dump_full_size_dispatch_other_formats(vg, vo, fmt):
+    """BASELINE's dispatch size for the formats whose payload is not the plain hash160 of the compressed key (P2WPKH shares
+    P2PKH's): all 2^20 payloads of one dispatch — P2SH-P2WPKH, the taproot output key, P2PKH-uncompressed, Ethereum — byte-equal
+    to the oracle's."""
+    batch = 1 << 20
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=2)
+    start = vo.seed_key(42, fmt)
+    got = dump(r, start)
+    ref = vo.payload_seq(fmt, start, batch)
+    assert len(got) == len(ref) == batch * (32 if fmt == 3 else 20)
+    assert hashlib.sha256(got).digest() == hashlib.sha256(ref).digest()
+    r.close()
+
+
 def test_both_frames_and_repeat_are_consistent(vg, vo):
     batch = 32768
     r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=4)
@@ -305,12 +320,21 @@ def test_cli_generate_and_range(vg, vo, tmp_path):
     assert out.returncode != 0 and "no CPU" in out.stderr
     # --random-keys: an independent random key per candidate, drawn on the device (the reference CPU path's shape); with a
     # seed the first matches are the oracle's scan_random walk of stream 0
-    out = subprocess.run([exe, "generate", "-p", "^1Ab", "--random-keys", "--seed", "42", "-c", "3", "-o", "jsonl",
+    out = subprocess.run([exe, "generate", "-p", "^1Ab", "--random-keys", "--no-endo", "--seed", "42", "-c", "3", "-o", "jsonl",
                           "--gpu-batch-size", "16384", "-q"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got = [json.loads(l) for l in out.stdout.strip().splitlines()]
     ref = vo.scan_random(0, "^1Ab", 42, count=3, threads=1)["matches"]
     assert [(g["address"], g["wif"]) for g in got] == [(x["address"], x["wif"]) for x in ref]
+    # ... and by default six keys per draw (the candidate and its endomorphism / negation images): any keys will do for a vanity search
+    out = subprocess.run([exe, "generate", "-p", "^1Ab", "--random-keys", "-c", "4", "-o", "jsonl", "--gpu-batch-size", "16384", "-q"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [json.loads(l) for l in out.stdout.strip().splitlines()]
+    assert len(got) == 4 and all(g["operations"] % (6 * 16384) == 0 for g in got)
+    for g in got:
+        o = vo.generate(0, int(g["private_key_hex"], 16))
+        assert g["address"].startswith("1Ab") and (o["address"], o["wif"]) == (g["address"], g["wif"])
     # provider pattern: address + key range from the static table / a table file (provider.rs, lib.rs:599-631)
     out = subprocess.run([exe, "range", "-p", "boha:b1000:1", "-o", "minimal", "--gpu-batch-size", "8192"],
                          capture_output=True, text=True, timeout=300)
@@ -1122,3 +1146,63 @@ def test_dump_mode_pins_a_bounded_amount_of_host_memory(vg, vo):
     for m in res.matches[:10]:
         assert vo.generate(0, int(m.hex, 16))["address"] == m.address
     r.close()
+
+
+def test_random_keys_on_an_endomorphism_context_test_six_keys_per_draw(vg, vo):
+    """On a VGEN_FLAG_ENDO context the arbitrary-scalar path hashes the six images of every point too
+    (keys_bwd_kernel<FMT, FULL, ENDO>): a draw k of the candidate stream is tested as k, lambda k, lambda^2 k and their negations,
+    image v of candidate i at index v * batch + i.  Every entry of such a dump against the oracle's payload of exactly that key;
+    filter mode against the oracle's regex over the dump; seeded scans against an oracle-side enumeration in index order."""
+    batch = 8192
+    for fmt in (0, 5, 4, 2):
+        r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=2, endo=True, match_cap=32768)
+        r.set_filter(None)
+        r.dispatch_random(11, fmt, 5 * batch, 0)
+        blob, _, tested = r.await_result(0)
+        assert tested == 6 * batch and len(blob) == 6 * batch * 20
+        lanes = range(batch) if fmt == 0 else list(range(0, batch, 131)) + [batch - 1]
+        for v in range(6):
+            for i in lanes:
+                k = vo.random_key(11, fmt, 5 * batch + i)
+                assert blob[20 * (v * batch + i):20 * (v * batch + i) + 20] == vo.payload(fmt, variant_key(k, v)), (fmt, v, i)
+        if fmt == 0:
+            # explicit scalars, fewer than a batch, one of them invalid: images at v * batch + i, nothing for the invalid one
+            keys = [5, N - 7, 0, 2**200 + 1, vo.seed_key(1, 1)]
+            r.dispatch_keys(keys, 1)
+            blob2, _, tested2 = r.await_result(1)
+            assert tested2 == 6 * len(keys)
+            for v in range(6):
+                for i, k in enumerate(keys):
+                    want = vo.payload(0, variant_key(k, v)) if 0 < k < N else bytes(20)
+                    assert blob2[20 * (v * batch + i):20 * (v * batch + i) + 20] == want, (v, i)
+            # filter mode = the oracle's regex over the dump
+            pat = vg.Pattern("^1[A-F]", False, vg.AddressFormat.P2pkh)
+            r.set_filter(pat)
+            r.dispatch_random(11, fmt, 5 * batch, 1)
+            recs, n, _ = r.await_result(1)
+            ore = vo.Regex("^1[A-F]", False)
+            want = [i for i in range(6 * batch) if ore.matches(vo.address_from_hash160(0, blob[20 * i:20 * i + 20]))]
+            assert n == len(recs) <= r.match_cap and [i for i, pl in recs if ore.matches(vo.address_from_hash160(0, pl))] == want and len(want) > 300
+            # a seeded random-key scan: the first matches in (batch, index) order, keys re-derived through variant + stream
+            res = vg.scan_gpu_with_runner("^1[A-F]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=40, seed=11, random_keys=True), r)
+            blob0 = None
+            r.set_filter(None)
+            r.dispatch_random(11, 0, 0, 0)
+            blob0, _, _ = r.await_result(0)
+            exp = [i for i in range(6 * batch) if ore.matches(vo.address_from_hash160(0, blob0[20 * i:20 * i + 20]))][:40]
+            assert len(exp) == 40 and res.operations == 6 * batch
+            assert [int(m.hex, 16) for m in res.matches] == [variant_key(vo.random_key(11, 0, i % batch), i // batch) for i in exp]
+            for m in res.matches[:8]:
+                g = vo.generate(0, int(m.hex, 16))
+                assert (g["address"], g["wif"]) == (m.address, m.wif)
+        r.close()
+    # two contexts: shard i walks stream i (never the same candidates twice)
+    rs = [vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2, endo=True) for _ in range(2)]
+    res = vg.scan_gpu_with_runner("^1Ab", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=12, seed=5, random_keys=True), rs)
+    keys = [int(m.hex, 16) for m in res.matches]
+    assert len(keys) == 12 and len(set(keys)) == 12
+    streams = set()
+    for k in keys:
+        assert vo.generate(0, k)["address"].startswith("1Ab")
+    for r in rs:
+        r.close()

@@ -153,7 +153,8 @@ void usage() {
             "                    [--no-endo]           (unseeded searches, any format but P2TR, test six keys per curve\n"
             "                                           point — k, lambda k, lambda^2 k and their negations; this walks k0 + i only)\n"
             "                    [--random-keys]       (an independent random key per candidate, drawn on the device — the shape of\n"
-            "                                           the reference's CPU path, src/scanner.rs:118-169; ~8x slower than the walk)\n"
+            "                                           the reference's CPU path, src/scanner.rs:118-169 —, six keys per draw unless\n"
+            "                                           --no-endo; ~3x slower than the walk)\n"
             "                    PATTERN may be a provider pattern boha:b1000:N [-l PREFIX_LENGTH] [--provider-table CSV]\n"
             "  vgen-hip range (--range START:END | --puzzle P) [-p PATTERN] [-f FORMAT] [-c COUNT (0 = whole range)] ...\n"
             "  vgen-hip estimate -p PATTERN [-f FORMAT] [-i]\n"
@@ -343,7 +344,8 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         p.frames = o.frames;
         // a vanity search proper — random base, no range, no seed, no checkpoint — may test any keys it likes:
         // six images per curve point (VGEN_FLAG_ENDO, +30 % keys per second); everything else walks k0 + i
-        if (!o.no_endo && !o.random_keys && !has_range && !o.seed && o.checkpoint.empty() && fmt != 3) p.flags |= VGEN_FLAG_ENDO;
+        // (--random-keys: six keys per draw; seeds name candidate streams there, so they do not rule it out)
+        if (!o.no_endo && fmt != 3 && (o.random_keys || (!has_range && !o.seed && o.checkpoint.empty()))) p.flags |= VGEN_FLAG_ENDO;
         vgen_ctx *c = nullptr;
         if (vgen_create(&p, &c) != VGEN_OK) die(std::string("GPU initialization failed: ") + vgen_last_error(nullptr));
         ctxs.push_back(c);

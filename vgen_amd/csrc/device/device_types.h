@@ -143,6 +143,8 @@ struct KeysArgs {
     const uint32_t *dfa_blob;  // DEVF_DFA (see SeqArgs)
     uint32_t dfa_bytes;
     uint32_t groups;           // workgroups = ceil(n / KEYS_WG)
+    uint32_t endo;             // keys_bwd: test the six endomorphism / negation images of every point (kernels.hip: ENDO) ...
+    uint32_t vstride;          // ... image `variant` of key i is reported / dumped at variant * vstride + i (= the context's batch size)
     uint32_t *pts;             // P2TR: affine internal keys in key order, [n][16] words (written by keys_bwd_kernel<P2TR>,
                                // read by p2tr_tweak_kernel); y = 0 marks "no key"
     uint32_t *xyz;             // scratch: Jacobian results, limb-major [27][groups * KEYS_WG] (X, Y, Z limbs; the taproot stage: X, validity word, Z)

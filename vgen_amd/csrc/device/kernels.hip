@@ -888,9 +888,13 @@ __global__ void __launch_bounds__(KEYS_WG) keys_fwd_kernel(const KeysArgs args) 
     if (tid < 9) args.root[(size_t)tid * args.groups + blockIdx.x] = tree[tid * KEYS_WG + 1];
 }
 
-template <int FMT, bool FULL>
+// ENDO (endomorphism contexts; every format but P2TR): the six images of every point, as seq_bwd_kernel<FMT, FULL, ENDO> tests them
+// — six keys hashed for one scalar multiplication (k, lambda k, lambda^2 k and their negations; image `variant` of key i is
+// reported / dumped at variant * vstride + i, vstride = the context's batch size).
+template <int FMT, bool FULL, bool ENDO = false>
 __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) {
     __shared__ u32 tree[9 * KEYS_WG];
+    __shared__ u32 ypark[ENDO && (FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM) ? 9 * KEYS_WG : 1];   // ENDO: the point's y
     extern __shared__ u32 dfa_lds[];    // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
     const int tid = threadIdx.x;
@@ -956,6 +960,59 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
         o[3] = valid ? ec_u4{{yw[4], yw[5], yw[6], yw[7]}} : ec_u4{{0u, 0u, 0u, 0u}};
         return;
     }
+    if (ENDO) {
+        // (every lane has read its pair's inverse from the tree before the multiplications above; after this barrier the tree's
+        //  LDS parks the x of the point in hand, as in seq_bwd_kernel)
+        constexpr bool NEEDS_Y = FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM;
+        __syncthreads();
+        const u32 ypar = y.n[0] & 1u;
+        lds_park_fe(tree, KEYS_WG, tid, x);
+        if (NEEDS_Y) lds_park_fe(ypark, KEYS_WG, tid, y);
+        const bool live = valid && idx < args.n;
+#pragma unroll 1
+        for (u32 v = 0; v < 6; v++) {
+            const u32 e = v >> 1, sneg = v & 1u;   // (x,+) (x,-) (bx,+) (bx,-) (b^2 x,+) (b^2 x,-)
+            fe xe, ye;
+            lds_unpark_fe(tree, KEYS_WG, tid, xe);
+            if (sneg == 0 && e > 0) {
+                fe beta;
+                fe_set_beta(beta);
+                fe_mul(xe, xe, beta);
+                fe_canonicalize_product(xe);
+                lds_park_fe(tree, KEYS_WG, tid, xe);
+            }
+            if (NEEDS_Y) {
+                lds_unpark_fe(ypark, KEYS_WG, tid, ye);
+                if (sneg) {
+                    fe ny;
+                    fe_neg(ny, ye, 1);
+                    fe_normalize(ny);      // p - y, canonical (y != 0 on this curve)
+                    ye = ny;
+                }
+            } else {
+                ye.n[0] = ypar ^ sneg;     // all a compressed key reads of y
+            }
+            u32 ple[NW];
+            (void)payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(xe, ye, ple);
+            if (idx >= args.n) continue;
+            const u32 vindex = (sneg * 3u + e) * args.vstride + idx;
+            if (args.dump) {
+                u32 *o = args.dump + (size_t)vindex * NW;
+#pragma unroll
+                for (int i = 0; i < NW; i++) o[i] = live ? ple[i] : 0u;
+            } else if (live && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple))) {
+                const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+                if (slot < args.match_cap) {
+                    DevMatch *m = args.mrec + slot;
+                    m->index = vindex;
+                    m->reserved = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? ple[i] : 0u;
+                }
+            }
+        }
+        return;
+    }
     u32 pl[NW];
     const bool ok = payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(x, y, pl) && valid;
 
@@ -994,7 +1051,10 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEven
         hipLaunchKernelGGL((keys_bwd_kernel<FMT, false>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
         return hipGetLastError();   // (runtime.cpp follows with launch_p2tr_tweak over the frame's taproot scratch)
     }
-    if (full) hipLaunchKernelGGL((keys_bwd_kernel<FMT, true>), dim3(a.groups), dim3(KEYS_WG), a.dfa_bytes, stream, a);
+    constexpr int F = FMT == VGF_P2TR ? VGF_P2PKH : FMT;   // (P2TR returned above: keeps its ENDO instantiations out of the binary)
+    if (a.endo && full) hipLaunchKernelGGL((keys_bwd_kernel<F, true, true>), dim3(a.groups), dim3(KEYS_WG), a.dfa_bytes, stream, a);
+    else if (a.endo) hipLaunchKernelGGL((keys_bwd_kernel<F, false, true>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
+    else if (full) hipLaunchKernelGGL((keys_bwd_kernel<FMT, true>), dim3(a.groups), dim3(KEYS_WG), a.dfa_bytes, stream, a);
     else hipLaunchKernelGGL((keys_bwd_kernel<FMT, false>), dim3(a.groups), dim3(KEYS_WG), 0, stream, a);
     return hipGetLastError();
 }

@@ -548,17 +548,19 @@ int wait_done(vgen_ctx *c, vgen_ctx::Frame &f) {
 
 // What follows the last kernel of a dispatch on the frame's stream: the copy of the results and the event
 // vgen_wait waits on.
-int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys) {
+int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys, bool endo) {
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_stop, f.s));
+    // payload slots of the dump: batch, or — six images per key, image v of key i at v * batch + i — 6 x batch
+    f.dump_slots = (uint64_t)c->batch * (endo ? 6 : 1);
     if (dump)
-        HIP_TRY(c, hipMemcpyAsync(f.h_dump, f.d_dump, (size_t)std::max<uint64_t>(keys, c->batch) * c->payload_words * sizeof(uint32_t), hipMemcpyDeviceToHost, f.s));
+        HIP_TRY(c, hipMemcpyAsync(f.h_dump, f.d_dump, (size_t)f.dump_slots * c->payload_words * sizeof(uint32_t), hipMemcpyDeviceToHost, f.s));
     else
         HIP_TRY(c, hipMemcpyAsync(f.h_match, f.d_match, match_bytes(FIRST_COPY), hipMemcpyDeviceToHost, f.s));
     if (!frame_owns_stream(c)) HIP_TRY(c, hipEventRecord(f.ev_done, f.s));
     f.in_flight = true;
     f.dumped = dump;
     f.keys_tested = keys;
-    f.endo_applied = keys > c->batch;
+    f.endo_applied = endo;
     return VGEN_OK;
 }
 
@@ -683,10 +685,16 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     a.tree = a.xyz + (size_t)27 * max_groups * KEYS_WG;
     a.root = a.tree + (size_t)max_groups * 9 * KEYS_WG;
     const bool dump = dump_mode(c);
+    if (c->h_filter.kind == DEVF_DFA && !dump) a.dfa_bytes = c->h_filter.dfa_bytes;
+    // endomorphism contexts: six images per scalar multiplication here too (see rt_dispatch for the LDS rule)
+    const bool parks_y = c->format == VGF_P2PKH_UNCOMPRESSED || c->format == VGF_ETHEREUM;
+    const bool endo_now = c->endo && !(a.dfa_bytes && parks_y && a.dfa_bytes + 2u * 9u * KEYS_WG * 4u > 64u * 1024u);
+    a.endo = endo_now ? 1u : 0u;
+    a.vstride = c->batch;
     if (dump) {
         if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
         if (!f.d_dump) return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
-        if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * c->payload_words * sizeof(uint32_t), f.s));
+        if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * (endo_now ? 6 : 1) * c->payload_words * sizeof(uint32_t), f.s));
         a.dump = f.d_dump;
     } else {
         a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);
@@ -703,7 +711,7 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     HIP_TRY(c, launch_keys_scan((int)c->format, a, f.s, c->timing ? f.ev_mid : nullptr));
     if (c->format == VGF_P2TR)
         if (int rc = enqueue_p2tr_stage(c, f, a, n)) return rc;
-    return finish_dispatch(c, f, dump, n);
+    return finish_dispatch(c, f, dump, endo_now ? (uint64_t)n * 6 : n, endo_now);
 }
 
 }  // namespace
@@ -796,7 +804,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     HIP_TRY(c, launch_seq_fwd(a, f.s));
     if (c->timing) HIP_TRY(c, hipEventRecord(f.ev_mid, f.s));
     HIP_TRY(c, launch_seq_bwd((int)c->format, a, f.s));
-    return finish_dispatch(c, f, dump, endo_now ? (uint64_t)c->batch * 6 : c->batch);
+    return finish_dispatch(c, f, dump, endo_now ? (uint64_t)c->batch * 6 : c->batch, endo_now);
 }
 
 int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32_t n) {
@@ -905,7 +913,7 @@ int rt_dump_view(vgen_ctx *c, uint32_t frame, const uint8_t **ptr, size_t *len) 
     if (f.in_flight) return c->fail(VGEN_E_STATE, "vgen_read_dump before vgen_wait");
     if (!f.dumped || !f.h_dump) return c->fail(VGEN_E_STATE, "frame's last dispatch was not in dump mode");
     *ptr = f.h_dump;
-    if (len) *len = (size_t)std::max<uint64_t>(f.keys_tested, c->batch) * c->payload_words * sizeof(uint32_t);
+    if (len) *len = (size_t)f.dump_slots * c->payload_words * sizeof(uint32_t);
     return VGEN_OK;
 }
 

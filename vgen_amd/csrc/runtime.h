@@ -52,6 +52,7 @@ struct vgen_ctx {
         uint32_t *d_p2tr_scratch = nullptr;   // P2TR, sequential path: tweaked points | flags | second tree | second roots (slice of d_slab)
         uint32_t *d_keys_p2tr = nullptr;      // P2TR, arbitrary-scalar path: internal keys | X, Z | tree | roots of the taproot stage (slice of d_keys_slab)
         uint64_t keys_tested = 0;
+        uint64_t dump_slots = 0;         // payload slots of the last dispatch's dump: batch, or 6 x batch on an endomorphism context
         uint32_t *d_scratch = nullptr;   // pre | tree | root | arrive (device_types.h / kernels.hip)
         uint32_t match_base = 0;         // candidate counter value when the last dispatch was enqueued
         uint8_t *d_match = nullptr;      // DevMatchHeader followed by match_cap DevMatch

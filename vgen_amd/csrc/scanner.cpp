@@ -362,13 +362,14 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                std::vector<vgen_generated> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
                bool *range_done = nullptr, SlotProgress *slot = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
-    if (ctx->endo && (cfg->has_start || cfg->has_end || cfg->seed || cfg->n_shards > 1 || cfg->checkpoint_path))
+    const bool random_keys = (cfg->flags & VGEN_SCAN_RANDOM_KEYS) != 0;
+    if (ctx->endo && !random_keys && (cfg->has_start || cfg->has_end || cfg->seed || cfg->n_shards > 1 || cfg->checkpoint_path))
         return ctx->fail(VGEN_E_INVALID, "a VGEN_FLAG_ENDO context tests six images of every point, not a contiguous key range: "
                                          "it serves unseeded random scans only (no start / end / seed / shards / checkpoint)");
-    const bool random_keys = (cfg->flags & VGEN_SCAN_RANDOM_KEYS) != 0;
-    if (random_keys && (ctx->endo || cfg->has_start || cfg->has_end || cfg->checkpoint_path))
-        return ctx->fail(VGEN_E_INVALID, "VGEN_SCAN_RANDOM_KEYS draws an independent key per candidate: no start / end / checkpoint, "
-                                         "and not on a VGEN_FLAG_ENDO context");
+    // (random keys on an endomorphism context: six keys per draw — the candidate and its lambda / negation images; seeds and
+    //  shards keep their meaning there, they name streams of candidates, not ranges)
+    if (random_keys && (cfg->has_start || cfg->has_end || cfg->checkpoint_path))
+        return ctx->fail(VGEN_E_INVALID, "VGEN_SCAN_RANDOM_KEYS draws an independent key per candidate: no start / end / checkpoint");
 
     const uint32_t N = ctx->batch;
     const size_t pbytes = (size_t)ctx->payload_words * 4;
@@ -787,17 +788,21 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     // own (disjoint with overwhelming probability, SURVEY.md 8(e) "random mode"), sharing the match counter.
     bool endo = false;
     for (uint32_t i = 0; i < n_ctx; i++) endo = endo || ctxs[i]->endo;
+    const bool random_keys = (cfg->flags & VGEN_SCAN_RANDOM_KEYS) != 0;
     if (endo) {
         for (uint32_t i = 0; i < n_ctx; i++)
             if (!ctxs[i]->endo) return ctxs[0]->fail(VGEN_E_INVALID, "vgen_scan_multi: VGEN_FLAG_ENDO must be set on all contexts or on none");
-        if (cfg->has_start || cfg->has_end || cfg->seed || cfg->checkpoint_path)
+        if (!random_keys && (cfg->has_start || cfg->has_end || cfg->seed || cfg->checkpoint_path))
             return ctxs[0]->fail(VGEN_E_INVALID, "VGEN_FLAG_ENDO contexts serve unseeded random scans only (no start / end / seed / checkpoint)");
     }
+    // the walk of an endomorphism context starts from a random base of its own per device; random-key scans stripe by
+    // stream (shard i walks stream i) whatever the context
+    const bool own_bases = endo && !random_keys;   // no slots to stripe or adopt: every context walks from its own random base
     if (cfg->checkpoint_path) {
         int rc = open_checkpoint(ctxs[0], ck, pattern, base, ctxs[0]->batch, n_ctx, 0, n_ctx);
         if (rc != VGEN_OK) return rc;
         ckp = &ck;
-    } else if (!endo) {
+    } else if (!own_bases && !random_keys) {
         resolve_base(base);   // all shards must walk the same base key
     }
     std::atomic<uint64_t> found{0}, ops_shared{0};
@@ -836,13 +841,13 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
             uint32_t slot = i;
             for (;;) {
                 vgen_scan_config c = base;
-                c.shard = endo ? 0 : slot;
-                c.n_shards = endo ? 0 : n_ctx;
+                c.shard = own_bases ? 0 : slot;
+                c.n_shards = own_bases ? 0 : n_ctx;
                 bool rd = false;
                 std::vector<vgen_generated> got;
                 uint64_t o = 0;
                 const int rc = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
-                                          got, o, ckp, slot, &rd, endo ? nullptr : &progress[slot]);
+                                          got, o, ckp, slot, &rd, own_bases ? nullptr : &progress[slot]);
                 std::unique_lock<std::mutex> lk(q_mu);
                 part[slot].insert(part[slot].end(), got.begin(), got.end());
                 ops[slot] += o;
@@ -852,7 +857,7 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
                     rcs[i] = rc;
                     failed_ctx++;
                     running--;
-                    if (!endo) orphans.push_back(slot);
+                    if (!own_bases) orphans.push_back(slot);
                     q_cv.notify_all();
                     return;
                 }
@@ -883,7 +888,7 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     // still handing over everything the committed batches found.
     bool uncovered = false;
     for (uint32_t i = 0; i < n_ctx && !skip_all; i++) uncovered = uncovered || !slot_finished[i];
-    const bool absorbed = first_err != VGEN_OK && (!uncovered || scan_over() || endo) && failed_ctx < n_ctx;
+    const bool absorbed = first_err != VGEN_OK && (!uncovered || scan_over() || own_bases) && failed_ctx < n_ctx;
     if (ckp) {
         std::lock_guard<std::mutex> g(ck.mu);
         ck.complete = ck.complete || all_done;
