@@ -301,11 +301,13 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, en
     rate = issued * batch * (6 if endo else 1) / dt
     kernels = ("rnd_fill_kernel", "keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel") if random_stream else ("keys_fwd_kernel", "keys_bwd_kernel", "seq_inv_kernel")
     # (the counter passes are of the one-key-per-draw kernels: per multiplication, i.e. per draw, also for the six-image form)
-    roof = None if endo else issue_roofline(rate, kernels, "random" if random_stream else "keys", "keys_fwd_kernel")
+    # (counters are per launch of 2^20 draws: the six-image form is priced per DRAW — keys per second / 6 x instructions per draw)
+    roof = issue_roofline(rate / 6, kernels, "random_endo", "keys_fwd_kernel") if endo else \
+        issue_roofline(rate, kernels, "random" if random_stream else "keys", "keys_fwd_kernel")
     if endo:
         return {"config": "independent random draws on an endomorphism context (VGEN_FLAG_ENDO): six keys per draw — k, lambda k, lambda^2 k and their negations",
                 "format": "p2pkh", "pattern": "^1Cat", "value": round(rate / 1e6, 1), "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": issued,
-                "draws_per_sec_M": round(rate / 6e6, 1), "chip_frac": None,
+                "draws_per_sec_M": round(rate / 6e6, 1), "chip_frac": roof["frac"] if roof else None, "roofline": roof,
                 "note": "vgen_dispatch_random on an endomorphism context (`vgen-hip generate --random-keys`): every scalar multiplication serves six keys "
                         "(keys_bwd_kernel<FMT, FULL, ENDO> hashes the six images); keys per second = 6 x draws per second; the draws themselves run at the "
                         "issue-bound rate of the entry above minus the five extra hash pairs per draw"}
@@ -335,6 +337,10 @@ def dump_mode_configs(vg, batch, device, seconds):
             "format": "p2pkh", "pattern": None, "value": round(n * batch / dt / 1e6, 1), "unit": "Mkeys/sec",
             "seconds": round(dt, 2), "dispatches": n,
             "pcie_gb_per_s": round(n * batch * 20 / dt / 1e9, 1),
+            "chip_frac": round(n * batch * 20 / dt / 64e9, 4),
+            "roofline": {"bound": "pcie", "achieved": round(n * batch * 20 / dt / 1e9, 1), "peak": 64.0, "unit": "GB/s",
+                         "frac": round(n * batch * 20 / dt / 64e9, 4), "traffic": batch * 20,
+                         "note": "PCIe 5.0 x16 device-to-host, 64 GB/s per direction nominal; the kernels of this dispatch take 0.13 ms, the copy 0.38 ms"},
             "note": "bound by the 20 B/key device-to-host copy, not by the kernels"}]
     # a pattern too permissive for the default match ring (1 key in ~64 matches): the scan grows the ring and stays on
     # the device filter; the host only encodes and confirms the candidates

@@ -69,3 +69,30 @@ for fmt in (0, 1, 2, 4, 5):
         runs3 += 1; keys3 += 6 * batch
     r.close()
 print("endomorphism soak ok: %d dispatches, %d keys (image 0 in full, 300 sampled images per dispatch), %.0f s" % (runs3, keys3, time.time() - t1))
+
+# fourth phase: the random-key stream (vgen_dispatch_random), one key per draw and six per draw, random seeds / streams / indices
+t1 = time.time()
+runs4 = keys4 = 0
+for fmt, endo in ((0, False), (0, True), (5, True), (3, False), (2, False), (4, True)):
+    batch = 8192
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=2, endo=endo)
+    r.set_filter(None)
+    pl = 32 if fmt == 3 else 20
+    t2 = time.time()
+    while time.time() - t2 < budget / 12:
+        seed, stream = rng.getrandbits(64), rng.getrandbits(32)
+        first = rng.choice([0, rng.getrandbits(64) % (2**64 - batch), 2**64 - batch, rng.getrandbits(20)])
+        r.dispatch_random(seed, stream, first, 0)
+        blob, _, tested = r.await_result(0)
+        assert tested == (6 if endo and fmt != 3 else 1) * batch
+        for _ in range(400):
+            i = rng.randrange(batch)
+            k = vo.random_key(seed, stream, first + i)
+            v = rng.randrange(6) if endo and fmt != 3 else 0
+            kv = pow(LAM, v % 3, N) * k % N
+            kv = N - kv if v >= 3 else kv
+            want = vo.payload(fmt, kv) if 0 < k < N else bytes(pl)
+            assert blob[pl * (v * batch + i):pl * (v * batch + i) + pl] == want, (fmt, endo, seed, stream, first, v, i)
+        runs4 += 1; keys4 += tested
+    r.close()
+print("random-key soak ok: %d dispatches, %d keys (400 sampled per dispatch), %.0f s" % (runs4, keys4, time.time() - t1))
