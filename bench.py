@@ -317,9 +317,9 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, en
             "value": round(rate / 1e6, 1), "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": issued,
             "chip_frac": roof["frac"] if roof else None, "roofline": roof,
             "note": ("the reference CPU loop's shape (rng.fill per candidate, src/scanner.rs:144-152): 2^20 independent scalars per dispatch "
-                     "from the counter-based stream SHA-256('vgen-mi355x-rand' || seed || stream || index), a full k*G each over the 22-bit "
-                     "window table (11 mixed additions); nothing is uploaded" if random_stream else
-                     "2^20 independent scalars per dispatch, a full k*G each over the 22-bit window table (11 mixed additions); includes the "
+                     "from the counter-based stream SHA-256('vgen-mi355x-rand' || seed || stream || index), a full k*G each over the 24-bit "
+                     "window table (10 mixed additions); nothing is uploaded" if random_stream else
+                     "2^20 independent scalars per dispatch, a full k*G each over the 24-bit window table (10 mixed additions); includes the "
                      "32 MB host-to-device upload of every dispatch")}
 
 

@@ -300,7 +300,7 @@ typedef struct vgen_scan_config {
                                       checkpoint.  With a fixed seed (and without VGEN_FLAG_ENDO) the matches are those of
                                       the oracle's scan_random walk of the same stream, in the same order.  On a VGEN_FLAG_ENDO
                                       context every draw is tested as six keys (the candidate and its lambda / negation images,
-                                      one multiplication for the six: 5.3 instead of 1.25 Gkeys/s); seeds and shards keep their
+                                      one multiplication for the six: 5.5 instead of 1.35 Gkeys/s); seeds and shards keep their
                                       meaning there (they name streams of candidates, not ranges). */
 
 /* GeneratedAddress (src/address.rs:63-72). */

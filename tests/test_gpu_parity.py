@@ -708,7 +708,7 @@ def test_permissive_pattern_grows_the_match_ring_instead_of_dumping(vg, vo):
     r.close()
 
 
-@pytest.mark.parametrize("bits", [8, 16, 20, 22, 24])
+@pytest.mark.parametrize("bits", [8, 16, 20, 22, 24, 26])
 def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypatch):
     """The arbitrary-scalar and taproot paths multiply through a fixed-window table of VGEN_GTAB_BITS-bit windows
     (8: the host-built 653 KB table; 16 / 20 / 22 / 24: built on the device from it, every entry as the sum of two

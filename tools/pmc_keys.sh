@@ -1,6 +1,6 @@
 # Counter passes for the paths that do a scalar multiplication per key (run on the GPU box from the repo root):
 #   keys  (vgen_dispatch_keys: keys_fwd_kernel / keys_bwd_kernel), p2tr (seq_bwd_kernel<P2TR> / p2tr_finish_kernel),
-#   random (vgen_dispatch_random, when built), at the default 22-bit generator table and, for the gather question, at 16 / 20 bits.
+#   random (vgen_dispatch_random, when built), at the default 24-bit generator table and, for the gather question, at 16 / 20 / 22 / 26 bits.
 # Each pass is its own rocprofv3 run (--pmc with --kernel-trace only; the program directly after `--`).
 # Output: gpurun_out/<tag>/pmc_keys.json  (copy to profiles/pmc_keys.json, which bench.py reads)
 TAG=${1:-pmc_keys}
@@ -25,7 +25,7 @@ for m in $MODES; do
   run ${m}_wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VALU -- $m
 done
 # the gather question (2^20 distinct random scalars per launch: the random-stream mode): the same KEYS kernel over tables that fit the 256 MB Infinity Cache (16 bits: 67 MB) or not (20: 872 MB; 24: 11.8 GB)
-for bits in 16 20 24; do
+for bits in 16 20 22 26; do
   export VGEN_GTAB_BITS=$bits
   run keys${bits}_sq $SQ -- random
   run keys${bits}_fetch FETCH_SIZE -- random

@@ -7,6 +7,7 @@ import glob
 import json
 import os
 import re
+import statistics
 import sys
 from collections import defaultdict
 
@@ -28,8 +29,9 @@ def counters(root):
                 names[row["Dispatch_Id"]] = short(row["Kernel_Name"])
         for (d, c), v in per.items():
             acc[names[d]][c].append(v)
-    # the first launch of a kernel includes cold caches / table build effects: average the later ones when there are several
-    return {k: {c: (sum(v[1:]) / len(v[1:]) if len(v) > 2 else sum(v) / len(v)) for c, v in cs.items()} for k, cs in acc.items()}
+    # the MEDIAN over the launches: the first one includes cold caches / table build effects, and now and then a launch is
+    # held up for milliseconds by something else on the box
+    return {k: {c: statistics.median(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
 def durations(root):
@@ -38,7 +40,7 @@ def durations(root):
         with open(path) as f:
             for row in csv.DictReader(f):
                 acc[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-    return {k: round(sum(v[1:]) / len(v[1:]) if len(v) > 2 else sum(v) / len(v), 2) for k, v in acc.items()}
+    return {k: round(statistics.median(v), 2) for k, v in acc.items()}
 
 
 def summarize(root, mode):
@@ -84,7 +86,7 @@ def main(root):
            "how": "rocprofv3 --kernel-trace --pmc, one pass per counter group (tools/pmc_keys.sh), frames = 1, kernels serialised; "
                   "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x 32); bytes = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, "
                   "uncalibrated for 16-byte-per-lane gathers of 64-byte sectors (ratios between table widths are what to read)"}
-    for mode in ("keys", "random", "random_endo", "p2tr", "keys16", "keys20", "keys24"):
+    for mode in ("keys", "random", "random_endo", "p2tr", "keys16", "keys20", "keys22", "keys24", "keys26"):
         if os.path.isdir(os.path.join(root, f"{mode}_sq")):
             res[mode] = summarize(root, mode)
     if os.path.exists(os.path.join(root, "failed.txt")):

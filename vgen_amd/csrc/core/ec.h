@@ -283,7 +283,7 @@ VG_HD void ec_mul_gen_w8(gej &acc, const u32 k[8], const u32 *tab8) { ec_mul_gen
 // Wide windows: WB = 16 .. 24 bits, NW = ceil(256 / WB) windows x (2^WB - 1) entries x 64 bytes (x then y as eight
 // little-endian 32-bit words each: one 64-byte sector per entry, four 16-byte loads), built on the device
 // (kernels.hip: gen_table_wide_kernel) and gathered through the L2 / Infinity Cache / HBM.  NW - 1 additions instead
-// of the 31 of the 8-bit form (16 bits: 15 additions, 67 MB; 20 bits: 12 additions, 872 MB; 22 bits: 11, 3.2 GB; 24 bits: 10, 11.8 GB);
+// of the 31 of the 8-bit form (16 bits: 15 additions, 67 MB; 20 bits: 12 additions, 872 MB; 22 bits: 11, 3.2 GB; 24 bits: 10, 11.8 GB; 26 bits: 9, 43 GB);
 // the limb conversion of a table point (two fe_from_words) is 4 % of an addition.
 VG_HD constexpr u32 ec_wide_windows(u32 wb) { return (256u + wb - 1u) / wb; }
 VG_HD constexpr u64 ec_wide_entries(u32 wb) { return (u64)ec_wide_windows(wb) * ((1ull << wb) - 1ull); }
@@ -298,7 +298,7 @@ VG_HD u32 ec_wide_digit(const u32 k[8], u32 w, u32 wb) {
 
 template <int WB>
 VG_HD void ec_mul_gen_wide(gej &acc, const u32 k[8], const u32 *tab) {
-    static_assert(WB >= 9 && WB <= 24, "window width");
+    static_assert(WB >= 9 && WB <= 26, "window width");
     constexpr u32 NW = ec_wide_windows(WB);
     constexpr u64 NE = (1ull << WB) - 1ull;
     gej_set_infinity(acc);
@@ -338,6 +338,7 @@ VG_HD void ec_mul_gen_tables(gej &acc, const u32 k[8], const GenTables &g) {
     else if (g.wide && g.wide_bits == 20) ec_mul_gen_wide<20>(acc, k, g.wide);
     else if (g.wide && g.wide_bits == 22) ec_mul_gen_wide<22>(acc, k, g.wide);
     else if (g.wide && g.wide_bits == 24) ec_mul_gen_wide<24>(acc, k, g.wide);
+    else if (g.wide && g.wide_bits == 26) ec_mul_gen_wide<26>(acc, k, g.wide);
     else ec_mul_gen_w8(acc, k, g.w8);
 }
 

@@ -1218,7 +1218,7 @@ __global__ void __launch_bounds__(256) gen_table_combine_kernel(const u32 *small
 
 // tab: the wide table (ec_wide_words(bits) words); small: scratch for the half-width table (ec_wide_words(bits / 2) words).
 hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 *small, u32 bits, hipStream_t stream) {
-    if (bits != 16 && bits != 20 && bits != 22 && bits != 24) return hipErrorInvalidValue;
+    if (bits != 16 && bits != 20 && bits != 22 && bits != 24 && bits != 26) return hipErrorInvalidValue;
     const u32 h = bits / 2;
     const unsigned long long small_entries = ec_wide_entries(h);
     hipLaunchKernelGGL(gen_table_wide_kernel, dim3((unsigned)((small_entries + 255) / 256)), dim3(256), 0, stream, tab8, small, h, small_entries);

@@ -586,17 +586,18 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
         }
         lap("upload");
     }
-    // The wide-window table, built on the device from the 8-bit one, once per context: 22-bit windows by default (12
-    // windows, 11 additions per multiplication instead of the 8-bit table's 31; 3.2 GB of the 288 GB).  Every entry is
-    // the affine sum of two entries of a table of half the width, eight entries per lane sharing an inversion
-    // (gen_table_combine_kernel): 20 bits build in 2.6 ms, 22 in ~10, 24 in 31 (one-level build: 40 / 150 ms / -).
-    // Measured, KEYS mode Mkeys/s: 8 bits 576, 16 bits (67 MB) 1014, 20 bits (872 MB) 1205, 22 bits 1272, 24 bits
-    // (11.8 GB, whose first hipMalloc in a process takes 0.6 s) 1359.  VGEN_GTAB_BITS = 8 | 16 | 20 | 22 | 24 selects.
+    // The wide-window table, built on the device from the 8-bit one, once per context: 24-bit windows by default (11 windows,
+    // 10 additions per multiplication instead of the 8-bit table's 31; 11.8 GB of the 288 GB).  Every entry is the affine sum
+    // of two entries of a table of half the width, eight entries per lane sharing an inversion (gen_table_combine_kernel).
+    // Measured in round 3 (profiles/r03_gtab26.txt; random-key mode Mkeys/s, build incl. allocation): 22 bits (3.2 GB) 1272,
+    // 6 ms; 24 bits 1362, 19 ms; 26 bits (43 GB, 9 additions) 1451, but its first hipMalloc takes ~1 s and the gathers begin
+    // to show (VALU-busy 0.97).  The paths are issue-bound (profiles/pmc_keys.json), so the rate follows the additions saved.
+    // VGEN_GTAB_BITS = 8 | 16 | 20 | 22 | 24 | 26 selects.
     if (wide && !c->d_gtab16 && !c->gtab_wide_failed) {
-        const uint32_t bits = env_u32("VGEN_GTAB_BITS", 22);
+        const uint32_t bits = env_u32("VGEN_GTAB_BITS", 24);
         if (bits == 8) {
             c->gtab_wide_failed = true;   // (asked for: nothing to build)
-        } else if (bits == 16 || bits == 20 || bits == 22 || bits == 24) {
+        } else if (bits == 16 || bits == 20 || bits == 22 || bits == 24 || bits == 26) {
             uint32_t *wide_tab = nullptr, *small = nullptr;   // small: the half-width table the wide one is combined from
             hipError_t e = hipMalloc((void **)&wide_tab, (size_t)ec_wide_words(bits) * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_wide_words(bits / 2) * sizeof(uint32_t));
@@ -618,7 +619,7 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
                 c->gtab_bits = bits;
             }
         } else {
-            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22 or 24");
+            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22, 24 or 26");
         }
     }
     return VGEN_OK;
