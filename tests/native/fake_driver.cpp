@@ -276,6 +276,15 @@ static void sc_random_keys() {
         CHECK(!strcmp(r.matches[i].address, o.matches[i].gen.address) && !memcmp(r.matches[i].key, o.matches[i].key, 32), "random match %zu", i);
     vo_scan_free(&o);
     vgen_scan_result_free(&r);
+    // a pattern nearly every candidate matches: full dumps filtered on the host pool — the oracle's first fifty, in order
+    cfg.count = 50;
+    rc = vgen_scan(c, "^1[1-9A-Za-z]", &cfg, nullptr, nullptr, nullptr, &r);
+    vo_scan_random(0, "^1[1-9A-Za-z]", 0, 42, 50, 0, 1, &o);
+    CHECK(rc == VGEN_OK && r.n_matches == 50 && o.n_matches == 50, "random host-filter rc=%d n=%llu", rc, (unsigned long long)r.n_matches);
+    for (size_t i = 0; i < 50 && i < r.n_matches && i < o.n_matches; i++)
+        CHECK(!strcmp(r.matches[i].address, o.matches[i].gen.address) && !memcmp(r.matches[i].key, o.matches[i].key, 32), "random host-filter match %zu", i);
+    vo_scan_free(&o);
+    vgen_scan_result_free(&r);
     vgen_destroy(c);
     // three striped contexts, shard i walking stream i; and endomorphism contexts (six keys per draw): every match re-derives
     for (uint32_t flags : {0u, (uint32_t)VGEN_FLAG_ENDO}) {
