@@ -363,11 +363,73 @@ static void sc_dispatch_api() {
     vgen_destroy(c);
 }
 
+// 32-byte big-endian from a hex string
+static void key_hex(const char *hex, uint8_t be[32]) {
+    memset(be, 0, 32);
+    const size_t n = strlen(hex);
+    for (size_t i = 0; i < n; i++) {
+        const char ch = hex[n - 1 - i];
+        const uint8_t v = (uint8_t)(ch <= '9' ? ch - '0' : (ch | 32) - 'a' + 10);
+        be[31 - i / 2] |= (uint8_t)(v << (4 * (i % 2)));
+    }
+}
+
+static void sc_edge_ranges() {
+    // ranges that are not whole batches: shorter than one, a single key, ending at the last valid scalar n - 1 (the batches
+    // that touch the group order take the per-key path and the key space runs out), end below start
+    vgen_ctx *c = make_ctx(0, 3);
+    struct { const char *lo, *hi; const char *pat; } cases[] = {
+        {"5", "64", "^1"},
+        {"1", "1", "^1"},
+        {"ffff", "ffff", "^1[A-Z]"},
+        {"fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0360000", "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364140", "^1[A-F]"},
+        {"fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364140", "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364140", "^1"},
+    };
+    for (auto &k : cases) {
+        vgen_scan_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
+        cfg.count = UINT64_MAX;
+        cfg.has_start = cfg.has_end = 1;
+        key_hex(k.lo, cfg.start);
+        key_hex(k.hi, cfg.end);
+        vo_scan_result o;
+        const int orc = vo_scan_range(0, k.pat, 0, cfg.start, cfg.end, (size_t)-1, 0, &o);
+        vgen_scan_result r;
+        const int rc = vgen_scan(c, k.pat, &cfg, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_OK && orc == 0 && r.n_matches == o.n_matches && r.complete == 1, "%s..%s: rc=%d n=%llu/%zu complete=%d", k.lo, k.hi, rc,
+              (unsigned long long)r.n_matches, o.n_matches, r.complete);
+        for (size_t i = 0; i < r.n_matches && i < o.n_matches; i++)
+            CHECK(!memcmp(r.matches[i].key, o.matches[i].key, 32) && !strcmp(r.matches[i].wif, o.matches[i].gen.wif), "%s..%s match %zu", k.lo, k.hi, i);
+        vo_scan_free(&o);
+        vgen_scan_result_free(&r);
+    }
+    // end below start: nothing to scan, no error, range "complete"
+    vgen_scan_config cfg = range_cfg(0, 1000, 10);
+    vgen_scan_result r;
+    int rc = vgen_scan(c, "^1", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && r.n_matches == 0 && r.operations == 0, "end < start: rc=%d ops=%llu", rc, (unsigned long long)r.operations);
+    vgen_scan_result_free(&r);
+    // start = 0 or >= n is refused (SecretKey::from_slice, gpu.rs:903)
+    cfg = range_cfg(0, 0, 10);
+    rc = vgen_scan(c, "^1", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_E_RANGE, "start 0: rc=%d", rc);
+    vgen_scan_result_free(&r);
+    // the same short ranges striped over three contexts (most shards have nothing to do)
+    vgen_ctx *cs[3] = {c, make_ctx(0, 2), make_ctx(0, 2)};
+    cfg = range_cfg(0, 5, 5 + 2ull * BATCH + 17);
+    auto want = oracle_range(0, "^1[A-H]", 0, 5, 5 + 2ull * BATCH + 17);
+    rc = vgen_scan_multi(cs, 3, "^1[A-H]", &cfg, nullptr, nullptr, nullptr, &r);
+    CHECK(rc == VGEN_OK && got_of(r) == want && r.complete == 1, "short striped range: rc=%d n=%llu/%zu", rc, (unsigned long long)r.n_matches, want.size());
+    vgen_scan_result_free(&r);
+    for (auto *x : cs) vgen_destroy(x);
+}
+
 int main(int argc, char **argv) {
     const std::map<std::string, std::function<void()>> all = {
         {"range_scan", sc_range_scan}, {"stop_flag", sc_stop_flag}, {"checkpoint", sc_checkpoint}, {"multi_context", sc_multi_context},
         {"ring_growth", sc_ring_growth_and_host_filter}, {"failure_takeover", sc_failure_takeover}, {"random_keys", sc_random_keys},
-        {"endo_and_formats", sc_endo_and_formats}, {"dispatch_api", sc_dispatch_api}};
+        {"endo_and_formats", sc_endo_and_formats}, {"dispatch_api", sc_dispatch_api}, {"edge_ranges", sc_edge_ranges}};
     std::vector<std::string> run;
     for (int i = 1; i < argc; i++) run.push_back(argv[i]);
     if (run.empty())
