@@ -64,6 +64,35 @@ def test_offset_table_built_on_the_device_for_any_lane_count(vg, vo, batch):
     r.close()
 
 
+@pytest.mark.parametrize("S", [2, 4, 16])
+def test_every_keys_per_lane_setting_gives_the_same_keys(vg, vo, S, monkeypatch):
+    """VGEN_SEQ_S: a lane of the sequential kernels tests 2S keys (S uniform points Q_j, each with +R_u and -R_u); the default
+    is 8.  The other settings (measured in profiles/r03_s_sweep.txt) must produce the same payloads: dumps against the oracle
+    for the hash160, Keccak and taproot forms, the six images of an endomorphism context, and a filtered scan."""
+    monkeypatch.setenv("VGEN_SEQ_S", str(S))
+    batch = 16384
+    for fmt in (0, 5, 3):
+        r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=2)
+        for start in (vo.seed_key(S, fmt), 1, N - 3 * batch):
+            assert dump(r, start) == vo.payload_seq(fmt, start, batch), (S, fmt, hex(start))
+        r.close()
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2, endo=True)
+    r.set_filter(None)
+    start = vo.seed_key(S, 9)
+    r.dispatch(start, 0)
+    blob, _, tested = r.await_result(0)
+    assert tested == 6 * batch and blob[:20 * batch] == vo.payload_seq(0, start, batch)
+    for v in range(1, 6):
+        for i in range(0, batch, 257):
+            assert blob[20 * (v * batch + i):20 * (v * batch + i) + 20] == vo.payload(0, variant_key(start + i, v)), (S, v, i)
+    r.close()
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=3)
+    res = vg.scan_gpu_with_runner("^1[A-C]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=7, end=7 + 5 * batch - 1), r)
+    ref = vo.scan_range(0, "^1[A-C]", 7, 7 + 5 * batch - 1, count=10**9)
+    assert [(m.address, m.wif) for m in res.matches] == [(x["address"], x["wif"]) for x in ref["matches"]]
+    r.close()
+
+
 def test_dump_full_size_dispatch_p2pkh(vg, vo):
     # BASELINE config 2, dispatch 0: all 2^20 hash160 byte-equal to the oracle
     batch = 1 << 20
