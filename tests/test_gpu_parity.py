@@ -1235,3 +1235,25 @@ def test_random_keys_on_an_endomorphism_context_test_six_keys_per_draw(vg, vo):
         assert vo.generate(0, k)["address"].startswith("1Ab")
     for r in rs:
         r.close()
+
+
+def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vg, vo, monkeypatch):
+    """The taproot and arbitrary-scalar paths multiply over a multi-gigabyte table built at first use.  When that table cannot
+    be allocated or built (here: injected through VGEN_DEBUG_GTAB_FAIL) the dispatch must not fail: the context says why in
+    vgen_last_error and carries on with the always-present 8-bit table — slower, same keys."""
+    from vgen_amd import api
+    monkeypatch.setenv("VGEN_DEBUG_GTAB_FAIL", "1")
+    batch = 8192
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2tr, frames=2)
+    start = vo.seed_key(77, 3)
+    assert dump(r, start) == vo.payload_seq(3, start, batch)
+    assert b"wide generator table unavailable" in api._L.vgen_last_error(r._h)
+    assert dump(r, start + batch, frame=1) == vo.payload_seq(3, start + batch, batch)     # and again: no retry storm, still right
+    r.close()
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2)
+    r.set_filter(None)
+    r.dispatch_random(3, 0, 0, 0)
+    blob, _, _ = r.await_result(0)
+    for i in range(0, batch, 61):
+        assert blob[20 * i:20 * i + 20] == vo.payload(0, vo.random_key(3, 0, i))
+    r.close()

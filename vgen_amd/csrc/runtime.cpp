@@ -599,7 +599,9 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
             c->gtab_wide_failed = true;   // (asked for: nothing to build)
         } else if (bits == 16 || bits == 20 || bits == 22 || bits == 24 || bits == 26) {
             uint32_t *wide_tab = nullptr, *small = nullptr;   // small: the half-width table the wide one is combined from
-            hipError_t e = hipMalloc((void **)&wide_tab, (size_t)ec_wide_words(bits) * sizeof(uint32_t));
+            // (VGEN_DEBUG_GTAB_FAIL: fault injection for the fallback below — behave as if the allocation had failed)
+            hipError_t e = getenv("VGEN_DEBUG_GTAB_FAIL") ? hipErrorOutOfMemory
+                                                          : hipMalloc((void **)&wide_tab, (size_t)ec_wide_words(bits) * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_wide_words(bits / 2) * sizeof(uint32_t));
             lap("hipMalloc wide + scratch");
             hipStream_t st0 = nullptr;
