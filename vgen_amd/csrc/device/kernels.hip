@@ -768,16 +768,20 @@ hipError_t launch_p2tr_tweak(const KeysArgs &a, hipStream_t stream) {
 //
 // The shape of the reference's CPU path (an independent key per iteration, src/scanner.rs:151-155, full
 // ec_pubkey_create each time) on the device, in the same three stages as the sequential path:
-//   keys_fwd_kernel   one key per lane: k*G by 8-bit fixed windows over the global table (31 branch-free mixed
-//                     additions: unsigned digits accumulated low to high keep the running sum below the next
-//                     addend's scalar, so P = +/-Q cannot occur; "still at infinity" is a select); the Jacobian
-//                     result goes to scratch, the Z's of the workgroup into a product tree, its root out.
+//   keys_fwd_kernel   one key per lane: k*G by fixed windows over a generator table in global memory — 24-bit windows by
+//                     default (10 branch-free mixed additions over an 11.8 GB table built on the device; the 8-bit table,
+//                     31 additions, when the wide one is not worth building or cannot be had): unsigned digits accumulated
+//                     low to high keep the running sum below the next addend's scalar, so P = +/-Q cannot occur; "still
+//                     at infinity" is a select; the Jacobian result goes to scratch (Y = 0 marks "no key"), the Z's of
+//                     the workgroup into a product tree, its root out.
 //   seq_inv_kernel    the roots of all workgroups, one per lane (shared with the sequential path).
-//   keys_bwd_kernel   tree down-sweep, 1/Z per lane, affine + canonical coordinates, payload, filter.
-// A fused single kernel with the inversion inside (one lone wave inverting while the other three of its
-// workgroup wait) measured 430 Mkeys/s; this form removes that serial section.
-// This mode is ~18x the work of the sequential mode per key; it also serves the rare sequential batches that
-// touch the group order.
+//   keys_bwd_kernel   tree down-sweep, 1/Z per lane, affine + canonical coordinates, payload (on an endomorphism context:
+//                     of the point's six images), filter.
+// The scalars come from the frame's key buffer: uploaded (vgen_dispatch_keys) or drawn on the device by rnd_fill_kernel
+// (vgen_dispatch_random).  A fused single kernel with the inversion inside (one lone wave inverting while the other three
+// of its workgroup wait) measured 430 Mkeys/s; this form removes that serial section.  Issue-bound: 21 300 + 3 600
+// instructions per key at the ~2.07 GHz the chip holds under this multiplier-dense code (profiles/pmc_keys.json) — ~9x the
+// work of the sequential mode per key; it also serves the rare sequential batches that touch the group order.
 
 constexpr u32 ORDER_N[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                             0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
