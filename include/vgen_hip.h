@@ -193,7 +193,9 @@ int vgen_clock_probe_read(vgen_ctx *ctx, double *mhz);
 int vgen_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]);
 /* Arbitrary-scalar mode (the CPU path's "independent random key" shape, src/scanner.rs:151-155):
  * tests keys_be[32*i], i < n <= batch_size, with a full fixed-base multiplication per key.
- * Invalid scalars (0 or >= n) yield no result (address.rs:93). */
+ * Invalid scalars (0 or >= n) yield no result (address.rs:93).  The upload rides the frame's stream: a pageable
+ * keys_be has been consumed when the call returns, a pinned (hipHostMalloc / hipHostRegister) one must stay
+ * unchanged until vgen_wait(frame) returns. */
 int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n);
 /* Independent random keys — the shape of the reference's CPU hot loop, which draws 32 fresh bytes per candidate
  * (rng.fill, src/scanner.rs:144-152) — without any upload: lane i of the dispatch tests candidate first_index + i of

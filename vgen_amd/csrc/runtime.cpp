@@ -566,8 +566,8 @@ int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys, b
 
 // Generator tables of the paths that multiply a scalar per key.  `wide`: the dispatch is worth the wide-window table
 // (every P2TR dispatch, arbitrary-scalar dispatches of a few thousand keys or more); a handful of keys, or the rare
-// sequential batch that touches the group order, runs on the always-present 8-bit table instead of paying 3.2 GB and
-// ~10 ms for it.  A wide table that cannot be had (allocation or build failure) is not an error either: the context
+// sequential batch that touches the group order, runs on the always-present 8-bit table instead of paying 11.8 GB and
+// ~19 ms for it.  A wide table that cannot be had (allocation or build failure) is not an error either: the context
 // notes why (vgen_last_error) and stays on the 8-bit table.
 int ensure_gtab(vgen_ctx *c, bool wide) {
     const bool trace = getenv("VGEN_TRACE_CREATE") != nullptr;
