@@ -439,6 +439,34 @@ def test_scan_with_unanchored_pattern_and_ring_overflow_fallback(vg, vo):
     r2.close()
 
 
+def test_a_pattern_every_key_matches_returns_its_first_matches_without_encoding_the_batch(vg, vo):
+    """The reference's default `range --puzzle N` (pattern ".", count 1, src/lib.rs:519): the first key of the range is the
+    match.  The scan filters full dumps on the host there; it examines the dump in index order and stops at `count` — the
+    oracle's first matches, in order, and in milliseconds rather than the time it takes to encode 2^20 addresses."""
+    import time
+    r = vg.GpuRunner(batch_size=1 << 20, fmt=vg.AddressFormat.P2pkh)
+    lo = 1 << 65
+    for pattern, count in ((".", 1), ("^1", 7), ("[a-z]", 1500)):
+        cfg = vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=count, start=lo, end=2 * lo - 1)
+        t0 = time.perf_counter()
+        res = vg.scan_gpu_with_runner(pattern, cfg, r)
+        dt = time.perf_counter() - t0
+        ref = sorted(vo.scan_range(0, pattern, lo, lo + 4095, count=10**9)["matches"], key=lambda x: int(x["hex"], 16))[:count]
+        assert [m.hex for m in res.matches] == [x["hex"] for x in ref] and len(res.matches) == count
+        assert [m.address for m in res.matches] == [x["address"] for x in ref]
+        assert res.operations == 1 << 20 and not res.complete
+        if pattern != ".":   # (the first scan also pays for the dump buffers)
+            assert dt < 0.1, dt
+    # six images per point: the first matches are images of the first points, in index order
+    e = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, endo=True)
+    res = vg.scan_gpu_with_runner(".", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=5), e)
+    assert len(res.matches) == 5
+    for m in res.matches:
+        assert vo.generate(0, int(m.hex, 16))["address"] == m.address
+    e.close()
+    r.close()
+
+
 # ---- P2TR: 32-byte payload (x-only output key), BIP-341 tweak done on the device -------------------------------
 
 

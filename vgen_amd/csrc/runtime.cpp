@@ -419,6 +419,8 @@ void rt_destroy(vgen_ctx *c) {
     if (c->h_slab) (void)hipHostFree(c->h_slab);
     if (c->d_dump_slab) (void)hipFree(c->d_dump_slab);
     if (c->h_dump_slab) (void)hipHostFree(c->h_dump_slab);
+    if (c->d_dump_slab2) (void)hipFree(c->d_dump_slab2);
+    if (c->h_dump_slab2) (void)hipHostFree(c->h_dump_slab2);
     if (c->d_keys_slab) (void)hipFree(c->d_keys_slab);
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
@@ -456,9 +458,29 @@ int rt_clock_probe_read(vgen_ctx *c, double *mhz) {
 
 namespace {
 
-// Dump mode's buffers for all frames: the payloads on the device and their pinned mirrors, which every dump-mode
-// dispatch fills with its own asynchronous copy (vgen_read_dump / vgen_dump_view then need no device call).
-// Allocated once, when dump mode is first selected — never while a dispatch of this context is in flight.
+// Dump mode's buffers: the payloads on the device and their pinned mirrors, which every dump-mode dispatch fills with its
+// own asynchronous copy (vgen_read_dump / vgen_dump_view then need no device call).  Allocated when dump mode is first
+// selected — never while a dispatch of this context is in flight — for the first two frames only: pinning memory is slow
+// (~0.15 ms per MiB), and a scan that wants the first match of a pattern every key satisfies (the reference's default
+// `range --puzzle N`, src/lib.rs:519) never uses a third.  The remaining frames get theirs, in one more piece, when one of
+// them is first dispatched in dump mode (ensure_dump_frame).
+int alloc_dump_piece(vgen_ctx *c, uint32_t first, uint32_t n, uint8_t **d_out, uint8_t **h_out) {
+    const size_t per = up256((size_t)c->batch * (c->endo ? 6 : 1) * c->payload_words * sizeof(uint32_t));
+    uint8_t *d = nullptr, *h = nullptr;
+    if (hipMalloc((void **)&d, per * n) != hipSuccess) return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed");
+    if (hipHostMalloc((void **)&h, per * n, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(d);
+        return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed (pinned host memory)");
+    }
+    *d_out = d;
+    *h_out = h;
+    for (uint32_t i = 0; i < n; i++) {
+        c->fr[first + i].d_dump = reinterpret_cast<uint32_t *>(d + per * i);
+        c->fr[first + i].h_dump = h + per * i;
+    }
+    return VGEN_OK;
+}
+
 int ensure_dump_slab(vgen_ctx *c) {
     if (c->d_dump_slab) return VGEN_OK;
     const size_t per = up256((size_t)c->batch * (c->endo ? 6 : 1) * c->payload_words * sizeof(uint32_t));
@@ -468,20 +490,18 @@ int ensure_dump_slab(vgen_ctx *c) {
     const size_t budget = (size_t)1 << 30;
     uint32_t n = (uint32_t)std::min<size_t>(c->frames, std::max<size_t>(2, budget / per));
     n = std::min(n, c->frames);
-    uint8_t *d = nullptr, *h = nullptr;
-    if (hipMalloc((void **)&d, per * n) != hipSuccess) return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed");
-    if (hipHostMalloc((void **)&h, per * n, hipHostMallocDefault) != hipSuccess) {
-        (void)hipFree(d);
-        return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed (pinned host memory)");
-    }
-    c->d_dump_slab = d;
-    c->h_dump_slab = h;
+    if (int rc = alloc_dump_piece(c, 0, std::min<uint32_t>(n, 2), &c->d_dump_slab, &c->h_dump_slab)) return rc;
     c->dump_frames = n;
-    for (uint32_t i = 0; i < n; i++) {
-        c->fr[i].d_dump = reinterpret_cast<uint32_t *>(c->d_dump_slab + per * i);
-        c->fr[i].h_dump = c->h_dump_slab + per * i;
-    }
     return VGEN_OK;
+}
+
+// The dump buffer of `frame`, on the dispatch path: frames 0 and 1 have theirs, the others' piece is made at first need.
+int ensure_dump_frame(vgen_ctx *c, uint32_t frame) {
+    if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
+    if (frame >= c->dump_frames)
+        return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
+    if (c->fr[frame].d_dump) return VGEN_OK;
+    return alloc_dump_piece(c, 2, c->dump_frames - 2, &c->d_dump_slab2, &c->h_dump_slab2);
 }
 
 bool dump_mode(const vgen_ctx *c) { return !c->have_filter || c->h_filter.kind == DEVF_HOST_ALL; }
@@ -695,8 +715,7 @@ int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const
     a.endo = endo_now ? 1u : 0u;
     a.vstride = c->batch;
     if (dump) {
-        if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
-        if (!f.d_dump) return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
+        if (int rc = ensure_dump_frame(c, (uint32_t)(&f - c->fr.data()))) return rc;
         if (n < c->batch) HIP_TRY(c, hipMemsetAsync(f.d_dump, 0, (size_t)c->batch * (endo_now ? 6 : 1) * c->payload_words * sizeof(uint32_t), f.s));
         a.dump = f.d_dump;
     } else {
@@ -768,8 +787,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     a.s = S;
     const bool dump = dump_mode(c);
     if (dump) {
-        if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
-        if (!f.d_dump) return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
+        if (int rc = ensure_dump_frame(c, (uint32_t)(&f - c->fr.data()))) return rc;
         a.dump = f.d_dump;
     } else {
         a.mhdr = reinterpret_cast<DevMatchHeader *>(f.d_match);

@@ -84,8 +84,9 @@ struct vgen_ctx {
     uint8_t *d_slab = nullptr;                   // device memory of all frames (scratch [| P2TR scratch], per frame)
     uint8_t *d_match_slab = nullptr;             // match rings of all frames (rt_set_match_cap)
     uint8_t *h_slab = nullptr;                   // pinned mirrors of the match rings
-    uint8_t *d_dump_slab = nullptr;              // dump mode: payload buffers of all frames (first vgen_set_filter(NULL))
+    uint8_t *d_dump_slab = nullptr;              // dump mode: payload buffers of frames 0 and 1 (first vgen_set_filter(NULL))
     uint8_t *h_dump_slab = nullptr;              // ... and their pinned mirrors
+    uint8_t *d_dump_slab2 = nullptr, *h_dump_slab2 = nullptr;   // frames 2 .. dump_frames-1: made when one of them first dumps
     uint32_t dump_frames = 0;                    // frames that have a dump buffer (all of them unless that would pin > ~1 GiB)
     uint8_t *d_keys_slab = nullptr;              // arbitrary-scalar path: keys + scratch of all frames (first use)
     hipStream_t probe_stream = nullptr;          // shader-clock probe (vgen_clock_probe_*)

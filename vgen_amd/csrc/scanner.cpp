@@ -551,19 +551,41 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             // here (encoding and matching 2^20 addresses takes the host tens of milliseconds).
             const uint8_t *dump = nullptr;
             if ((status = vgen_dump_view(ctx, frame, &dump, nullptr)) != VGEN_OK) break;
-            if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
-            const unsigned nt = pool->size();
-            std::vector<std::vector<vgen_generated>> part(nt);
+            // A scan that wants few matches of a pattern nearly every key satisfies (the reference's default `range
+            // --puzzle N`: pattern ".", count 1, src/lib.rs:519) must not encode a million addresses to return the first:
+            // the dump is examined in index order in growing pieces — a first short one on this thread — until `count` is
+            // reached; what is left unexamined counts as cut.  With a checkpoint the whole batch is examined (a committed
+            // batch is recorded with every match it holds).
             const uint32_t total = (uint32_t)tested;   // N, or 6 N for an endomorphism dispatch
-            pool->run([&](unsigned t) {
-                const uint32_t lo = (uint32_t)((uint64_t)total * t / nt), hi = (uint32_t)((uint64_t)total * (t + 1) / nt);
-                vgen_generated g;
-                for (uint32_t i = lo; i < hi; i++)
-                    if (make_match(flt, cfg->format, batch_start, i, dump + (size_t)i * pbytes, end, g, N, images)) part[t].push_back(g);
-            });
-            for (auto &p : part)
-                for (auto &g : p)
-                    if (!push(g)) cut = true;
+            uint32_t pos = 0;
+            for (unsigned round = 0; pos < total && (ck || found() < count); round++) {
+                const uint64_t have = found();
+                const uint64_t need = ck ? total : have < count ? count - have : 0;
+                uint64_t len = total - pos;
+                if (!ck && need < total / 8) len = std::min<uint64_t>(len, std::max<uint64_t>(need * 4, 64) << std::min(2 * round, 24u));
+                if (len < 1024) {
+                    vgen_generated g;
+                    const uint32_t stop_at = pos + (uint32_t)len;
+                    for (; pos < stop_at && (ck || found() < count); pos++)
+                        if (make_match(flt, cfg->format, batch_start, pos, dump + (size_t)pos * pbytes, end, g, N, images)) (void)push(g);
+                    continue;
+                }
+                if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
+                const unsigned nt = pool->size();
+                std::vector<std::vector<vgen_generated>> part(nt);
+                const uint32_t base = pos, span = (uint32_t)len;
+                pool->run([&](unsigned t) {
+                    const uint32_t lo = base + (uint32_t)((uint64_t)span * t / nt), hi = base + (uint32_t)((uint64_t)span * (t + 1) / nt);
+                    vgen_generated g;
+                    for (uint32_t i = lo; i < hi; i++)
+                        if (make_match(flt, cfg->format, batch_start, i, dump + (size_t)i * pbytes, end, g, N, images)) part[t].push_back(g);
+                });
+                for (auto &p : part)
+                    for (auto &g : p)
+                        if (!push(g)) cut = true;
+                pos += span;
+            }
+            if (pos < total) cut = true;   // keys left unexamined (conservative: they may not all be matches)
         }
 
         bool dispatched_next = false;
