@@ -6,12 +6,14 @@
 // `estimate` (lib.rs:345-375) reports the device rate.  Provider patterns resolve against a static table (host/provider.cpp), not the boha crate.  Deliberately absent: the TUI and any CPU scan path (`--no-gpu` is an
 // error here: this build has no CPU backend).  Added: --seed (the reference seeds from OS entropy
 // only), --devices (batch-striped multi-GPU scan), --frames, --checkpoint (resumable scans).
+#include <ctype.h>
 #include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -144,6 +146,33 @@ bool parse_hex_key(const std::string &hex, uint8_t out[32]) {
     return true;
 }
 
+// A mainnet WIF string (Base58Check of 0x80 | key [| 0x01]) taken apart WITHOUT its checksum being verified (the caller
+// re-encodes the key and compares strings): the 32 key bytes, and whether the string claims a compressed public key.
+bool parse_wif(const std::string &s, uint8_t key[32], bool *compressed) {
+    static const char *alphabet = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz";
+    if (s.size() < 50 || s.size() > 53) return false;
+    std::vector<uint8_t> num;   // big-endian base-256 digits
+    for (char ch : s) {
+        const char *q = strchr(alphabet, ch);
+        if (!q || !ch) return false;
+        unsigned carry = (unsigned)(q - alphabet);
+        for (size_t i = num.size(); i-- > 0;) {
+            carry += 58u * num[i];
+            num[i] = (uint8_t)carry;
+            carry >>= 8;
+        }
+        while (carry) {
+            num.insert(num.begin(), (uint8_t)carry);
+            carry >>= 8;
+        }
+    }
+    if ((num.size() != 37 && num.size() != 38) || num[0] != 0x80) return false;
+    if (num.size() == 38 && num[33] != 0x01) return false;
+    memcpy(key, num.data() + 1, 32);
+    if (compressed) *compressed = num.size() == 38;
+    return true;
+}
+
 void usage() {
     fprintf(stderr,
             "vgen-hip — MI355X scan engine for the vgen hot path\n\n"
@@ -158,7 +187,7 @@ void usage() {
             "                    PATTERN may be a provider pattern boha:b1000:N [-l PREFIX_LENGTH] [--provider-table CSV]\n"
             "  vgen-hip range (--range START:END | --puzzle P) [-p PATTERN] [-f FORMAT] [-c COUNT (0 = whole range)] ...\n"
             "  vgen-hip estimate -p PATTERN [-f FORMAT] [-i]\n"
-            "  vgen-hip verify -k HEXKEY [-a ADDRESS]\n"
+            "  vgen-hip verify -k WIF_OR_HEX [-a ADDRESS]\n"
             "  vgen-hip list-gpus [--json]\n");
 }
 
@@ -499,19 +528,74 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (o.cmd == "verify") {
+        // src/lib.rs:377-492: the key as WIF first, then as hex (an optional 0x in front); every address of the key; with
+        // --address, MATCH when it is one of them (Bech32 in one case either way, Ethereum case-insensitively, raw 40 hex too)
         uint8_t k[32];
-        if (!parse_hex_key(o.key, k)) die("verify: --key must be a hex private key in this build");
-        const int fmts[] = {VGEN_FMT_P2PKH, VGEN_FMT_P2WPKH, VGEN_FMT_P2SH_P2WPKH, VGEN_FMT_P2TR,
-                            VGEN_FMT_P2PKH_UNCOMPRESSED, VGEN_FMT_ETHEREUM};
-        bool ok = o.address.empty();
-        for (int f : fmts) {
-            char addr[128], wif[128];
-            if (vgen_derive((uint32_t)f, k, addr, sizeof addr, wif, sizeof wif) != VGEN_OK) die("invalid private key");
-            printf("%-22s %s\n", format_display(f), addr);
-            if (o.address == addr) ok = true;
+        bool is_wif = false;
+        char addr[128], wif[128];
+        if (parse_wif(o.key, k, nullptr)) {
+            // the checksum: the key re-encoded in the form the string claims must be the string again
+            bool compressed = false;
+            (void)parse_wif(o.key, k, &compressed);
+            if (vgen_derive(compressed ? VGEN_FMT_P2PKH : VGEN_FMT_P2PKH_UNCOMPRESSED, k, addr, sizeof addr, wif, sizeof wif) == VGEN_OK && o.key == wif)
+                is_wif = true;
         }
-        if (!o.address.empty()) printf("%s\n", ok ? "MATCH" : "MISMATCH");
-        return ok ? 0 : 1;
+        if (!is_wif) {
+            std::string h = o.key;
+            while (h.compare(0, 2, "0x") == 0) h = h.substr(2);   // trim_start_matches("0x")
+            bool is_hex = !h.empty() && h.size() % 2 == 0;
+            for (char c : h) is_hex = is_hex && isxdigit((unsigned char)c);
+            if (!is_hex) die("Invalid key format (not WIF or hex)");
+            if (h.size() != 64 || !parse_hex_key(h, k)) die("Hex key must be 32 bytes");
+        }
+        std::string a[6];
+        const int fmts[6] = {VGEN_FMT_P2PKH, VGEN_FMT_P2PKH_UNCOMPRESSED, VGEN_FMT_P2WPKH, VGEN_FMT_P2SH_P2WPKH, VGEN_FMT_P2TR, VGEN_FMT_ETHEREUM};
+        std::string wif_c, wif_u;
+        for (int i = 0; i < 6; i++) {
+            if (vgen_derive((uint32_t)fmts[i], k, addr, sizeof addr, wif, sizeof wif) != VGEN_OK) die("malformed or out-of-range secret key");
+            a[i] = addr;
+            if (fmts[i] == VGEN_FMT_P2PKH) wif_c = wif;
+            if (fmts[i] == VGEN_FMT_P2PKH_UNCOMPRESSED) wif_u = wif;
+        }
+        std::string hex;
+        for (int i = 0; i < 32; i++) {
+            char b[3];
+            snprintf(b, sizeof b, "%02x", k[i]);
+            hex += b;
+        }
+        printf("Private key: %s\n", is_wif ? o.key.c_str() : wif_c.c_str());
+        printf("WIF (uncompr.):     %s\n", wif_u.c_str());
+        printf("Hex: %s\n\n", hex.c_str());
+        printf("P2PKH address:      %s\n", a[0].c_str());
+        printf("P2PKH (uncompr.):   %s\n", a[1].c_str());
+        printf("P2WPKH address:     %s\n", a[2].c_str());
+        printf("P2SH-P2WPKH addr:  %s\n", a[3].c_str());
+        printf("P2TR address:       %s\n", a[4].c_str());
+        printf("Ethereum address:   %s\n", a[5].c_str());
+        if (!o.address.empty()) {
+            auto lower = [](std::string t) {
+                for (char &c : t) c = (char)tolower((unsigned char)c);
+                return t;
+            };
+            const std::string &e = o.address;
+            bool all_lower = true, all_upper = true, all_hex = true;
+            for (char c : e) {
+                if (isalpha((unsigned char)c)) {
+                    all_lower = all_lower && islower((unsigned char)c);
+                    all_upper = all_upper && isupper((unsigned char)c);
+                }
+                all_hex = all_hex && isxdigit((unsigned char)c);
+            }
+            const bool bech = e.size() >= 3 && lower(e.substr(0, 3)) == "bc1";
+            const std::string norm = bech && (all_lower || all_upper) ? lower(e) : e;
+            const std::string eth = norm.size() == 40 && all_hex ? "0x" + norm : norm;
+            bool listed = false;
+            for (const std::string &x : a) listed = listed || x == norm;
+            if (listed) printf("\nMATCH!\n");
+            else if (eth.size() >= 2 && lower(eth.substr(0, 2)) == "0x" && lower(a[5]) == lower(eth)) printf("\nMATCH! (Ethereum, case-insensitive)\n");
+            else printf("\nMISMATCH! Expected: %s\n", e.c_str());
+        }
+        return 0;
     }
     usage();
     return 2;
