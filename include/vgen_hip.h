@@ -65,11 +65,13 @@ typedef enum vgen_format {
                                  vgen_frame_dispatch_ms report durations (bench.py); without it a dispatch is
                                  three kernels and one copy, and the host loop is ~10 us per step cheaper */
 
+#define VGEN_MAX_BATCH 16777216u   /* 2^24 keys per dispatch (the rate is flat from 2^20 up: DESIGN.md, batch sweep) */
+
 typedef struct vgen_params {
     uint32_t struct_size;  /* = sizeof(vgen_params) */
     int32_t device;        /* HIP device ordinal */
     uint32_t batch_size;   /* keys per dispatch; reference default 524288 (gpu.rs:83); must be a
-                              multiple of 8192; 0 selects 1048576 */
+                              multiple of 8192, at most VGEN_MAX_BATCH; 0 selects 1048576 */
     uint32_t format;       /* vgen_format */
     uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 12; max 20.  One dispatch is one wave per SIMD, so throughput grows with the frames
                               in flight: 7.4 / 11.4 / 12.0 / 12.1 Gkeys/s at 2 / 4 / 8 / 12 (P2PKH, 2^20 keys each).  The

@@ -261,8 +261,8 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     c->payload_words = p->format == VGF_P2TR ? 8 : 5;
     c->endo = (p->flags & VGEN_FLAG_ENDO) != 0 && p->format != VGF_P2TR;
     c->S = 8;
-    if (c->frames > 20 || c->batch % 8192 != 0) {
-        err = "frames must be <= 20 and batch_size a multiple of 8192";
+    if (c->frames > 20 || c->batch % 8192 != 0 || c->batch > VGEN_MAX_BATCH) {
+        err = "frames must be <= 20 and batch_size a multiple of 8192, at most 2^24";
         delete c;
         return VGEN_E_INVALID;
     }

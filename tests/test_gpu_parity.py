@@ -64,6 +64,56 @@ def test_offset_table_built_on_the_device_for_any_lane_count(vg, vo, batch):
     r.close()
 
 
+def test_the_largest_dispatch(vg, vo):
+    """VGEN_MAX_BATCH = 2^24 keys per dispatch (sixteen times BASELINE's): the dump against the oracle at both ends and on a
+    sample in between, every candidate of a filtered dispatch against that dump and against sixteen 2^20-key dispatches
+    over the same keys, and one key more per dispatch refused."""
+    B = 1 << 24
+    with pytest.raises(vg.VgenError):
+        vg.GpuRunner(batch_size=B + 8192, fmt=vg.AddressFormat.P2pkh, frames=2)
+    r = vg.GpuRunner(batch_size=B, fmt=vg.AddressFormat.P2pkh, frames=2, match_cap=8192)
+    start = vo.seed_key(24, 24)
+    blob = bytes(dump(r, start))
+    assert len(blob) == 20 * B
+    assert blob[:20 * 8192] == vo.payload_seq(0, start, 8192)
+    assert blob[20 * (B - 8192):] == vo.payload_seq(0, start + B - 8192, 8192)
+    import random
+    rng = random.Random(24)
+    for i in [B // 2 - 1, B // 2, B // 2 + 1] + [rng.randrange(B) for _ in range(3000)]:
+        assert blob[20 * i:20 * i + 20] == vo.payload(0, start + i), i
+    pat = vg.Pattern("^1Cat", False, vg.AddressFormat.P2pkh)
+    r.set_filter(pat)
+    r.dispatch(start, 1)
+    big, n_big, tested = r.await_result(1)
+    assert tested == B and n_big == len(big) > 40 and all(blob[20 * i:20 * i + 20] == pl for i, pl in big)
+    small = vg.GpuRunner(batch_size=1 << 20, fmt=vg.AddressFormat.P2pkh, frames=2)
+    small.set_filter(pat)
+    want = []
+    for j in range(16):
+        small.dispatch(start + (j << 20), 0)
+        want += [((j << 20) + i, pl) for i, pl in small.await_result(0)[0]]
+    assert big == want
+    small.close()
+    r.close()
+    # six images per point at that size: candidate indices v * 2^24 + i stay below 2^32
+    r = vg.GpuRunner(batch_size=B, fmt=vg.AddressFormat.P2pkh, frames=2, match_cap=8192, endo=True)
+    small = vg.GpuRunner(batch_size=1 << 20, fmt=vg.AddressFormat.P2pkh, frames=2, endo=True)
+    r.set_filter(pat)
+    small.set_filter(pat)
+    r.dispatch(start, 0)
+    big, n_big, tested = r.await_result(0)
+    assert tested == 6 * B and n_big == len(big) > 300
+    want = []
+    for j in range(16):
+        small.dispatch(start + (j << 20), 0)
+        want += [((i >> 20) * B + (j << 20) + (i & 0xFFFFF), pl) for i, pl in small.await_result(0)[0]]
+    assert big == sorted(want)
+    for i, pl in big[::7]:
+        assert vo.payload(0, variant_key(start + (i % B), i // B)) == pl
+    small.close()
+    r.close()
+
+
 @pytest.mark.parametrize("S", [2, 4, 16])
 def test_every_keys_per_lane_setting_gives_the_same_keys(vg, vo, S, monkeypatch):
     """VGEN_SEQ_S: a lane of the sequential kernels tests 2S keys (S uniform points Q_j, each with +R_u and -R_u); the default

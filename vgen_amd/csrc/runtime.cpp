@@ -260,6 +260,9 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     if (c->S < 2 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two in [2, 16]");
     if (c->batch % 8192 != 0 || c->batch % (2 * SEQ_WG * c->S) != 0 || c->batch < 8192)
         return bail(VGEN_E_INVALID, "batch_size must be a multiple of 8192 (and of 512*S)");
+    // the largest dispatch the kernels are laid out and tested for: 32-bit indices into 6 x batch payload slots, 24 bits of
+    // lane number in the offset-table build, ~75 B of scratch per key and frame
+    if (c->batch > VGEN_MAX_BATCH) return bail(VGEN_E_INVALID, "batch_size must not exceed 16777216 (2^24)");
     if (c->match_cap < FIRST_COPY) c->match_cap = FIRST_COPY;
     c->lanes = c->batch / (2 * c->S);
     c->groups = c->lanes / SEQ_WG;
