@@ -517,6 +517,19 @@ def test_a_pattern_every_key_matches_returns_its_first_matches_without_encoding_
     r.close()
 
 
+def test_scan_with_a_pattern_whose_dfa_is_not_built(vg, vo):
+    """"a.{20}$" and its like (regex_dfa.h: Dfa::lazy): no device test can be derived, the scan filters full dumps on the host
+    by walking the NFA — the oracle's matches over the same range, in order."""
+    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=3)
+    for pattern, ci in (("a.{20}$", False), ("^1.*[ab].{16}Q", True)):
+        lo, hi = 0x77000, 0x77000 + 3 * 8192 - 1
+        res = vg.scan_gpu_with_runner(pattern, vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, start=lo, end=hi, case_insensitive=ci), r)
+        ref = sorted(vo.scan_range(0, pattern, lo, hi, count=10**9, ci=ci)["matches"], key=lambda x: int(x["hex"], 16))
+        assert len(ref) > 20 and [(m.address, m.hex) for m in res.matches] == [(x["address"], x["hex"]) for x in ref]
+        assert res.operations == 3 * 8192 and res.complete
+    r.close()
+
+
 # ---- P2TR: 32-byte payload (x-only output key), BIP-341 tweak done on the device -------------------------------
 
 

@@ -255,3 +255,27 @@ def test_exotic_patterns_still_compile_to_device_filters(core):
         assert kind.value in want_kinds, (pat, kind.value)
         for fl in flags.raw:
             assert (fl & 1) or not (fl & 2)      # the device prefilter never rejects an exact match
+
+
+# ---- patterns whose DFA is not built: an end anchor (or a word boundary) behind a counted wildcard ---------------
+LAZY = [("a[ab]{14}$", False), ("a.{20}$", False), ("[ab]*a[ab]{30}$", False), (r"(?i)x.{15}\b", False), ("A.{16}$", True),
+        ("^1.*a.{18}$", False), (r"(a|bb).{17}$", False)]
+
+
+@pytest.mark.parametrize("pat, ci", LAZY)
+def test_patterns_too_large_to_determinise_are_matched_by_walking_the_nfa(core, pat, ci):
+    """regex::Regex compiles "a.{20}$" without blinking (its own engines fall back to an NFA walk); a table of the 2^21 sets
+    of offsets such a pattern remembers is not built here either: regex_compile keeps the NFA (Dfa::lazy) and is_match walks
+    it.  Three-way differential: product, oracle (an NFA simulation of its own), Python's re."""
+    rng = random.Random(len(pat))
+    flags = re.I if ci else 0
+    hits = 0
+    ora = vo.Regex(pat, ci)
+    for _ in range(200):   # (the test shim compiles the pattern per call: ~25 ms each)
+        head = "".join(rng.choice("abAxX1 c") for _ in range(rng.randrange(0, 9)))
+        tail = "".join(rng.choice("abxA") if rng.random() < 0.04 else rng.choice("ab") for _ in range(rng.randrange(8, 36)))
+        text = rng.choice(["", "1"]) + head + rng.choice(["a", "x", "bb", "A", "X"]) + tail
+        want = int(re.search(pat, text, flags) is not None)
+        assert product(core, pat, ci, text) == want == int(ora.matches(text)), (pat, text)
+        hits += want
+    assert 0 < hits < 200, hits

@@ -29,7 +29,7 @@ ATOMS = ["1", "3", "b", "c", "q", "A", "Z", "a", "z", "0", "9", "x", "f", ".", "
          "[\\]]", "[a-", "[", "]", "(", ")", "(?:", "(?i)", "(?-i)", "(?i:", "(?x)", "(?s)", "(?m)", "(?U)", "(?u)", "(?-u)",
          "(?P<n>", "(?<n>", "(?", "|", "*", "+", "?", "*?", "+?", "??", "{2}", "{1,3}", "{,3}", "{3,}", "{", "}", "{99999}",
          "{0}", "{1000}", "^", "$", "\\A", "\\z", "\\x41", "\\x{41}", "\\x{110000}", "\\u0041", "\\u{1F600}", "\\U00000041",
-         "\\x", "\\", "\\Q", "\\0", "\\1", "\\n", "\\t", " ", "#", "\n", "\x80", "\xff", "\xc3\xa9", "1Cat", "bc1q", "0xdead"]
+         ".{20}$", "[ab]{14}$", "a.{13}\\b", "(a|bb).{17}", "\\x", "\\", "\\Q", "\\0", "\\1", "\\n", "\\t", " ", "#", "\n", "\x80", "\xff", "\xc3\xa9", "1Cat", "bc1q", "0xdead"]
 
 
 def gen(rng):

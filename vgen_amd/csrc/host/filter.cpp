@@ -497,6 +497,12 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
     out.format = format;
     memset(&out.dev, 0, sizeof out.dev);
     if (!regex_compile(pattern, case_insensitive, out.dfa, err)) return false;
+    if (out.dfa.lazy) {
+        // no DFA tables (regex_dfa.h): nothing to derive a device test from — the reference's mode, every key to the host
+        out.dev.kind = DEVF_HOST_ALL;
+        out.selectivity = 1.0;
+        return true;
+    }
     switch (format) {
     case VGF_P2PKH:
     case VGF_P2PKH_UNCOMPRESSED:
@@ -536,6 +542,11 @@ bool filter_compile(const std::string &pattern, bool case_insensitive, uint32_t 
         if (!regex_compile(pattern, true, folded, e2)) {
             err = e2;
             return false;
+        }
+        if (folded.lazy) {
+            out.dev.kind = DEVF_HOST_ALL;
+            out.selectivity = 1.0;
+            return true;
         }
         const SymSpec sp = {"0x", HEXL, 4, 40, 0, 160};
         derive_symbols(folded, sp, out.dev, out.selectivity);

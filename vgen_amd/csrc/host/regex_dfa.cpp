@@ -824,9 +824,45 @@ void closure(const Nfa &nfa, const std::vector<int> &seeds, Kind prev, Kind next
     std::sort(out.begin(), out.end());
 }
 
+struct TooManyStates {};
+
 }  // namespace
 
+// The pattern as its NFA, for patterns regex_compile does not determinise (regex_dfa.h).
+struct LazyNfa {
+    Nfa nfa;
+    int start = -1, match = -1;
+
+    // The walk regex_compile tabulates, done on the haystack itself: the set of NFA states after each byte.
+    bool is_match(const char *text) const {
+        std::vector<uint32_t> mark(nfa.st.size(), 0);
+        uint32_t epoch = 0;
+        std::vector<int> cur, resolved, seeds;
+        closure(nfa, {start}, K_EDGE, K_UNKNOWN, cur, mark, epoch);
+        Kind prev = K_EDGE;
+        for (const unsigned char *p = (const unsigned char *)text; *p; p++) {
+            if (std::binary_search(cur.begin(), cur.end(), match)) return true;
+            const int c = *p < 128 ? *p : 128;
+            const Kind nk = kind_of(c);
+            closure(nfa, cur, prev, nk, resolved, mark, epoch);
+            if (std::binary_search(resolved.begin(), resolved.end(), match)) return true;
+            seeds.clear();
+            for (int s : resolved) {
+                const NState &n = nfa.st[s];
+                if (n.type == NState::CHAR && n.set.has(c)) seeds.push_back(n.a);
+            }
+            seeds.push_back(start);   // unanchored search
+            closure(nfa, seeds, nk, K_UNKNOWN, cur, mark, epoch);
+            prev = nk;
+        }
+        if (std::binary_search(cur.begin(), cur.end(), match)) return true;
+        closure(nfa, cur, prev, K_EDGE, resolved, mark, epoch);
+        return std::binary_search(resolved.begin(), resolved.end(), match);
+    }
+};
+
 bool Dfa::is_match(const char *text) const {
+    if (lazy) return lazy->is_match(text);
     uint32_t s = 0;
     for (const unsigned char *p = (const unsigned char *)text; *p; p++) {
         if (match_now[s]) return true;
@@ -892,13 +928,15 @@ bool regex_compile(const std::string &pattern, bool case_insensitive, Dfa &out, 
             auto key = std::make_pair(set, any_assert ? (int)prev : (int)K_OTHER);
             auto it = ids.find(key);
             if (it != ids.end()) return it->second;
-            if (states.size() >= 20000) throw ParseError("pattern needs too many DFA states");
+            if (states.size() >= 20000) throw TooManyStates();
             uint32_t id = (uint32_t)states.size();
             ids[key] = id;
             states.push_back(key);
             return id;
         };
 
+        out.lazy.reset();
+        try {
         closure(nfa, {start}, K_EDGE, K_UNKNOWN, tmp, mark, epoch);
         {
             // the start state keeps K_EDGE even without assertions in the pattern: nothing depends on it then
@@ -997,6 +1035,21 @@ bool regex_compile(const std::string &pattern, bool case_insensitive, Dfa &out, 
         out.dead.assign(out.n_states, 0);
         for (uint32_t s = 0; s < out.n_states; s++) out.dead[s] = !live[s];
         return true;
+        } catch (const TooManyStates &) {
+            // no table for this one: keep the NFA and walk it per haystack (regex_dfa.h)
+            auto lz = std::make_shared<LazyNfa>();
+            lz->nfa = std::move(nfa);
+            lz->start = start;
+            lz->match = match;
+            out.lazy = lz;
+            out.n_cls = n_cls;
+            out.n_states = 0;
+            out.trans.clear();
+            out.match_now.clear();
+            out.match_at_end.clear();
+            out.dead.clear();
+            return true;
+        }
     } catch (const ParseError &e) {
         err = "Invalid regex pattern: " + pattern + " (" + e.what() + ")";
         return false;

@@ -12,10 +12,13 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
 namespace vg {
+
+struct LazyNfa;   // regex_dfa.cpp
 
 struct Dfa {
     // byte -> symbol class (bytes >= 128 share one class that only '.' and negated classes accept)
@@ -28,6 +31,10 @@ struct Dfa {
     std::vector<uint8_t> match_at_end;  // matches if the haystack ends here
     std::vector<uint8_t> dead;          // no match reachable any more
     uint32_t n_states = 0;
+    // Patterns whose DFA would need more states than regex_compile builds (an end anchor behind a counted wildcard —
+    // "a.{20}$" — remembers 2^20 sets of offsets): the tables above stay empty and is_match simulates the NFA, as the regex
+    // crate's own fallback engines do (n_states == 0; filter.cpp then has no device test to derive: every key goes to the host).
+    std::shared_ptr<const LazyNfa> lazy;
 
     bool is_match(const char *text) const;
     bool is_match(const std::string &s) const { return is_match(s.c_str()); }
