@@ -425,11 +425,104 @@ static void sc_edge_ranges() {
     for (auto *x : cs) vgen_destroy(x);
 }
 
+// Randomised differential: formats x pattern kinds (hash160 ranges, bit masks, on-device automaton, full dumps filtered on the
+// host, NFA-walk patterns) x ranges cut anywhere x counts x one to three contexts x frames x ring sizes x injected failures,
+// every result against the oracle's scan of the same range.  VGEN_FAKE_FUZZ_SEED / VGEN_FAKE_FUZZ_CASES select the walk.
+static void sc_fuzz() {
+    struct Pat { uint32_t fmt; const char *p; int ci; };
+    static const Pat pats[] = {
+        {0, "^1[A-C]", 0}, {0, "^1", 0}, {0, "[A-Z]{2}", 0}, {0, "Q$", 0}, {0, "a.{20}$", 0}, {0, "^1c", 1}, {0, "^1[Oo]", 0},
+        {1, "^bc1q[ac]", 0}, {1, "a$", 0}, {1, "xy", 0}, {1, "^BC1Q[AC]", 1},
+        {2, "^3[A-C]", 0}, {2, "^3", 0}, {2, "z$", 0},
+        {4, "^1[D-F]", 0}, {4, "[a-f]{3}", 0},
+        {5, "^0x[0-3]", 0}, {5, "^0xA", 1}, {5, "f$", 0}, {5, "^0x[A-F]", 0},
+    };
+    const char *es = getenv("VGEN_FAKE_FUZZ_SEED"), *ec = getenv("VGEN_FAKE_FUZZ_CASES");
+    uint64_t x = es ? strtoull(es, nullptr, 0) : 20261004ull;
+    const int cases = ec ? atoi(ec) : 16;
+    auto rnd = [&x](uint64_t n) {   // xorshift64*
+        x ^= x >> 12;
+        x ^= x << 25;
+        x ^= x >> 27;
+        return (x * 2685821657736338717ull >> 16) % n;
+    };
+    for (int t = 0; t < cases; t++) {
+        const Pat &pt = pats[rnd(sizeof pats / sizeof pats[0])];
+        const uint64_t lo = 1 + rnd(2) * rnd(1ull << 40) + rnd(3 * BATCH);
+        const uint64_t len = 1 + rnd(4 * BATCH) + rnd(2) * rnd(BATCH);
+        const uint64_t hi = lo + len - 1;
+        static const uint64_t counts[] = {1, 3, 50, UINT64_MAX, UINT64_MAX};
+        const uint64_t count = counts[rnd(5)];
+        const uint32_t n_ctx = 1 + (uint32_t)rnd(3);
+        const uint32_t cap = rnd(2) ? 0 : 256;
+        vgen_ctx *cs[3] = {nullptr, nullptr, nullptr};
+        for (uint32_t i = 0; i < n_ctx; i++) cs[i] = make_ctx(pt.fmt, 2 + (uint32_t)rnd(4), cap);
+        int victim = -1;
+        if (n_ctx > 1 && rnd(3) == 0) {
+            victim = (int)rnd(n_ctx);
+            vgen_debug_fail_after(cs[victim], rnd(3));
+        }
+        if (n_ctx == 1 && rnd(5) == 0) {
+            // an independent random key per candidate (seeded stream): the oracle's walk of the same stream, in order
+            vgen_scan_config rc_cfg;
+            memset(&rc_cfg, 0, sizeof rc_cfg);
+            rc_cfg.struct_size = sizeof rc_cfg;
+            rc_cfg.format = pt.fmt;
+            rc_cfg.case_insensitive = pt.ci;
+            rc_cfg.count = 1 + rnd(6);
+            rc_cfg.seed = 1 + rnd(1000);
+            rc_cfg.flags = VGEN_SCAN_RANDOM_KEYS;
+            rc_cfg.max_batches = 6;
+            vgen_scan_result r;
+            const int rc = vgen_scan(cs[0], pt.p, &rc_cfg, nullptr, nullptr, nullptr, &r);
+            vo_scan_result o;
+            const int orc = vo_scan_random((int)pt.fmt, pt.p, pt.ci, rc_cfg.seed, (size_t)rc_cfg.count, 6ull * BATCH, 1, &o);
+            CHECK(rc == VGEN_OK && orc == 0 && r.n_matches == o.n_matches, "case %d: random keys fmt %u '%s' seed %llu count %llu: rc=%d n=%llu/%zu", t, pt.fmt, pt.p,
+                  (unsigned long long)rc_cfg.seed, (unsigned long long)rc_cfg.count, rc, (unsigned long long)r.n_matches, o.n_matches);
+            for (size_t i = 0; i < r.n_matches && i < o.n_matches; i++)
+                CHECK(!strcmp(r.matches[i].address, o.matches[i].gen.address) && !memcmp(r.matches[i].key, o.matches[i].key, 32), "case %d: random match %zu", t, i);
+            vo_scan_free(&o);
+            vgen_scan_result_free(&r);
+            vgen_destroy(cs[0]);
+            continue;
+        }
+        auto want = oracle_range((int)pt.fmt, pt.p, pt.ci, lo, hi);
+        vgen_scan_config cfg = range_cfg(pt.fmt, lo, hi, count);
+        cfg.case_insensitive = pt.ci;
+        vgen_scan_result r;
+        const int rc = n_ctx == 1 ? vgen_scan(cs[0], pt.p, &cfg, nullptr, nullptr, nullptr, &r)
+                                  : vgen_scan_multi(cs, n_ctx, pt.p, &cfg, nullptr, nullptr, nullptr, &r);
+        auto got = got_of(r);
+        const size_t expect = (size_t)std::min<uint64_t>(count, want.size());
+        char what[256];
+        snprintf(what, sizeof what, "case %d: fmt %u '%s'%s [%llx, +%llu] count %lld ctx %u cap %u victim %d: rc=%d n=%zu/%zu (want %zu)", t, pt.fmt, pt.p,
+                 pt.ci ? " -i" : "", (unsigned long long)lo, (unsigned long long)len, (long long)count, n_ctx, cap, victim, rc, got.size(), expect, want.size());
+        CHECK(rc == VGEN_OK, "%s: %s", what, vgen_last_error(cs[0]));
+        CHECK(got.size() == expect, "%s", what);
+        if (n_ctx == 1 || count == UINT64_MAX) {
+            // one context walks in key order; an unbounded scan of several returns everything, sorted
+            CHECK(got == Pairs(want.begin(), want.begin() + std::min(expect, want.size())), "%s: not the oracle's first matches", what);
+        } else {
+            // several contexts racing to `count`: which of the range's matches made it depends on their speeds
+            for (auto &m : got) CHECK(std::find(want.begin(), want.end(), m) != want.end(), "%s: %s is not a match of the range", what, m.first.c_str());
+            for (size_t i = 1; i < got.size(); i++) CHECK(got[i] != got[i - 1], "%s: duplicate", what);
+        }
+        if (count == UINT64_MAX) {
+            const uint64_t batches = (len + BATCH - 1) / BATCH;
+            CHECK(r.complete == 1 && r.operations == batches * BATCH, "%s: complete=%d ops=%llu", what, r.complete, (unsigned long long)r.operations);
+        }
+        // (the victim fails only if it gets to its k-th dispatch before the scan ends)
+        CHECK(r.failed_shards == 0 || (victim >= 0 && r.failed_shards == 1), "%s: failed_shards=%d", what, r.failed_shards);
+        vgen_scan_result_free(&r);
+        for (uint32_t i = 0; i < n_ctx; i++) vgen_destroy(cs[i]);
+    }
+}
+
 int main(int argc, char **argv) {
     const std::map<std::string, std::function<void()>> all = {
         {"range_scan", sc_range_scan}, {"stop_flag", sc_stop_flag}, {"checkpoint", sc_checkpoint}, {"multi_context", sc_multi_context},
         {"ring_growth", sc_ring_growth_and_host_filter}, {"failure_takeover", sc_failure_takeover}, {"random_keys", sc_random_keys},
-        {"endo_and_formats", sc_endo_and_formats}, {"dispatch_api", sc_dispatch_api}, {"edge_ranges", sc_edge_ranges}};
+        {"endo_and_formats", sc_endo_and_formats}, {"dispatch_api", sc_dispatch_api}, {"edge_ranges", sc_edge_ranges}, {"fuzz", sc_fuzz}};
     std::vector<std::string> run;
     for (int i = 1; i < argc; i++) run.push_back(argv[i]);
     if (run.empty())
