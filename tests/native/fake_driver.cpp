@@ -436,6 +436,7 @@ static void sc_fuzz() {
         {2, "^3[A-C]", 0}, {2, "^3", 0}, {2, "z$", 0},
         {4, "^1[D-F]", 0}, {4, "[a-f]{3}", 0},
         {5, "^0x[0-3]", 0}, {5, "^0xA", 1}, {5, "f$", 0}, {5, "^0x[A-F]", 0},
+        {3, "^bc1p[ac]", 0}, {3, "q$", 0},
     };
     const char *es = getenv("VGEN_FAKE_FUZZ_SEED"), *ec = getenv("VGEN_FAKE_FUZZ_CASES");
     uint64_t x = es ? strtoull(es, nullptr, 0) : 20261004ull;
@@ -461,6 +462,35 @@ static void sc_fuzz() {
         if (n_ctx > 1 && rnd(3) == 0) {
             victim = (int)rnd(n_ctx);
             vgen_debug_fail_after(cs[victim], rnd(3));
+        }
+        if (pt.fmt != 3 && rnd(8) == 0) {
+            // a vanity search on endomorphism contexts (six images per point, random bases): every match re-derives on the
+            // oracle from its key and satisfies the pattern, no key twice
+            for (uint32_t i = 0; i < n_ctx; i++) vgen_destroy(cs[i]);
+            for (uint32_t i = 0; i < n_ctx; i++) cs[i] = make_ctx(pt.fmt, 2 + (uint32_t)rnd(3), cap, VGEN_FLAG_ENDO);
+            vgen_scan_config e;
+            memset(&e, 0, sizeof e);
+            e.struct_size = sizeof e;
+            e.format = pt.fmt;
+            e.case_insensitive = pt.ci;
+            e.count = 1 + rnd(20);
+            e.max_batches = 40;
+            vgen_scan_result r;
+            const int rc = n_ctx == 1 ? vgen_scan(cs[0], pt.p, &e, nullptr, nullptr, nullptr, &r) : vgen_scan_multi(cs, n_ctx, pt.p, &e, nullptr, nullptr, nullptr, &r);
+            CHECK(rc == VGEN_OK && r.n_matches <= e.count, "case %d: endo fmt %u '%s' ctx %u: rc=%d n=%llu", t, pt.fmt, pt.p, n_ctx, rc, (unsigned long long)r.n_matches);
+            char rerr[128];
+            vo_regex *re = vo_regex_new(pt.p, pt.ci, rerr, sizeof rerr);
+            for (uint64_t i = 0; i < r.n_matches; i++) {
+                vo_generated g;
+                CHECK(vo_generate((int)pt.fmt, r.matches[i].key, &g) && !strcmp(g.address, r.matches[i].address) && !strcmp(g.wif, r.matches[i].wif),
+                      "case %d: endo match %llu does not re-derive", t, (unsigned long long)i);
+                CHECK(re && vo_regex_is_match(re, r.matches[i].address), "case %d: endo match %s does not satisfy '%s'", t, r.matches[i].address, pt.p);
+                for (uint64_t j = 0; j < i; j++) CHECK(memcmp(r.matches[i].key, r.matches[j].key, 32) != 0, "case %d: endo duplicate key", t);
+            }
+            if (re) vo_regex_free(re);
+            vgen_scan_result_free(&r);
+            for (uint32_t i = 0; i < n_ctx; i++) vgen_destroy(cs[i]);
+            continue;
         }
         if (n_ctx == 1 && rnd(5) == 0) {
             // an independent random key per candidate (seeded stream): the oracle's walk of the same stream, in order

@@ -1,0 +1,27 @@
+"""The C driver of tests/native/fake_driver.cpp linked against the REAL libvgen_hip.so (tests/native/scan_driver_hip, built
+by __graft_entry__.build()): the scenarios the host sanitizer runs walk over the CPU stand-in of the runtime — range scans
+with progress, stop flag, checkpoint / resume, striped contexts, ring growth and host-filtered dumps, failing contexts taken
+over, random keys, endomorphism images, the frame-level API, ranges cut anywhere — and its seeded random walk over formats x
+pattern kinds x ranges x counts x contexts x frames x ring sizes x injected failures, here through runtime.cpp and the
+kernels on the MI355X, every result checked against the oracle by the driver itself."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DRIVER = os.path.join(HERE, "native", "scan_driver_hip")
+SCENARIOS = ["range_scan", "stop_flag", "checkpoint", "multi_context", "ring_growth", "failure_takeover", "random_keys",
+             "endo_and_formats", "dispatch_api", "edge_ranges", "fuzz"]
+
+
+@pytest.mark.parametrize("seed, cases", [(20261004, 150), (77, 150)])
+def test_scan_driver_scenarios_and_random_walk_on_the_device(seed, cases):
+    assert os.path.exists(DRIVER), "tests/native/scan_driver_hip is built by __graft_entry__.build()"
+    env = dict(os.environ, VGEN_FAKE_FUZZ_SEED=str(seed), VGEN_FAKE_FUZZ_CASES=str(cases))
+    p = subprocess.run([DRIVER], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and "CHECK FAILED" not in p.stderr, (p.stdout[-1500:], p.stderr[-3000:])
+    for name in SCENARIOS:
+        assert any(line.startswith(name) and " ok " in line for line in p.stdout.splitlines()), (name, p.stdout)
