@@ -1,0 +1,148 @@
+"""A seeded random walk over the frame-level C ABI on the MI355X: contexts of several formats (one with six images per point)
+on which sequential, explicit-scalar and random-stream dispatches, filter changes (prefilter / on-device automaton / dump
+mode) and ring resizes follow each other in random order on random frames, several frames in flight — every completed
+dispatch checked against the oracle (dump mode: all payloads; filter mode: every candidate's payload, and the confirmed
+set against the oracle's regex over ALL keys of the dispatch).  What the hand-written parity tests fix one at a time —
+mode of the previous dispatch on the same frame, leftovers in a dump buffer, ring position, table state — varies here."""
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+PATTERNS = {
+    0: [("^1[A-C]", False), ("^1c", True), ("[A-Z]{3}", False), ("Q$", False), ("^1Cat", False)],
+    1: [("^bc1q[ac]", False), ("a$", False), ("xyz", False)],
+    3: [("^bc1p[ac]", False), ("qq$", False)],
+    5: [("^0x[0-3]", False), ("^0xa", True), ("ff$", True)],
+}
+
+
+def variant_key(k, v):
+    kv = pow(LAMBDA, v % 3, N) * k % N
+    return N - kv if v >= 3 else kv
+
+
+@pytest.fixture(scope="module")
+def vg():
+    import vgen_amd
+    assert vgen_amd.device_count() >= 1, "no HIP device: the gpu-marked tests need an MI355X"
+    return vgen_amd
+
+
+@pytest.fixture(scope="module")
+def vo():
+    from oracle import pyoracle
+    return pyoracle
+
+
+@pytest.mark.parametrize("fmt, endo, seed", [(0, False, 1), (5, False, 2), (0, True, 3), (1, False, 4), (3, False, 5), (5, True, 6)])
+def test_random_walk_over_dispatch_wait_and_filter_changes(vg, vo, fmt, endo, seed):
+    import vgen_amd.api as api
+    rng = random.Random(seed + 1000 * int(os.environ.get("VGEN_WALK_SEED", "0")))   # (VGEN_WALK_SEED / VGEN_WALK_STEPS: longer walks by hand)
+    batch, F = 8192, 4
+    plen = 32 if fmt == 3 else 20
+    images = 6 if endo else 1
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=F, match_cap=4096, endo=endo, timing=False)
+    pats = [None] + [(vg.Pattern(p, ci, vg.AddressFormat(fmt)), vo.Regex(p, ci)) for p, ci in PATTERNS[fmt]]
+    pats = [x for x in pats if x is None or x[0].device_kind != 0]
+    current = None
+    r.set_filter(None)
+    in_flight = {}
+    waits = 0
+
+    def addr(pl):   # the oracle's address of a payload
+        return vo.segwit_addr("bc", 1, pl) if fmt == 3 else vo.address_from_hash160(fmt, pl)
+
+    def keys_of(kind, arg):
+        """the dispatch's scalars by lane (None: no key there / not a valid scalar)"""
+        if kind == "seq":
+            return [arg + i if arg + i < N else None for i in range(batch)]
+        if kind == "keys":
+            return [k if 0 < k < N else None for k in arg] + [None] * (batch - len(arg))
+        s, st, first = arg
+        return [vo.random_key(s, st, first + i) for i in range(batch)]
+
+    def check(frame):
+        kind, arg, mode = in_flight.pop(frame)
+        got, n_found, tested = r.await_result(frame)
+        ks = keys_of(kind, arg)
+        n_lanes = len(arg) if kind == "keys" else batch
+        assert tested == images * n_lanes, (kind, tested)
+        if kind == "seq" and arg + batch < N:
+            base = vo.payload_seq(fmt, arg, batch)
+            pl0 = [base[plen * i:plen * (i + 1)] for i in range(batch)]
+        else:
+            pl0 = [vo.payload(fmt, k) if k is not None else None for k in ks]
+
+        def want(slot):   # oracle payload of dump / ring slot v * batch + i
+            v, i = divmod(slot, batch)
+            if ks[i] is None:
+                return None
+            return pl0[i] if v == 0 else vo.payload(fmt, variant_key(ks[i], v))
+        if mode is None:
+            assert len(got) == images * batch * plen
+            slots = range(batch) if not endo else list(range(batch)) + [rng.randrange(batch, images * batch) for _ in range(300)]
+            for s in slots:
+                w = want(s)
+                assert got[plen * s:plen * (s + 1)] == (w if w is not None else bytes(plen)), (kind, s)
+            return
+        pat, ore = mode
+        stored = {}
+        for s, pl in got:
+            assert s not in stored and pl == want(s), (kind, s)
+            stored[s] = pl
+        if n_found > r.match_cap:
+            return   # ring overflow: what is stored is right, the rest was dropped (vgen_scan grows the ring then)
+        confirmed = sorted(s for s, pl in stored.items() if ore.matches(addr(pl)))
+        if endo and kind != "keys":
+            # the expected set needs all 6 x batch payloads: sample the images, take image 0 in full
+            expect0 = [i for i in range(batch) if pl0[i] is not None and ore.matches(addr(pl0[i]))]
+            assert [s for s in confirmed if s < batch] == expect0
+            for s in [rng.randrange(batch, images * batch) for _ in range(200)]:
+                w = want(s)
+                assert (s in confirmed) == (w is not None and bool(ore.matches(addr(w)))), s
+        else:
+            n_slots = images * batch if kind != "keys" else None
+            slots = range(n_slots) if n_slots else [v * batch + i for v in range(images) for i in range(len(arg))]
+            expect = [s for s in slots if want(s) is not None and ore.matches(addr(want(s)))]
+            assert confirmed == expect, (kind, len(confirmed), len(expect))
+
+    for _ in range(int(os.environ.get("VGEN_WALK_STEPS", "70"))):
+        free = [f for f in range(F) if f not in in_flight]
+        x = rng.random()
+        if in_flight and (not free or x < 0.4):
+            check(rng.choice(sorted(in_flight)))
+            waits += 1
+        elif not in_flight and x < 0.55:
+            current = rng.choice(pats)
+            r.set_filter(current[0] if current else None)
+            if rng.random() < 0.3:
+                cap = rng.choice([256, 1024, 4096, 16384])
+                assert api._L.vgen_set_match_cap(r._h, cap) == 0
+                r.match_cap = cap
+        else:
+            f = rng.choice(free)
+            kind = rng.choice(["seq", "seq", "keys", "random"])
+            if kind == "seq":
+                arg = rng.choice([rng.randrange(1, N - batch - 100), rng.randrange(1, 2**64), N - batch + rng.randrange(-3000, 3000) - 40,
+                                  (rng.randrange(1, N) >> rng.randrange(0, 250)) or 1])
+                arg = max(1, min(arg, N - 1))
+                r.dispatch(arg, f)
+            elif kind == "keys":
+                n = rng.choice([1, 7, 300, 1500])
+                arg = [rng.choice([rng.randrange(1, N), rng.randrange(1, 2**32), 0, N, N - 1, 2**256 - 1]) if rng.random() < 0.1 else rng.randrange(1, N)
+                       for _ in range(n)]
+                r.dispatch_keys(arg, f)
+            else:
+                arg = (rng.randrange(1, 2**64), rng.randrange(0, 2**32), rng.choice([0, rng.randrange(2**64 - batch), 2**64 - batch]))
+                r.dispatch_random(arg[0], arg[1], arg[2], f)
+            in_flight[f] = (kind, arg, current)
+    for f in sorted(in_flight):
+        check(f)
+        waits += 1
+    assert waits >= 15
+    r.close()
