@@ -203,3 +203,74 @@ def test_device_full_match_algorithm_equals_exact_dfa(core, fmt):
         else:
             assert dev == exact, (pat, [a for a, d, e in zip(addrs, dev, exact) if d != e][:3])
     assert n_dfa >= 5
+
+
+def generalise(rng, a, head, alphabet, fmt):
+    """A pattern that matches address `a`, made from it the way users write vanity patterns: an anchored prefix and/or
+    suffix (or a piece of the middle) in which characters are replaced by classes, dots, alternatives, optional characters
+    and counted wildcards.  Returns (pattern, case_insensitive)."""
+    def soften(piece):
+        out = []
+        for c in piece:
+            x = rng.random()
+            if x < 0.55:
+                out.append(re.escape(c))
+            elif x < 0.75:
+                members = {c} | {rng.choice(alphabet) for _ in range(rng.randrange(1, 4))}
+                out.append("[" + "".join(sorted(members)) + "]")
+            elif x < 0.85:
+                out.append(".")
+            elif x < 0.92:
+                out.append("(?:" + re.escape(c) + "|" + re.escape(rng.choice(alphabet)) + rng.choice(["", re.escape(rng.choice(alphabet))]) + ")")
+            else:
+                out.append(re.escape(c) + re.escape(rng.choice(alphabet)) + "?")
+        return "".join(out)
+    ci = rng.random() < 0.25
+    kind = rng.choice(["prefix", "prefix", "suffix", "both", "middle", "gap"])
+    k = rng.randrange(1, 5)
+    body = a[head:]
+    if kind == "prefix":
+        pat = "^" + re.escape(a[:head]) + soften(body[:k])
+    elif kind == "suffix":
+        pat = soften(a[-k:]) + "$"
+    elif kind == "both":
+        pat = "^" + re.escape(a[:head]) + soften(body[:k]) + ".*" + soften(a[-rng.randrange(1, 3):]) + "$"
+    elif kind == "middle":
+        i = rng.randrange(head, len(a) - k)
+        pat = soften(a[i:i + k])
+    else:
+        g = rng.randrange(0, 4)
+        pat = "^" + re.escape(a[:head]) + ".{%d}" % g + soften(body[g:g + k])
+    if ci:
+        pat = "".join(ch.swapcase() if ch.isalpha() and rng.random() < 0.5 and fmt != 5 else ch for ch in pat) if "\\" not in pat and "(?" not in pat else pat
+    return pat, ci
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2, 3, 4, 5])
+def test_generalised_patterns_never_lose_a_match_to_the_device_test(core, fmt):
+    """The failure a vanity scanner must not have is the silent one: a device test that rejects an address the pattern
+    accepts.  120 patterns per format (VGEN_PATTERN_WALK: more by hand) grown from real addresses (classes, dots, alternatives, optional characters, gaps,
+    either case) — each accepts at least the address it grew from —: exact DFA == oracle regex on every address, and the
+    device test (hash160 ranges / bit masks / checksum masks, or 'pass everything' ahead of the on-device automaton)
+    accepts whatever the DFA accepts."""
+    rng = random.Random(900 + fmt)
+    pb = 32 if fmt == 3 else 20
+    payloads = [bytes(rng.randrange(256) for _ in range(pb)) for _ in range(700)]
+    payloads += [bytes(k) + bytes(rng.randrange(256) for _ in range(pb - k)) for k in (1, 2, 3) for _ in range(30)]
+    addrs = [address(core, fmt, p) for p in payloads]
+    head = {0: 1, 4: 1, 2: 1, 1: 4, 3: 4, 5: 2}[fmt]
+    alphabet = {0: "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz", 1: "qpzry9x8gf2tvdw0s3jn54khce6mua7l",
+                5: "0123456789abcdefABCDEF"}
+    alphabet = alphabet.get(fmt, alphabet[0] if fmt in (2, 4) else alphabet[1])
+    kinds = {}
+    for n in range(int(os.environ.get("VGEN_PATTERN_WALK", "120"))):
+        a = rng.choice(addrs)
+        pat, ci = generalise(rng, a, head, alphabet, fmt)
+        kind, sel, dev, exact = check(core, pat, ci, fmt, payloads)
+        kinds[kind] = kinds.get(kind, 0) + 1
+        ore = vo.Regex(pat, ci)
+        assert exact == [int(ore.matches(x)) for x in addrs], (pat, ci)
+        assert exact[addrs.index(a)] == 1, (pat, ci, a)      # it accepts the address it grew from
+        for d, e, x in zip(dev, exact, addrs):
+            assert d or not e, f"device test rejected a real match: {pat!r} ci={ci} {x}"
+    assert len(kinds) >= 2, kinds    # the walk reached more than one kind of device test
