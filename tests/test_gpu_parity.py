@@ -229,6 +229,51 @@ def test_filter_mode_equals_dfa_over_dump(vg, vo, fmt, pattern, ci):
     r.close()
 
 
+@pytest.mark.parametrize("fmt", [0, 1, 2, 3, 4, 5])
+def test_generated_patterns_on_the_device(vg, vo, fmt):
+    """Patterns grown from addresses of the dispatch itself (tests/test_host_pattern_filter.py: classes, dots, alternatives,
+    optional characters, gaps, either case; anchored prefixes, suffixes, both, pieces of the middle) through whichever device
+    test they compile to — ranges, masks, checksum masks, the on-device automaton —: every candidate's payload is the
+    dump's, and the confirmed set equals the oracle's regex over all 2^16 addresses of the dispatch."""
+    import random
+    from test_host_pattern_filter import generalise
+    rng = random.Random(4000 + fmt)
+    batch = 1 << 16
+    plen = 32 if fmt == 3 else 20
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), match_cap=65536, frames=2)
+    start = vo.seed_key(43, fmt)
+    blob = dump(r, start)
+    assert blob == vo.payload_seq(fmt, start, batch)
+    addr_of = (lambda pl: vo.segwit_addr("bc", 1, pl)) if fmt == 3 else (lambda pl: vo.address_from_hash160(fmt, pl))
+    addrs = [addr_of(blob[plen * i:plen * (i + 1)]) for i in range(batch)]
+    head = {0: 1, 4: 1, 2: 1, 1: 4, 3: 4, 5: 2}[fmt]
+    alphabet = {1: "qpzry9x8gf2tvdw0s3jn54khce6mua7l", 3: "qpzry9x8gf2tvdw0s3jn54khce6mua7l", 5: "0123456789abcdefABCDEF"}.get(
+        fmt, "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz")
+    kinds = {}
+    import os
+    for _ in range(int(os.environ.get("VGEN_PATTERN_WALK", "60"))):
+        a = rng.choice(addrs)
+        pattern, ci = generalise(rng, a, head, alphabet, fmt)
+        p = vg.Pattern(pattern, ci, vg.AddressFormat(fmt))
+        kinds[p.device_kind] = kinds.get(p.device_kind, 0) + 1
+        if p.device_kind == 0:
+            continue
+        ore = vo.Regex(pattern, ci)
+        expect = [i for i, x in enumerate(addrs) if ore.matches(x)]
+        assert addrs.index(a) in expect
+        r.set_filter(p)
+        r.dispatch(start, 1)
+        recs, n_found, _ = r.await_result(1)
+        if n_found > r.match_cap:
+            continue      # nearly every key is a candidate (a one-symbol class): the scan would filter dumps on the host
+        for i, payload in recs:
+            assert payload == blob[plen * i:plen * (i + 1)]
+        confirmed = [i for i, payload in recs if ore.matches(addr_of(payload))]
+        assert confirmed == expect, (pattern, ci, p.device_kind, len(confirmed), len(expect))
+    assert sum(v for k, v in kinds.items() if k != 0) >= 12, kinds
+    r.close()
+
+
 def test_scan_finds_first_match_like_reference_cpu_path(vg, vo):
     # BASELINE config 1/2 shape: generate -p ^1Cat -f p2pkh -c 1 with a fixed seed
     r = vg.GpuRunner(batch_size=1 << 20, fmt=vg.AddressFormat.P2pkh)

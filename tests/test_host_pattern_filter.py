@@ -249,7 +249,7 @@ def generalise(rng, a, head, alphabet, fmt):
 @pytest.mark.parametrize("fmt", [0, 1, 2, 3, 4, 5])
 def test_generalised_patterns_never_lose_a_match_to_the_device_test(core, fmt):
     """The failure a vanity scanner must not have is the silent one: a device test that rejects an address the pattern
-    accepts.  120 patterns per format (VGEN_PATTERN_WALK: more by hand) grown from real addresses (classes, dots, alternatives, optional characters, gaps,
+    accepts.  80 patterns per format (VGEN_PATTERN_WALK: more by hand) grown from real addresses (classes, dots, alternatives, optional characters, gaps,
     either case) — each accepts at least the address it grew from —: exact DFA == oracle regex on every address, and the
     device test (hash160 ranges / bit masks / checksum masks, or 'pass everything' ahead of the on-device automaton)
     accepts whatever the DFA accepts."""
@@ -263,7 +263,9 @@ def test_generalised_patterns_never_lose_a_match_to_the_device_test(core, fmt):
                 5: "0123456789abcdefABCDEF"}
     alphabet = alphabet.get(fmt, alphabet[0] if fmt in (2, 4) else alphabet[1])
     kinds = {}
-    for n in range(int(os.environ.get("VGEN_PATTERN_WALK", "120"))):
+    blob = b"".join(payloads)
+    core.core_dfa_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    for n in range(int(os.environ.get("VGEN_PATTERN_WALK", "80"))):
         a = rng.choice(addrs)
         pat, ci = generalise(rng, a, head, alphabet, fmt)
         kind, sel, dev, exact = check(core, pat, ci, fmt, payloads)
@@ -273,4 +275,14 @@ def test_generalised_patterns_never_lose_a_match_to_the_device_test(core, fmt):
         assert exact[addrs.index(a)] == 1, (pat, ci, a)      # it accepts the address it grew from
         for d, e, x in zip(dev, exact, addrs):
             assert d or not e, f"device test rejected a real match: {pat!r} ci={ci} {x}"
+        if kind == 4:
+            # the on-device automaton over the encoded address (core/dfa_eval.h, run on the host): exactly the DFA's verdict
+            # (Ethereum: the case-folded language, a superset the host's exact DFA then confirms)
+            flags = ctypes.create_string_buffer(len(payloads))
+            assert core.core_dfa_check(pat.encode(), int(ci), fmt, blob, len(payloads), flags) == 4
+            full = [b & 1 for b in flags.raw]
+            if fmt == 5:
+                assert all(f or not e for f, e in zip(full, exact)), pat
+            else:
+                assert full == exact, (pat, ci)
     assert len(kinds) >= 2, kinds    # the walk reached more than one kind of device test
