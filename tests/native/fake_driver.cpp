@@ -440,7 +440,7 @@ static void sc_fuzz() {
     };
     const char *es = getenv("VGEN_FAKE_FUZZ_SEED"), *ec = getenv("VGEN_FAKE_FUZZ_CASES");
     uint64_t x = es ? strtoull(es, nullptr, 0) : 20261004ull;
-    const int cases = ec ? atoi(ec) : 16;
+    const int cases = ec ? atoi(ec) : 12;
     auto rnd = [&x](uint64_t n) {   // xorshift64*
         x ^= x >> 12;
         x ^= x << 25;

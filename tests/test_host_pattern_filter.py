@@ -249,7 +249,7 @@ def generalise(rng, a, head, alphabet, fmt):
 @pytest.mark.parametrize("fmt", [0, 1, 2, 3, 4, 5])
 def test_generalised_patterns_never_lose_a_match_to_the_device_test(core, fmt):
     """The failure a vanity scanner must not have is the silent one: a device test that rejects an address the pattern
-    accepts.  80 patterns per format (VGEN_PATTERN_WALK: more by hand) grown from real addresses (classes, dots, alternatives, optional characters, gaps,
+    accepts.  50 patterns per format (VGEN_PATTERN_WALK: more by hand) grown from real addresses (classes, dots, alternatives, optional characters, gaps,
     either case) — each accepts at least the address it grew from —: exact DFA == oracle regex on every address, and the
     device test (hash160 ranges / bit masks / checksum masks, or 'pass everything' ahead of the on-device automaton)
     accepts whatever the DFA accepts."""
@@ -265,7 +265,7 @@ def test_generalised_patterns_never_lose_a_match_to_the_device_test(core, fmt):
     kinds = {}
     blob = b"".join(payloads)
     core.core_dfa_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
-    for n in range(int(os.environ.get("VGEN_PATTERN_WALK", "80"))):
+    for n in range(int(os.environ.get("VGEN_PATTERN_WALK", "50"))):
         a = rng.choice(addrs)
         pat, ci = generalise(rng, a, head, alphabet, fmt)
         kind, sel, dev, exact = check(core, pat, ci, fmt, payloads)

@@ -8,7 +8,7 @@ ThreadSanitizer and with AddressSanitizer + UBSan.  tests/native/fake_driver.cpp
 scenarios (range scan with progress callback, stop flag from another thread, checkpoint / resume, three striped contexts,
 ring growth + host-filter pool, a failing context taken over by the others, random keys, endomorphism images and the other
 formats, the frame-level API, ranges that are not whole batches incl. the end of the key space) and a randomised walk over
-formats x pattern kinds x ranges x counts x contexts x ring sizes x injected failures (`fuzz`: 16 cases here, more with
+formats x pattern kinds x ranges x counts x contexts x ring sizes x injected failures (`fuzz`: 12 cases here, more with
 VGEN_FAKE_FUZZ_CASES / VGEN_FAKE_FUZZ_SEED), and checks every result against the oracle.  CPU only: no sanitizer runs on the GPU box.
 """
 import os

@@ -271,11 +271,11 @@ def test_patterns_too_large_to_determinise_are_matched_by_walking_the_nfa(core, 
     flags = re.I if ci else 0
     hits = 0
     ora = vo.Regex(pat, ci)
-    for _ in range(200):   # (the test shim compiles the pattern per call: ~25 ms each)
+    for _ in range(90):   # (the test shim compiles the pattern per call: ~25 ms each)
         head = "".join(rng.choice("abAxX1 c") for _ in range(rng.randrange(0, 9)))
         tail = "".join(rng.choice("abxA") if rng.random() < 0.04 else rng.choice("ab") for _ in range(rng.randrange(8, 36)))
         text = rng.choice(["", "1"]) + head + rng.choice(["a", "x", "bb", "A", "X"]) + tail
         want = int(re.search(pat, text, flags) is not None)
         assert product(core, pat, ci, text) == want == int(ora.matches(text)), (pat, text)
         hits += want
-    assert 0 < hits < 200, hits
+    assert 0 < hits < 90, hits
