@@ -1393,3 +1393,12 @@ def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vg, vo, monke
     for i in range(0, batch, 61):
         assert blob[20 * i:20 * i + 20] == vo.payload(0, vo.random_key(3, 0, i))
     r.close()
+    # the command line says so too (what a scan absorbs must not pass unseen), and only then
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgen_amd", "vgen-hip")
+    p = subprocess.run([cli, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "Warning: device 0: wide generator table unavailable" in p.stderr and len(p.stdout.split()) == 1
+    env = {k: v for k, v in os.environ.items() if k != "VGEN_DEBUG_GTAB_FAIL"}
+    q = subprocess.run([cli, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120, env=env)
+    assert q.returncode == 0 and "Warning: device" not in q.stderr and q.stdout == p.stdout

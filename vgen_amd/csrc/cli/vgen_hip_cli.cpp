@@ -407,6 +407,14 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
                                   : vgen_scan_multi(ctxs.data(), (uint32_t)ctxs.size(), pattern.c_str(), &cfg, nullptr,
                                                     nullptr, &g_stop, &res);
         if (rc != VGEN_OK) die(vgen_last_error(ctxs[0]));
+        // what the scan absorbed must not pass unseen: a device that failed (the others took its ranges over), a generator
+        // table that could not be had (the scan went on with the small one, at a third of the rate)
+        if (res.failed_shards > 0)
+            fprintf(stderr, "Warning: %d of %zu devices failed during the scan; the remaining ones took their ranges over\n", res.failed_shards, ctxs.size());
+        for (size_t i = 0; i < ctxs.size(); i++) {
+            const char *note = vgen_last_error(ctxs[i]);
+            if (rep == 0 && note && *note) fprintf(stderr, "Warning: device %zu: %s\n", i, note);
+        }
         for (uint64_t i = 0; i < res.n_matches; i++) all.push_back(res.matches[i]);
         total_ops += res.operations;
         total_secs += res.elapsed_secs;
