@@ -1402,3 +1402,22 @@ def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vg, vo, monke
     env = {k: v for k, v in os.environ.items() if k != "VGEN_DEBUG_GTAB_FAIL"}
     q = subprocess.run([cli, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120, env=env)
     assert q.returncode == 0 and "Warning: device" not in q.stderr and q.stdout == p.stdout
+
+
+def test_cli_progress_line_only_on_a_terminal(vg):
+    """The reference's spinner (src/lib.rs:783-805) lives on stderr, only when that is a terminal and not with --quiet: the CLI
+    redraws "[elapsed] Checked N addresses" there from the scan's progress callback and clears it before the results.
+    (The GPU boxes have no pty devices: VGEN_PROGRESS=1 stands in for the terminal.)"""
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgen_amd", "vgen-hip")
+    args = [cli, "range", "-r", "1:3ffffffff", "-p", "^1ZZZZZZZZZ", "-o", "minimal"]      # 2^34 keys, no match: a second or so
+    forced = dict(os.environ, VGEN_PROGRESS="1")
+    p = subprocess.run(args, capture_output=True, text=True, timeout=120, env=forced)
+    assert p.returncode == 0 and p.stdout == "" and "Checked " in p.stderr and " addresses" in p.stderr
+    assert p.stderr.rstrip().endswith(")") and "No match found after 17,179,869,184 operations" in p.stderr.split("\x1b[K")[-1]
+    p = subprocess.run(args + ["-q"], capture_output=True, text=True, timeout=120, env=forced)
+    assert p.returncode == 0 and "Checked" not in p.stderr
+    plain = {k: v for k, v in os.environ.items() if k != "VGEN_PROGRESS"}
+    q = subprocess.run(args, capture_output=True, text=True, timeout=120, env=plain)      # stderr is a pipe: no progress line
+    assert q.returncode == 0 and "Checked" not in q.stderr and "No match found after" in q.stderr

@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -352,6 +354,33 @@ int run_estimate(Opts &o) {
     return 0;
 }
 
+// The reference's spinner line (src/lib.rs:783-805: "[elapsed] Checked N addresses", hidden when stderr is not a terminal and
+// with --quiet): redrawn at most ten times a second from the scan's progress callback.
+struct Progress {
+    uint64_t base = 0;      // operations of the finished --repeat rounds
+    double last = 0, t0 = 0;
+    bool shown = false;
+};
+double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void progress_cb(uint64_t ops, void *user) {
+    Progress *p = static_cast<Progress *>(user);
+    const double t = now_s();
+    if (t - p->last < 0.1) return;
+    p->last = t;
+    p->shown = true;
+    const unsigned secs = (unsigned)(t - p->t0);
+    fprintf(stderr, "\r[%02u:%02u:%02u] Checked %s addresses\x1b[K", secs / 3600, secs / 60 % 60, secs % 60, with_commas(p->base + ops).c_str());
+    fflush(stderr);
+}
+void progress_clear(Progress &p) {
+    if (p.shown) fprintf(stderr, "\r\x1b[K");
+    p.shown = false;
+}
+
 int run_search(const Opts &o, const std::string &pattern, bool has_range, const uint8_t start[32], const uint8_t end[32]) {
     if (o.no_gpu) die("--no-gpu: this build has no CPU scan path (the MI355X engine is the only backend)");
     const int fmt = format_id(o.format);
@@ -401,11 +430,16 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
     std::vector<vgen_generated> all;
     uint64_t total_ops = 0;
     double total_secs = 0;
+    Progress prog;
+    prog.t0 = now_s();
+    const bool show_progress = !o.quiet && (isatty(2) || getenv("VGEN_PROGRESS") != nullptr);   // (VGEN_PROGRESS=1: also into a pipe or a log)
     for (uint64_t rep = 0; rep < (o.repeat ? o.repeat : 1) && !g_stop; rep++) {   // lib.rs:825-865
         vgen_scan_result res;
-        int rc = ctxs.size() == 1 ? vgen_scan(ctxs[0], pattern.c_str(), &cfg, nullptr, nullptr, &g_stop, &res)
-                                  : vgen_scan_multi(ctxs.data(), (uint32_t)ctxs.size(), pattern.c_str(), &cfg, nullptr,
-                                                    nullptr, &g_stop, &res);
+        prog.base = total_ops;
+        int rc = ctxs.size() == 1 ? vgen_scan(ctxs[0], pattern.c_str(), &cfg, show_progress ? progress_cb : nullptr, &prog, &g_stop, &res)
+                                  : vgen_scan_multi(ctxs.data(), (uint32_t)ctxs.size(), pattern.c_str(), &cfg, show_progress ? progress_cb : nullptr,
+                                                    &prog, &g_stop, &res);
+        progress_clear(prog);
         if (rc != VGEN_OK) die(vgen_last_error(ctxs[0]));
         // what the scan absorbed must not pass unseen: a device that failed (the others took its ranges over), a generator
         // table that could not be had (the scan went on with the small one, at a third of the rate)
