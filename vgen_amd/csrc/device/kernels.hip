@@ -238,70 +238,11 @@ struct SeqWaves {
                                  : FMT == VGF_P2PKH_UNCOMPRESSED ? VG_SEQ_WAVES_UNCOMP : 4;
 };
 
-// What every per-key kernel does with a payload: into the dump (dump mode; zeros where the lane has no key), or — when it passes
-// the dispatch's test, the prefilter or the automaton over the encoded address — into the frame's match ring (the counter is
-// monotonic: no per-dispatch reset, this dispatch's slots start at match_base; hipcc turns the atomicAdd of a wave into one).
-template <int NW, bool FULL, class ARGS>
-__device__ __forceinline__ void report_payload(const ARGS &args, u32 *dump, const u32 *dfa_lds, int fmt, u32 index, const u32 (&pl)[NW], bool ok) {
-    if (dump) {
-        u32 *o = dump + (size_t)index * NW;
-#pragma unroll
-        for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
-    } else if (ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, fmt, pl) : filter_eval_n<NW>(args.filter, pl))) {
-        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-        if (slot < args.match_cap) {
-            DevMatch *m = args.mrec + slot;
-            m->index = index;
-            m->reserved = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? pl[i] : 0u;
-        }
-    }
-}
-
-// The six endomorphism / negation images of the affine point (x, y) — (x, +-y), (beta x, +-y), (beta^2 x, +-y): the public keys of
-// k, lambda k, lambda^2 k and their negations — each hashed and reported at (s * 3 + e) * vstride + index (e = power of beta,
-// s = negated).  x waits in `xpark` (the workgroup's dead product-tree LDS) between the images, y — for the formats that hash
-// it whole — in `ypark`; compressed-key formats need only y's parity, flipped for the negations.  `in_range`: the lane has a
-// slot in the outputs at all; `ok`: it has a key.
-template <int FMT, bool FULL, int WGSZ, class ARGS>
-__device__ __forceinline__ void report_six_images(const ARGS &args, u32 *dump, u32 *xpark, u32 *ypark, const u32 *dfa_lds, int tid, const fe &x,
-                                                  const fe &y, u32 index, u32 vstride, bool in_range, bool ok) {
-    constexpr int NW = PayloadWords<FMT>::value;
-    constexpr bool NEEDS_Y = FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM;
-    const u32 ypar = y.n[0] & 1u;
-    lds_park_fe(xpark, WGSZ, tid, x);
-    if (NEEDS_Y) lds_park_fe(ypark, WGSZ, tid, y);
-#pragma unroll 1
-    for (u32 v = 0; v < 6; v++) {
-        const u32 e = v >> 1, sneg = v & 1u;   // (x,+) (x,-) (bx,+) (bx,-) (b^2 x,+) (b^2 x,-)
-        fe xe, ye;
-        lds_unpark_fe(xpark, WGSZ, tid, xe);
-        if (sneg == 0 && e > 0) {
-            fe beta;
-            fe_set_beta(beta);
-            fe_mul(xe, xe, beta);
-            fe_canonicalize_product(xe);
-            lds_park_fe(xpark, WGSZ, tid, xe);
-        }
-        if (NEEDS_Y) {
-            lds_unpark_fe(ypark, WGSZ, tid, ye);
-            if (sneg) {
-                fe ny;
-                fe_neg(ny, ye, 1);
-                fe_normalize(ny);      // p - y, canonical (y != 0 on this curve)
-                ye = ny;
-            }
-        } else {
-            ye.n[0] = ypar ^ sneg;     // all a compressed key reads of y
-        }
-        u32 ple[NW];
-        (void)payload_from_point<FMT>(xe, ye, ple);
-        if (!in_range) continue;
-        report_payload<NW, FULL>(args, dump, dfa_lds, (int)args.fmt, (sneg * 3u + e) * vstride + index, ple, ok);
-    }
-}
-
+// (The blocks that write a payload to the dump or the match ring, and the six-image loops of seq_bwd_kernel and keys_bwd_kernel,
+//  are written out in place on purpose: round 3 folded them into two shared __forceinline__ helpers — same instruction counts,
+//  2 787 VALU per key in the headline loop — and the Ethereum kernels lost 1-2.5 % to a different scalar-register allocation
+//  (one form re-read args.dump inside the per-key loop and waited for the scalar load; A/B on one box, tools/ab_fmt.sh).)
+//
 // ENDO (vanity searches; every format but P2TR, with a prefilter, the on-device DFA or in dump mode): every point is tested under its six
 // endomorphism / negation images — (x, +-y), (beta x, +-y), (beta^2 x, +-y), the public keys of k, lambda k, lambda^2 k and
 // their negations — so six keys are hashed for one point's arithmetic plus two multiplications by beta.  Image `variant`
@@ -370,6 +311,7 @@ seq_bwd_kernel(const SeqArgs args) {
     }
 
     const u32 half = args.n >> 1;
+    const bool dump = args.dump != nullptr;
     fe zrun;            // P2TR: running product of this lane's Z(Q)
     u32 step = 0;       // P2TR: key step 0 .. 2S-1 in loop order
 
@@ -449,15 +391,74 @@ seq_bwd_kernel(const SeqArgs args) {
 
             const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (ENDO) {
-                report_six_images<FMT == VGF_P2TR ? VGF_P2PKH : FMT, FULL, WG>(args, args.dump, tree, ypark, dfa_lds, tid, x3, y3, index,
-                                                                                   args.n, true, true);
+                // compressed-key formats need only the parity of y (flipped for the negations); the others the canonical
+                // y itself, parked beside x, and p - y for the negations
+                constexpr bool NEEDS_Y = FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM;
+                const u32 ypar = y3.n[0] & 1u;
+                lds_park_fe(tree, WG, tid, x3);
+                if (NEEDS_Y) lds_park_fe(ypark, WG, tid, y3);
+#pragma unroll 1
+                for (u32 v = 0; v < 6; v++) {
+                    const u32 e = v >> 1, sneg = v & 1u;   // (x,+) (x,-) (bx,+) (bx,-) (b^2 x,+) (b^2 x,-)
+                    fe xe, ye;
+                    lds_unpark_fe(tree, WG, tid, xe);
+                    if (sneg == 0 && e > 0) {
+                        fe beta;
+                        fe_set_beta(beta);
+                        fe_mul(xe, xe, beta);
+                        fe_canonicalize_product(xe);
+                        lds_park_fe(tree, WG, tid, xe);
+                    }
+                    if (NEEDS_Y) {
+                        lds_unpark_fe(ypark, WG, tid, ye);
+                        if (sneg) {
+                            fe ny;
+                            fe_neg(ny, ye, 1);
+                            fe_normalize(ny);      // p - y, canonical (y != 0 on this curve)
+                            ye = ny;
+                        }
+                    } else {
+                        ye.n[0] = ypar ^ sneg;     // all a compressed key reads of y
+                    }
+                    u32 ple[NW];
+                    (void)payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(xe, ye, ple);
+                    const u32 vindex = (sneg * 3u + e) * args.n + index;
+                    if (dump) {
+                        u32 *o = args.dump + (size_t)vindex * NW;
+#pragma unroll
+                        for (int i = 0; i < NW; i++) o[i] = ple[i];
+                    } else if (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple)) {
+                        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+                        if (slot < args.match_cap) {
+                            DevMatch *m = args.mrec + slot;
+                            m->index = vindex;
+                            m->reserved = 0;
+#pragma unroll
+                            for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? ple[i] : 0u;
+                        }
+                    }
+                }
                 continue;
             }
 
             u32 pl[NW];
             const bool ok = payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(x3, y3, pl);   // (never reached for P2TR: see above)
 
-            report_payload<NW, FULL>(args, args.dump, dfa_lds, (int)args.fmt, index, pl, ok);
+            if (dump) {
+                u32 *o = args.dump + (size_t)index * NW;
+#pragma unroll
+                for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
+            } else if (ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl))) {
+                // monotonic counter: no per-dispatch reset; this dispatch's slots start at match_base
+                const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+                if (slot < args.match_cap) {
+                    DevMatch *m = args.mrec + slot;
+                    m->index = index;
+                    m->reserved = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? pl[i] : 0u;
+                }
+            }
         }
     }
     if (stamp && tid == 0) {   // (launches of one frame are ordered on their stream: plain accumulation, mod 2^32)
@@ -537,6 +538,7 @@ __global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
         fe_mul(inv, ip, sib);
     }
     const u32 half = args.n >> 1;
+    const bool dump = args.dump != nullptr;
 #pragma unroll 1
     for (int step = (int)steps - 1; step >= 0; step--) {
         const u32 *in = args.tq + (size_t)step * 27 * lanes + u;
@@ -567,7 +569,20 @@ __global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
         // stage A walks j = S-1 .. 0 and, within j, +R then -R
         const u32 j = S - 1 - ((u32)step >> 1), sgn = (u32)step & 1u;
         const u32 index = sgn ? (half - (u + 1) * S + j) : (half + u * S + j);
-        report_payload<8, FULL>(args, args.dump, dfa_lds, VGF_P2TR, index, pl, ok);
+        if (dump) {
+            u32 *o = args.dump + (size_t)index * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
+        } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
+            const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+            if (slot < args.match_cap) {
+                DevMatch *m = args.mrec + slot;
+                m->index = index;
+                m->reserved = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) m->payload[i] = pl[i];
+            }
+        }
     }
 }
 
@@ -720,7 +735,20 @@ __global__ void __launch_bounds__(KEYS_WG) p2tr_out_kernel(const KeysArgs args) 
 #pragma unroll
     for (int i = 0; i < 8; i++) pl[i] = bswap32(xw[7 - i]);   // 32 big-endian bytes in memory order
     if (idx >= args.n) return;
-    report_payload<8, FULL>(args, args.dump, dfa_lds, VGF_P2TR, idx, pl, ok);
+    if (args.dump) {
+        u32 *o = args.dump + (size_t)idx * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
+    } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
+        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+        if (slot < args.match_cap) {
+            DevMatch *m = args.mrec + slot;
+            m->index = idx;
+            m->reserved = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) m->payload[i] = pl[i];
+        }
+    }
 }
 
 // a: the context's output / filter / table fields, n keys whose internal keys lie in a.pts; a.xyz / a.tree / a.root: scratch
@@ -944,16 +972,74 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
     if (ENDO) {
         // (every lane has read its pair's inverse from the tree before the multiplications above; after this barrier the tree's
         //  LDS parks the x of the point in hand, as in seq_bwd_kernel)
+        constexpr bool NEEDS_Y = FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM;
         __syncthreads();
-        report_six_images<FMT == VGF_P2TR ? VGF_P2PKH : FMT, FULL, KEYS_WG>(args, args.dump, tree, ypark, dfa_lds, tid, x, y, idx, args.vstride, idx < args.n,
-                                                                               valid && idx < args.n);
+        const u32 ypar = y.n[0] & 1u;
+        lds_park_fe(tree, KEYS_WG, tid, x);
+        if (NEEDS_Y) lds_park_fe(ypark, KEYS_WG, tid, y);
+        const bool live = valid && idx < args.n;
+#pragma unroll 1
+        for (u32 v = 0; v < 6; v++) {
+            const u32 e = v >> 1, sneg = v & 1u;   // (x,+) (x,-) (bx,+) (bx,-) (b^2 x,+) (b^2 x,-)
+            fe xe, ye;
+            lds_unpark_fe(tree, KEYS_WG, tid, xe);
+            if (sneg == 0 && e > 0) {
+                fe beta;
+                fe_set_beta(beta);
+                fe_mul(xe, xe, beta);
+                fe_canonicalize_product(xe);
+                lds_park_fe(tree, KEYS_WG, tid, xe);
+            }
+            if (NEEDS_Y) {
+                lds_unpark_fe(ypark, KEYS_WG, tid, ye);
+                if (sneg) {
+                    fe ny;
+                    fe_neg(ny, ye, 1);
+                    fe_normalize(ny);      // p - y, canonical (y != 0 on this curve)
+                    ye = ny;
+                }
+            } else {
+                ye.n[0] = ypar ^ sneg;     // all a compressed key reads of y
+            }
+            u32 ple[NW];
+            (void)payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(xe, ye, ple);
+            if (idx >= args.n) continue;
+            const u32 vindex = (sneg * 3u + e) * args.vstride + idx;
+            if (args.dump) {
+                u32 *o = args.dump + (size_t)vindex * NW;
+#pragma unroll
+                for (int i = 0; i < NW; i++) o[i] = live ? ple[i] : 0u;
+            } else if (live && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple))) {
+                const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+                if (slot < args.match_cap) {
+                    DevMatch *m = args.mrec + slot;
+                    m->index = vindex;
+                    m->reserved = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? ple[i] : 0u;
+                }
+            }
+        }
         return;
     }
     u32 pl[NW];
     const bool ok = payload_from_point<FMT == VGF_P2TR ? VGF_P2PKH : FMT>(x, y, pl) && valid;
 
     if (idx >= args.n) return;
-    report_payload<NW, FULL>(args, args.dump, dfa_lds, (int)args.fmt, idx, pl, ok);
+    if (args.dump) {
+        u32 *o = args.dump + (size_t)idx * NW;
+#pragma unroll
+        for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
+    } else if (ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl))) {
+        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
+        if (slot < args.match_cap) {
+            DevMatch *m = args.mrec + slot;
+            m->index = idx;
+            m->reserved = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) m->payload[i] = i < NW ? pl[i] : 0u;
+        }
+    }
 }
 
 template <int FMT>
