@@ -429,9 +429,14 @@ def main():
     # VGEN_BENCH_REHEARSE=1: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share
     # devices).  Never the measured configuration: one rank per GPU is.
     rehearse = world > 1 and os.environ.get("VGEN_BENCH_REHEARSE") == "1"
-    if torch.cuda.device_count() < world and not rehearse:
+    # A launcher may also pin ONE device per rank through HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES: every rank then sees a single
+    # device 0.  Accepted — and checked below, like every N > 1 run: the ranks must sit on N DIFFERENT devices.
+    pinned = torch.cuda.device_count() == 1 and world > 1 and any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if torch.cuda.device_count() < world and not rehearse and not pinned:
         sys.exit(f"bench.py: --gpus {world} needs {world} devices, {torch.cuda.device_count()} visible "
                  "(VGEN_BENCH_REHEARSE=1 lets ranks share a device for a rehearsal; its numbers are not a measurement)")
+    if pinned and not rehearse:
+        local_rank = 0
     if rehearse:
         per_dev = -(-world // torch.cuda.device_count())   # ranks sharing one GPU split the frames between them:
         args.frames = max(2, args.frames // per_dev)       # more than ~20 busy queues per device collapse the throughput
@@ -450,6 +455,15 @@ def main():
         # the frames' own.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+        if not rehearse:
+            # one rank per GPU, verified: N ranks on fewer than N devices would print an aggregate that is not N GPUs' worth
+            pr = torch.cuda.get_device_properties(local_rank)
+            ident = (os.uname().nodename, pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id, str(pr.uuid))
+            idents = [None] * world
+            dist.all_gather_object(idents, ident)
+            if len(set(idents)) < world:
+                sys.exit(f"bench.py: --gpus {world} but the ranks sit on {len(set(idents))} device(s) — one rank per GPU is the measured configuration "
+                         "(VGEN_BENCH_REHEARSE=1 for a rehearsal on fewer devices)")
 
     import vgen_amd as vg
     fmt = vg.AddressFormat(FORMATS[args.format])

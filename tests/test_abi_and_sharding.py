@@ -251,7 +251,12 @@ def test_bench_plain_gpus_2_prints_n_gpus_2():
     assert d["n_gpus"] == 2 and d["steps"] == 64 and d["value"] > 1000 and d["config"]["parallelism"].startswith("range-striped x2")
     if vg.device_count() < 2:
         out = _bench(args)
-        assert out.returncode != 0 and out.stdout.strip() == "" and "needs 2 devices" in out.stderr
+        # (a box that exports *_VISIBLE_DEVICES itself is taken for a pinning launcher and refused one step later)
+        assert out.returncode != 0 and out.stdout.strip() == "" and ("needs 2 devices" in out.stderr or "the ranks sit on 1 device(s)" in out.stderr)
+        # a launcher that pins one device per rank shows every rank a single device 0: accepted, but the ranks must then
+        # sit on different devices — here both were given the same one
+        out = _bench(args, {"HIP_VISIBLE_DEVICES": "0"})
+        assert out.returncode != 0 and out.stdout.strip() == "" and "the ranks sit on 1 device(s)" in out.stderr, out.stderr[-1500:]
 
 
 def test_cli_warns_about_impossible_patterns_before_touching_the_device():
