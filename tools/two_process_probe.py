@@ -14,7 +14,13 @@ def run(n_proc, frames, secs=8.0):
         rates.append(int(m.group(1).replace(",", "")) / secs / 1e9 if m else None)
     print(f"{n_proc} process(es) x {frames} frames: " + ", ".join("%.2f" % r if r else "?" for r in rates) + " Gkeys/s each"
           + (f" (sum {sum(r for r in rates if r):.2f})" if n_proc > 1 else ""), flush=True)
-run(1, 12)
-for fr in (12, 6, 4): run(2, fr)
-run(3, 4)
-run(4, 3)
+import sys
+if len(sys.argv) > 1:      # explicit cases: PROCESSESxFRAMES ...
+    for a in sys.argv[1:]:
+        n, f = a.split('x')
+        run(int(n), int(f))
+else:
+    run(1, 12)
+    for fr in (12, 6, 4): run(2, fr)
+    run(3, 4)
+    run(4, 3)

@@ -181,7 +181,7 @@ void usage() {
             "  vgen-hip generate -p PATTERN [-f FORMAT] [-i] [-c COUNT] [-o text|json|jsonl|csv|minimal] [--file PATH]\n"
             "                    [--gpu-batch-size N] [--repeat N] [-q] [--seed S] [--devices 0,1,..|all] [--frames F]\n"
             "                    [--frames F]          (dispatches in flight, default 12; several searches on ONE device share it\n"
-            "                                           evenly when their frames add up to twelve: 2 x 6, 3 x 4 ...)\n"
+            "                                           evenly as long as their frames add up to twenty or fewer: 2 x 8, 3 x 6 ...)\n"
             "                    [--checkpoint FILE]   (resume an interrupted scan from FILE; written as the scan runs)\n"
             "                    [--no-endo]           (unseeded searches, any format but P2TR, test six keys per curve\n"
             "                                           point — k, lambda k, lambda^2 k and their negations; this walks k0 + i only)\n"
