@@ -300,8 +300,8 @@ typedef struct vgen_scan_config {
 #define VGEN_SCAN_RANDOM_KEYS 1u   /* scan_with_progress's shape (src/scanner.rs:118-169): every candidate an independent random key
                                       (vgen_dispatch_random: batch b tests candidates b * batch_size .. of stream `shard` under
                                       `seed`; seed 0 = OS entropy) instead of the reference GPU path's walk from one base key.
-                                      A full scalar multiplication per key: ~10x slower than the walk.  No start / end /
-                                      checkpoint.  With a fixed seed (and without VGEN_FLAG_ENDO) the matches are those of
+                                      A full scalar multiplication per key: ~10x slower than the walk.  No start / end; a
+                                      checkpoint records the seed and the batches done per stream.  With a fixed seed (and without VGEN_FLAG_ENDO) the matches are those of
                                       the oracle's scan_random walk of the same stream, in the same order.  On a VGEN_FLAG_ENDO
                                       context every draw is tested as six keys (the candidate and its lambda / negation images,
                                       one multiplication for the six: 5.5 instead of 1.35 Gkeys/s); seeds and shards keep their

@@ -302,6 +302,71 @@ static void sc_random_keys() {
     }
 }
 
+// A random-key scan with a checkpoint: interrupted after three batches, resumed, it returns what the oracle's walk of the same
+// stream returns — seeded, and unseeded (the file then carries the seed the first leg drew); a key-range checkpoint is refused.
+static void sc_random_checkpoint() {
+    for (uint64_t seed : {77ull, 0ull}) {
+        char path[] = "/tmp/vgen_fake_rck_XXXXXX";
+        int fd = mkstemp(path);
+        close(fd);
+        unlink(path);
+        vgen_ctx *c = make_ctx(0, 3);
+        vgen_scan_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
+        cfg.count = UINT64_MAX;
+        cfg.seed = seed;
+        cfg.flags = VGEN_SCAN_RANDOM_KEYS;
+        cfg.checkpoint_path = path;
+        cfg.checkpoint_interval_ms = 1;
+        cfg.max_batches = 1;
+        vgen_scan_result r;
+        int rc = vgen_scan(c, "^1[A-D][a-k]", &cfg, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_OK && r.operations == 1ull * BATCH && r.complete == 0, "leg 1 (seed %llu): rc=%d ops=%llu %s", (unsigned long long)seed, rc,
+              (unsigned long long)r.operations, vgen_last_error(c));
+        const uint64_t first = r.n_matches;
+        vgen_scan_result_free(&r);
+        cfg.max_batches = 2;   // (per call: two more batches, three in all)
+        rc = vgen_scan(c, "^1[A-D][a-k]", &cfg, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_OK && r.resumed_operations == 1ull * BATCH && r.operations == 2ull * BATCH, "leg 2 (seed %llu): rc=%d resumed=%llu ops=%llu %s",
+              (unsigned long long)seed, rc, (unsigned long long)r.resumed_operations, (unsigned long long)r.operations, vgen_last_error(c));
+        CHECK(first > 0 && r.n_matches > first, "matches %llu then %llu", (unsigned long long)first, (unsigned long long)r.n_matches);
+        if (seed) {
+            // the oracle walks its stream in batches of 10 000 keys (scanner.rs:107): 3 x 8192 = 24 576 keys lie between its 20 000
+            // and its 30 000 — the product's matches must extend the former's and be a prefix of the latter's
+            vo_scan_result lo, hi;
+            vo_scan_random(0, "^1[A-D][a-k]", 0, seed, (size_t)-1, 20000, 1, &lo);
+            vo_scan_random(0, "^1[A-D][a-k]", 0, seed, (size_t)-1, 3ull * BATCH, 1, &hi);
+            CHECK(lo.n_matches <= r.n_matches && r.n_matches <= hi.n_matches && hi.n_matches > lo.n_matches && lo.n_matches > 100,
+                  "resumed random scan: %llu matches, the oracle's %zu (20 000 keys) .. %zu (30 000)", (unsigned long long)r.n_matches, lo.n_matches, hi.n_matches);
+            for (size_t i = 0; i < r.n_matches && i < hi.n_matches; i++)
+                CHECK(!memcmp(r.matches[i].key, hi.matches[i].key, 32) && !strcmp(r.matches[i].address, hi.matches[i].gen.address), "resumed random match %zu", i);
+            vo_scan_free(&lo);
+            vo_scan_free(&hi);
+        } else {
+            for (uint64_t i = 0; i < r.n_matches; i++) {   // the drawn seed is the file's business: every match must re-derive, none twice
+                vo_generated g;
+                CHECK(vo_generate(0, r.matches[i].key, &g) && !strcmp(g.address, r.matches[i].address), "unseeded resumed match %llu", (unsigned long long)i);
+                for (uint64_t j = 0; j < i; j++) CHECK(memcmp(r.matches[i].key, r.matches[j].key, 32) != 0, "duplicate %llu/%llu", (unsigned long long)i, (unsigned long long)j);
+            }
+        }
+        vgen_scan_result_free(&r);
+        // the same file under another seed, or as a key-range scan: refused
+        vgen_scan_config other = cfg;
+        other.seed = seed + 5;
+        rc = vgen_scan(c, "^1[A-D][a-k]", &other, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_E_INVALID, "another seed: rc=%d", rc);
+        vgen_scan_result_free(&r);
+        other = range_cfg(0, 1, 100);
+        other.checkpoint_path = path;
+        rc = vgen_scan(c, "^1[A-D][a-k]", &other, nullptr, nullptr, nullptr, &r);
+        CHECK(rc == VGEN_E_INVALID, "as a range scan: rc=%d", rc);
+        vgen_scan_result_free(&r);
+        unlink(path);
+        vgen_destroy(c);
+    }
+}
+
 static void sc_endo_and_formats() {
     // six images per point: every match must re-derive on the oracle from its reported key
     vgen_ctx *c = make_ctx(0, 3, 0, VGEN_FLAG_ENDO);
@@ -552,7 +617,7 @@ int main(int argc, char **argv) {
     const std::map<std::string, std::function<void()>> all = {
         {"range_scan", sc_range_scan}, {"stop_flag", sc_stop_flag}, {"checkpoint", sc_checkpoint}, {"multi_context", sc_multi_context},
         {"ring_growth", sc_ring_growth_and_host_filter}, {"failure_takeover", sc_failure_takeover}, {"random_keys", sc_random_keys},
-        {"endo_and_formats", sc_endo_and_formats}, {"dispatch_api", sc_dispatch_api}, {"edge_ranges", sc_edge_ranges}, {"fuzz", sc_fuzz}};
+        {"endo_and_formats", sc_endo_and_formats}, {"dispatch_api", sc_dispatch_api}, {"edge_ranges", sc_edge_ranges}, {"fuzz", sc_fuzz}, {"random_checkpoint", sc_random_checkpoint}};
     std::vector<std::string> run;
     for (int i = 1; i < argc; i++) run.push_back(argv[i]);
     if (run.empty())

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 DRIVER = os.path.join(HERE, "native", "scan_driver_hip")
 SCENARIOS = ["range_scan", "stop_flag", "checkpoint", "multi_context", "ring_growth", "failure_takeover", "random_keys",
-             "endo_and_formats", "dispatch_api", "edge_ranges", "fuzz"]
+             "endo_and_formats", "dispatch_api", "edge_ranges", "fuzz", "random_checkpoint"]
 
 
 @pytest.mark.parametrize("seed, cases", [(20261004, 150), (77, 150)])

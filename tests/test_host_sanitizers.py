@@ -4,9 +4,9 @@ safety from `unsafe_code = "forbid"`, Cargo.toml:14).
 The part of libvgen_hip.so that needs a device to run — scanner.cpp (worker pool, helper-thread ramp, shared counters,
 checkpoint lock, multi-context threads, failure take-over) and cabi.cpp — is linked against a CPU stand-in of the runtime
 interface (tests/native/fake_rt.cpp, over the product's own core/*.h, NOT the oracle) and built twice by g++: with
-ThreadSanitizer and with AddressSanitizer + UBSan.  tests/native/fake_driver.cpp then drives the C ABI through eleven
+ThreadSanitizer and with AddressSanitizer + UBSan.  tests/native/fake_driver.cpp then drives the C ABI through twelve
 scenarios (range scan with progress callback, stop flag from another thread, checkpoint / resume, three striped contexts,
-ring growth + host-filter pool, a failing context taken over by the others, random keys, endomorphism images and the other
+ring growth + host-filter pool, a failing context taken over by the others, random keys (also checkpointed and resumed), endomorphism images and the other
 formats, the frame-level API, ranges that are not whole batches incl. the end of the key space) and a randomised walk over
 formats x pattern kinds x ranges x counts x contexts x ring sizes x injected failures (`fuzz`: 12 cases here, more with
 VGEN_FAKE_FUZZ_CASES / VGEN_FAKE_FUZZ_SEED), and checks every result against the oracle.  CPU only: no sanitizer runs on the GPU box.
@@ -19,7 +19,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 NATIVE = os.path.join(HERE, "native")
 SCENARIOS = ["range_scan", "stop_flag", "checkpoint", "multi_context", "ring_growth", "failure_takeover", "random_keys",
-             "endo_and_formats", "dispatch_api", "edge_ranges", "fuzz"]
+             "endo_and_formats", "dispatch_api", "edge_ranges", "fuzz", "random_checkpoint"]
 
 
 @pytest.fixture(scope="module")

@@ -425,7 +425,7 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
     }
     if (!o.checkpoint.empty()) cfg.checkpoint_path = o.checkpoint.c_str();   // resumable scan (not in the reference)
     if (o.random_keys) {
-        if (has_range || !o.checkpoint.empty()) die("--random-keys draws an independent key per candidate: no range, no checkpoint");
+        if (has_range) die("--random-keys draws an independent key per candidate: no range");
         cfg.flags |= VGEN_SCAN_RANDOM_KEYS;
     }
 

@@ -139,7 +139,7 @@ bool generated_from_key(uint32_t format, const uint8_t kb[32], vgen_generated &g
 // File (text, mode 0600 — it holds the private keys of the matches; rewritten atomically through <path>.tmp,
 // fsync, rename):
 //   vgen-hip checkpoint v1 / pattern_hex= / case_insensitive= / format= / batch_size= / n_shards= /
-//   first_shard= / base= / end= / operations= / done=<per slot> / complete= / match=<key hex> ...
+//   first_shard= / base= / end= / operations= / done=<per slot> / complete= / mode=range|random / match=<key hex> ...
 struct Checkpoint {
     std::string path;
     std::string pattern;
@@ -147,6 +147,7 @@ struct Checkpoint {
     uint32_t format = 0, batch = 0, n_shards = 1, first_shard = 0;
     uint8_t base[32] = {0}, end[32] = {0};
     bool has_end = false;
+    bool random = false;                   // a random-key scan: `base` holds its seed (last eight bytes), done[] counts batches of the streams
     double interval_s = 10.0;
 
     std::mutex mu;
@@ -209,6 +210,10 @@ struct Checkpoint {
         if (differs("n_shards", std::to_string(n_shards))) return bad("n_shards");
         if (differs("first_shard", std::to_string(first_shard))) return bad("first_shard");
         if (differs("end", has_end ? hex(end, 32) : "none")) return bad("end");
+        {
+            const std::string *m = get("mode");   // (files written before the field existed are key-range scans')
+            if ((m ? *m : std::string("range")) != (random ? "random" : "range")) return bad("mode");
+        }
         std::vector<uint8_t> b;
         const std::string *bs = get("base");
         if (!bs || !unhex(*bs, b) || b.size() != 32) return bad("base");
@@ -259,7 +264,7 @@ struct Checkpoint {
                 hex((const uint8_t *)pattern.data(), pattern.size()).c_str(), ci, format, batch, n_shards, first_shard,
                 hex(base, 32).c_str(), has_end ? hex(end, 32).c_str() : "none", (unsigned long long)operations);
         for (size_t i = 0; i < done.size(); i++) fprintf(f, "%s%llu", i ? " " : "", (unsigned long long)done[i]);
-        fprintf(f, "\ncomplete=%d\n", complete ? 1 : 0);
+        fprintf(f, "\ncomplete=%d\nmode=%s\n", complete ? 1 : 0, random ? "random" : "range");
         for (auto &g : ledger) fprintf(f, "match=%s\n", hex(g.key, 32).c_str());
         bool ok = fflush(f) == 0 && fsync(fd) == 0;
         ok = (fclose(f) == 0) && ok;
@@ -368,8 +373,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                                          "it serves unseeded random scans only (no start / end / seed / shards / checkpoint)");
     // (random keys on an endomorphism context: six keys per draw — the candidate and its lambda / negation images; seeds and
     //  shards keep their meaning there, they name streams of candidates, not ranges)
-    if (random_keys && (cfg->has_start || cfg->has_end || cfg->checkpoint_path))
-        return ctx->fail(VGEN_E_INVALID, "VGEN_SCAN_RANDOM_KEYS draws an independent key per candidate: no start / end / checkpoint");
+    if (random_keys && (cfg->has_start || cfg->has_end))
+        return ctx->fail(VGEN_E_INVALID, "VGEN_SCAN_RANDOM_KEYS draws an independent key per candidate: no start / end");
+    if (random_keys && ck && !cfg->seed) return ctx->fail(VGEN_E_INVALID, "a checkpointed random-key scan needs its seed (open_checkpoint sets it)");
 
     const uint32_t N = ctx->batch;
     const size_t pbytes = (size_t)ctx->payload_words * 4;
@@ -696,8 +702,21 @@ void resolve_base(vgen_scan_config &c) {
 // file when there is one (adopting its base key for an unseeded random scan).  VGEN_OK / error.
 int open_checkpoint(vgen_ctx *ctx, Checkpoint &ck, const char *pattern, vgen_scan_config &c, uint32_t batch, uint32_t n_shards,
                     uint32_t first_shard, uint32_t slots) {
+    const bool random_keys = (c.flags & VGEN_SCAN_RANDOM_KEYS) != 0;
     const bool pin_base = c.has_start || c.seed;
-    resolve_base(c);
+    if (random_keys) {
+        // the scan is named by its seed (OS entropy when the caller gave none: the file then carries it to the next run);
+        // `done` counts the batches of each stream
+        while (!c.seed) {
+            std::random_device rd;
+            c.seed = ((uint64_t)rd() << 32) | rd();
+        }
+        memset(c.start, 0, 32);
+        for (int i = 0; i < 8; i++) c.start[31 - i] = (uint8_t)(c.seed >> (8 * i));
+    } else {
+        resolve_base(c);
+    }
+    ck.random = random_keys;
     ck.path = c.checkpoint_path;
     ck.pattern = pattern;
     ck.ci = c.case_insensitive != 0;
@@ -713,6 +732,12 @@ int open_checkpoint(vgen_ctx *ctx, Checkpoint &ck, const char *pattern, vgen_sca
     const int r = ck.load(pin_base);
     if (r < 0) return ctx->fail(VGEN_E_INVALID, ck.error);
     memcpy(c.start, ck.base, 32);
+    if (random_keys) {   // (the file's seed when the caller gave none)
+        c.seed = 0;
+        for (int i = 0; i < 8; i++) c.seed = (c.seed << 8) | ck.base[24 + i];
+        memset(c.start, 0, 32);
+        if (!c.seed) return ctx->fail(VGEN_E_INVALID, "checkpoint file '" + ck.path + "' carries no seed");
+    }
     return VGEN_OK;
 }
 
