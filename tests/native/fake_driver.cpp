@@ -585,8 +585,26 @@ static void sc_fuzz() {
         vgen_scan_config cfg = range_cfg(pt.fmt, lo, hi, count);
         cfg.case_insensitive = pt.ci;
         vgen_scan_result r;
+        // every fourth unbounded case through a checkpoint: a first leg of a few batches per context, then the rest
+        char ckpath[] = "/tmp/vgen_fake_fz_XXXXXX";
+        const bool with_ck = count == UINT64_MAX && rnd(4) == 0;
+        if (with_ck) {
+            int fd = mkstemp(ckpath);
+            close(fd);
+            unlink(ckpath);
+            cfg.checkpoint_path = ckpath;
+            cfg.checkpoint_interval_ms = 1;
+            cfg.max_batches = 1 + rnd(2);
+            const int rc1 = n_ctx == 1 ? vgen_scan(cs[0], pt.p, &cfg, nullptr, nullptr, nullptr, &r)
+                                       : vgen_scan_multi(cs, n_ctx, pt.p, &cfg, nullptr, nullptr, nullptr, &r);
+            CHECK(rc1 == VGEN_OK || victim >= 0, "case %d: checkpoint leg 1 rc=%d %s", t, rc1, vgen_last_error(cs[0]));
+            vgen_scan_result_free(&r);
+            cfg.max_batches = 0;
+            if (victim >= 0) vgen_debug_fail_after(cs[victim], UINT64_MAX);   // (the failure belongs to the first leg)
+        }
         const int rc = n_ctx == 1 ? vgen_scan(cs[0], pt.p, &cfg, nullptr, nullptr, nullptr, &r)
                                   : vgen_scan_multi(cs, n_ctx, pt.p, &cfg, nullptr, nullptr, nullptr, &r);
+        if (with_ck) unlink(ckpath);
         auto got = got_of(r);
         const size_t expect = (size_t)std::min<uint64_t>(count, want.size());
         char what[256];
@@ -604,10 +622,11 @@ static void sc_fuzz() {
         }
         if (count == UINT64_MAX) {
             const uint64_t batches = (len + BATCH - 1) / BATCH;
-            CHECK(r.complete == 1 && r.operations == batches * BATCH, "%s: complete=%d ops=%llu", what, r.complete, (unsigned long long)r.operations);
+            CHECK(r.complete == 1 && r.operations + r.resumed_operations == batches * BATCH && (with_ck || r.resumed_operations == 0), "%s: complete=%d ops=%llu+%llu%s", what,
+                  r.complete, (unsigned long long)r.resumed_operations, (unsigned long long)r.operations, with_ck ? " (checkpoint)" : "");
         }
         // (the victim fails only if it gets to its k-th dispatch before the scan ends)
-        CHECK(r.failed_shards == 0 || (victim >= 0 && r.failed_shards == 1), "%s: failed_shards=%d", what, r.failed_shards);
+        CHECK(r.failed_shards == 0 || (victim >= 0 && !with_ck && r.failed_shards == 1), "%s: failed_shards=%d", what, r.failed_shards);
         vgen_scan_result_free(&r);
         for (uint32_t i = 0; i < n_ctx; i++) vgen_destroy(cs[i]);
     }
