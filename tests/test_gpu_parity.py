@@ -1421,3 +1421,24 @@ def test_cli_progress_line_only_on_a_terminal(vg):
     plain = {k: v for k, v in os.environ.items() if k != "VGEN_PROGRESS"}
     q = subprocess.run(args, capture_output=True, text=True, timeout=120, env=plain)      # stderr is a pipe: no progress line
     assert q.returncode == 0 and "Checked" not in q.stderr and "No match found after" in q.stderr
+
+
+def test_random_key_scan_resumes_through_a_checkpoint(vg, vo, tmp_path):
+    """VGEN_SCAN_RANDOM_KEYS with checkpoint_path: two legs (2 + 3 batches) find what one scan of five batches finds — the
+    oracle-checked stream walk of test_random_key_scan_* —, also with six images per draw; the file names its mode and seed."""
+    for endo in (False, True):
+        r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=3, endo=endo)
+        whole = vg.scan_gpu_with_runner("^1[A-D][a-k]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, seed=21, random_keys=True, max_batches=5), r)
+        ck = str(tmp_path / f"rk{int(endo)}.ckpt")
+        a = vg.scan_gpu_with_runner("^1[A-D][a-k]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, seed=21, random_keys=True, max_batches=2, checkpoint_path=ck), r)
+        b = vg.scan_gpu_with_runner("^1[A-D][a-k]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, seed=21, random_keys=True, max_batches=3, checkpoint_path=ck), r)
+        assert 0 < len(a.matches) < len(b.matches) and b.resumed_operations == a.operations and a.operations + b.operations == whole.operations
+        assert [(m.address, m.wif) for m in b.matches] == [(m.address, m.wif) for m in whole.matches] and len(whole.matches) > 100
+        for m in whole.matches[::17]:
+            assert vo.generate(0, int(m.hex, 16))["address"] == m.address
+        text = open(ck).read()
+        assert "mode=random" in text and ("%016x" % 21) in text
+        with pytest.raises(vg.VgenError):   # another seed: not this scan's file
+            vg.scan_gpu_with_runner("^1[A-D][a-k]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, seed=22, random_keys=True, max_batches=1, checkpoint_path=ck), r)
+        r.close()
+
