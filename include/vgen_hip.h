@@ -283,7 +283,8 @@ typedef struct vgen_scan_config {
     uint32_t shard;          /* this scanner's index among n_shards batch-striped scanners */
     uint32_t n_shards;       /* 0/1 = single device; >1: this context takes global batches b with
                                 b % n_shards == shard */
-    uint64_t max_batches;    /* stop after this many dispatches per shard (0 = no limit) */
+    uint64_t max_batches;    /* stop after this many dispatches per shard IN THIS CALL (0 = no limit): a resumed scan
+                                counts from where the checkpoint left off */
     /* Build-side addition (the reference cannot resume): when non-NULL, the scan records the finished
      * batches of every shard and the matches found in them in this file (rewritten atomically, at most
      * every checkpoint_interval_ms and once when the scan returns) and, when the file already exists and
