@@ -63,3 +63,11 @@ def test_verify_address_matching(address, verdict):
 def test_verify_rejects_what_the_reference_rejects(key, message):
     rc, out, err = run("-k", key)
     assert rc == 1 and message in err and out == ""
+
+
+@pytest.mark.parametrize("args", [["--key=" + HEX, "--address=1GAehh7TsJAHuUAeKZcXf5CnwuGuGgyX2S"], ["-k" + HEX, "-a1GAehh7TsJAHuUAeKZcXf5CnwuGuGgyX2S"],
+                                  ["-k=" + WIF_U, "-a", "1GAehh7TsJAHuUAeKZcXf5CnwuGuGgyX2S"]])
+def test_claps_spellings_of_an_argument(args):
+    """--name=value, -nVALUE and -n=VALUE are the same argument to clap (the reference's parser) as -n VALUE."""
+    rc, out, _ = run(*args)
+    assert rc == 0 and out.splitlines()[-1] == "MATCH!"

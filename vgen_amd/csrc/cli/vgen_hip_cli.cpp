@@ -203,11 +203,36 @@ Opts parse(int argc, char **argv) {
     }
     o.cmd = argv[1];
     if (o.cmd == "range") o.count = 1;
+    // clap's spellings of one argument: --name=value, -nVALUE, and boolean shorts run together (-iq) — split up front
+    std::vector<std::string> args;
     for (int i = 2; i < argc; i++) {
-        std::string a = argv[i];
+        const std::string a = argv[i];
+        const size_t eq = a.find('=');
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-' && eq != std::string::npos) {
+            args.push_back(a.substr(0, eq));
+            args.push_back(a.substr(eq + 1));
+        } else if (a.size() > 2 && a[0] == '-' && a[1] != '-') {
+            size_t k = 1;
+            for (; k < a.size(); k++) {
+                const char ch = a[k];
+                if (strchr("pfcorkaltT", ch)) {   // shorts that take a value: the rest of the word (after an optional '=') is it
+                    args.push_back(std::string("-") + ch);
+                    std::string rest = a.substr(k + 1);
+                    if (!rest.empty() && rest[0] == '=') rest = rest.substr(1);
+                    if (!rest.empty()) args.push_back(rest);
+                    break;
+                }
+                args.push_back(std::string("-") + ch);
+            }
+        } else {
+            args.push_back(a);
+        }
+    }
+    for (size_t i = 0; i < args.size(); i++) {
+        const std::string a = args[i];
         auto val = [&]() -> std::string {
-            if (i + 1 >= argc) die("a value is required for '" + a + "'");
-            return argv[++i];
+            if (i + 1 >= args.size()) die("a value is required for '" + a + "'");
+            return args[++i];
         };
         if (a == "-p" || a == "--pattern") { o.pattern = val(); o.has_pattern = true; }
         else if (a == "-f" || a == "--format") o.format = val();
