@@ -1,0 +1,160 @@
+"""The ISA contract of the device code, checked on the assembly hipcc emits for gfx950 (no GPU needed).
+
+What DESIGN.md and BASELINE.json's north_star say about the kernels is asserted here on `build/lib/device/kernels.s`
+(made by vgen_amd/csrc/Makefile with the flags of the shipped object), so that a toolchain or source change that breaks
+one of them fails the CPU suite instead of silently costing throughput:
+
+  * no MFMA anywhere (integer / modular arithmetic, not a contraction);
+  * the headline kernel seq_bwd_kernel<P2PKH, prefilter> fits 128 VGPRs (four waves per SIMD) with no scratch and the
+    9 KB product tree as its only LDS;
+  * match compaction is per WAVE: one global atomic per kernel, fed by the popcount of the wave's ballot, the leader's
+    result broadcast by v_readlane, ranks by v_mbcnt (kernels.hip: match_slot) — never a per-lane atomic, never system scope;
+  * the short first-half kernels of a dispatch raise their issue priority (s_setprio);
+  * no instantiation uses more registers or scratch than the committed table profiles/r04_kernel_resources.txt.
+
+Reference counterpart of the code under test: src/shaders/search.wgsl:2-31 (one storage write per key, no compaction).
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ISA = os.path.join(ROOT, "build", "lib", "device", "kernels.s")
+SRC = os.path.join(ROOT, "vgen_amd", "csrc", "device", "kernels.hip")
+HEADLINE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0EEEvNS_7SeqArgsE"
+
+
+def parse_isa(txt):
+    """-> {symbol: {"body": [lines], "vgpr": n, "scratch": n, "lds": n}} for every kernel of the file."""
+    out = {}
+    for m in re.finditer(r"^\s*\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", txt, re.M | re.S):
+        sym, meta = m.group(1), m.group(2)
+
+        def field(name, meta=meta):
+            f = re.search(r"\." + name + r"\s+(\d+)", meta)
+            return int(f.group(1)) if f else None
+        body = txt.split("\n" + sym + ":", 1)[1].split(".Lfunc_end", 1)[0].split("\n")
+        out[sym] = {"body": body, "vgpr": field("amdhsa_next_free_vgpr"), "scratch": field("amdhsa_private_segment_fixed_size"),
+                    "lds": field("amdhsa_group_segment_fixed_size")}
+    return out
+
+
+def count(body, pat):
+    return sum(1 for line in body if re.match(r"\s+" + pat, line))
+
+
+@pytest.fixture(scope="module")
+def isa():
+    # (a no-op when __graft_entry__.build() has just run; ~1 min of hipcc otherwise)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "vgen_amd", "csrc"), "../../build/lib/device/kernels.s"])
+    return parse_isa(open(ISA).read())
+
+
+def check_match_path(sym, k):
+    """One wave-aggregated atomic: see the module docstring.  -> list of violations."""
+    bad = []
+    atom = [i for i, line in enumerate(k["body"]) if re.match(r"\s+(global|flat|buffer)_atomic", line)]
+    if len(atom) != 1:
+        return [f"{sym}: {len(atom)} atomics on the match path, expected exactly 1"]
+    line = k["body"][atom[0]]
+    if "global_atomic_add" not in line:
+        bad.append(f"{sym}: the slot counter is not a global_atomic_add: {line.strip()}")
+    if re.search(r"\bsc1\b", line):
+        bad.append(f"{sym}: system-scope atomic (sc1) on the match path: {line.strip()}")
+    if count(k["body"], "s_bcnt1_i32_b64") < 1:
+        bad.append(f"{sym}: no s_bcnt1 — the atomic's addend is not the popcount of the wave's ballot")
+    if count(k["body"], "v_mbcnt_hi_u32_b32") < 1:
+        bad.append(f"{sym}: no v_mbcnt — candidates do not take ranks within the wave")
+    # the reserved base comes back to every candidate lane from the leader (first set bit of the ballot): s_ff1 + v_readlane
+    # in the lines after the atomic — the part only the explicit compaction has (LLVM's own atomic optimizer reads lane 0
+    # of the active set with v_readfirstlane instead)
+    tail = k["body"][atom[0]:atom[0] + 40]
+    if not any(re.match(r"\s+s_ff1_i32_b64", t) for t in tail) or not any(re.match(r"\s+v_readlane_b32", t) for t in tail):
+        bad.append(f"{sym}: no s_ff1_i32_b64 + v_readlane_b32 after the atomic — the leader's slot base is not broadcast")
+    # and the atomic must not sit inside a loop of its own (a per-lane "waterfall")
+    head = k["body"][max(0, atom[0] - 12):atom[0]]
+    if any("s_cbranch_execnz" in t for t in head):
+        bad.append(f"{sym}: the atomic sits behind an exec loop")
+    return bad
+
+
+def test_no_mfma_anywhere(isa):
+    assert len(isa) >= 45, "kernels went missing from the assembly"
+    for sym, k in isa.items():
+        assert count(k["body"], "v_mfma") == 0 and count(k["body"], "v_smfmac") == 0, sym
+
+
+def test_headline_kernel_budget(isa):
+    k = isa[HEADLINE]
+    assert k["vgpr"] <= 128, k["vgpr"]              # four waves per SIMD: four launches of different frames share one
+    assert k["scratch"] == 0, k["scratch"]
+    assert k["lds"] == 9 * 256 * 4, k["lds"]        # the workgroup's product tree and nothing else
+    assert count(k["body"], "scratch_") == 0 and count(k["body"], "buffer_(load|store)") == 0
+    # the instruction classes the path is made of: 64-bit multiply-adds, rotates, three-input booleans
+    assert count(k["body"], "v_mad_u64_u32") > 500 and count(k["body"], "v_alignbit_b32") > 700 and count(k["body"], "v_bitop3_b32") > 400
+
+
+def test_match_compaction_is_one_atomic_per_wave(isa):
+    with_match = [s for s in isa if re.search(r"(seq_bwd_kernelILi[0245]|keys_bwd_kernelILi[0245]|p2tr_finish_kernel|p2tr_out_kernel)", s)]
+    assert len(with_match) == 16 + 16 + 2 + 2, sorted(with_match)
+    bad = []
+    for sym in with_match:
+        bad += check_match_path(sym, isa[sym])
+    assert not bad, "\n".join(bad)
+    # kernels that only park intermediate results have no atomic at all
+    for sym, k in isa.items():
+        if sym not in with_match:
+            assert count(k["body"], "(global|flat|buffer)_atomic") == 0, sym
+
+
+def test_match_compaction_is_written_in_the_source():
+    src = open(SRC).read()
+    body = src.split("u32 match_slot(", 1)[1].split("\n}\n", 1)[0]
+    assert "__ballot(hit)" in body and "__popcll(m)" in body and "mbcnt" in body and "readlane" in body
+    assert body.count("atomicAdd(") == 1
+    # every match site goes through it; nothing else touches the ring's counter
+    rest = src.replace(body, "")
+    code = "\n".join(line.split("//")[0] for line in rest.split("\n"))
+    assert "atomicAdd" not in code and "__hip_atomic" not in code and "atomic_fetch" not in code
+    assert code.count("match_slot(args.mhdr, hit, args.match_base)") == 6
+
+
+def test_the_checker_rejects_a_per_lane_or_system_scope_atomic():
+    """The checker itself: fed the shapes a regression would have, it must complain."""
+    good = ["\ts_bcnt1_i32_b64 s52, vcc", "\tv_mbcnt_hi_u32_b32 v1, vcc_hi, v1", "\tglobal_atomic_add v8, v13, v8, s[28:29] sc0",
+            "\ts_ff1_i32_b64 s2, vcc", "\tv_readlane_b32 s2, v3, s2"]
+    assert check_match_path("k", {"body": good}) == []
+    # per-lane atomic with system scope, as the compiler emits it when nothing aggregates
+    assert check_match_path("k", {"body": ["\tglobal_atomic_add v8, v13, v8, s[28:29] sc0 sc1"]})
+    # what LLVM's optimizer makes of a per-lane agent-scope atomicAdd(…, 1): aggregated, but not by the source
+    llvm = ["\tv_mbcnt_lo_u32_b32 v3, s50, 0", "\tv_mbcnt_hi_u32_b32 v3, s51, v3", "\ts_bcnt1_i32_b64 s2, s[50:51]",
+            "\tglobal_atomic_add v8, v13, v8, s[28:29] sc0", "\tv_readfirstlane_b32 s2, v8"]
+    assert check_match_path("k", {"body": llvm})
+    assert check_match_path("k", {"body": good + ["\tglobal_atomic_add v8, v13, v8, s[28:29] sc0"]})     # two atomics
+    assert check_match_path("k", {"body": ["\ts_cbranch_execnz .LBB0_1"] + good})                         # waterfall loop
+
+
+def test_chain_kernels_raise_their_priority(isa):
+    for name in ("seq_fwd_kernel", "seq_inv_kernel"):
+        sym = next(s for s in isa if name in s)
+        body = isa[sym]["body"]
+        first_valu = next(i for i, line in enumerate(body) if re.match(r"\s+v_", line))
+        prio = [i for i, line in enumerate(body) if re.match(r"\s+s_setprio 3", line)]
+        assert prio and prio[0] < first_valu + 40, (name, prio, first_valu)
+
+
+def test_register_and_scratch_budgets_against_the_committed_table(isa):
+    table = {}
+    for line in open(os.path.join(ROOT, "profiles", "r04_kernel_resources.txt")):
+        m = re.match(r"(\S+)\tVGPRs: (\d+)\tScratchSize: (\d+)", line)
+        if m:
+            table[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    assert len(table) >= 45
+    for sym, k in isa.items():
+        short = sym.replace("_ZN2vg", "", 1)
+        assert short in table, f"{sym}: not in profiles/r04_kernel_resources.txt (tools/kernel_resources.sh regenerates it)"
+        v, s = table[short]
+        assert k["vgpr"] <= v, f"{sym}: {k['vgpr']} VGPRs, committed {v}"
+        assert k["scratch"] <= s, f"{sym}: {k['scratch']} B scratch, committed {s}"

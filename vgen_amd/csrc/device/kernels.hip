@@ -98,6 +98,25 @@ __device__ __forceinline__ void shfl_xor_fe(fe &r, const fe &a, int mask) {
     for (int i = 0; i < 9; i++) r.n[i] = (u32)__shfl_xor((int)a.n[i], mask);
 }
 
+// ---- match compaction: one atomic per WAVE ------------------------------------------------------------
+// The candidates of a wave are compacted with the wave's own ballot (north_star: "wavefront ballot/reduce for match
+// compaction"): the lanes that hold a candidate are counted (s_bcnt1 of the ballot mask), the first of them reserves that
+// many consecutive slots of the frame's ring with ONE global atomic, and every candidate takes the reserved base plus its
+// rank among the wave's candidates (v_mbcnt of the mask).  Written out here rather than left to LLVM's atomic optimizer,
+// which happened to produce this form from a per-lane atomicAdd(…, 1): tests/test_isa_contract.py pins the result in the ISA.
+// Must be reached by all lanes of the wave that are still active together (it is: `hit` is computed by every such lane).
+// -> the slot relative to this dispatch's base for lanes with hit (monotonic counter, no per-dispatch reset), unspecified for the others.
+__device__ __forceinline__ u32 match_slot(DevMatchHeader *hdr, bool hit, u32 match_base) {
+    const unsigned long long m = __ballot(hit);
+    if (m == 0) return 0xFFFFFFFFu;            // wave-uniform: the common case costs the ballot and one scalar branch
+    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));   // candidates in lower lanes
+    const int leader = __ffsll((long long)m) - 1;
+    u32 first = 0;
+    if (hit && rank == 0) first = atomicAdd(&hdr->count, (u32)__popcll(m));
+    first = (u32)__builtin_amdgcn_readlane((int)first, leader);
+    return first + rank - match_base;
+}
+
 // ---- payload per format -----------------------------------------------------------------------------
 
 template <int FMT>
@@ -427,9 +446,10 @@ seq_bwd_kernel(const SeqArgs args) {
                         u32 *o = args.dump + (size_t)vindex * NW;
 #pragma unroll
                         for (int i = 0; i < NW; i++) o[i] = ple[i];
-                    } else if (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple)) {
-                        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-                        if (slot < args.match_cap) {
+                    } else {
+                        const bool hit = FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple);
+                        const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
+                        if (hit && slot < args.match_cap) {
                             DevMatch *m = args.mrec + slot;
                             m->index = vindex;
                             m->reserved = 0;
@@ -448,10 +468,11 @@ seq_bwd_kernel(const SeqArgs args) {
                 u32 *o = args.dump + (size_t)index * NW;
 #pragma unroll
                 for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
-            } else if (ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl))) {
+            } else {
                 // monotonic counter: no per-dispatch reset; this dispatch's slots start at match_base
-                const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-                if (slot < args.match_cap) {
+                const bool hit = ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl));
+                const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
+                if (hit && slot < args.match_cap) {
                     DevMatch *m = args.mrec + slot;
                     m->index = index;
                     m->reserved = 0;
@@ -573,9 +594,10 @@ __global__ void __launch_bounds__(WG) p2tr_finish_kernel(const SeqArgs args) {
             u32 *o = args.dump + (size_t)index * 8;
 #pragma unroll
             for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
-        } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
-            const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-            if (slot < args.match_cap) {
+        } else {
+            const bool hit = ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl));
+            const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
+            if (hit && slot < args.match_cap) {
                 DevMatch *m = args.mrec + slot;
                 m->index = index;
                 m->reserved = 0;
@@ -739,9 +761,10 @@ __global__ void __launch_bounds__(KEYS_WG) p2tr_out_kernel(const KeysArgs args) 
         u32 *o = args.dump + (size_t)idx * 8;
 #pragma unroll
         for (int i = 0; i < 8; i++) o[i] = ok ? pl[i] : 0u;
-    } else if (ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl))) {
-        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-        if (slot < args.match_cap) {
+    } else {
+        const bool hit = ok && (FULL ? dfa_match_payload_n<8>(dfa_lds, VGF_P2TR, pl) : filter_eval_n<8>(args.filter, pl));
+        const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
+        if (hit && slot < args.match_cap) {
             DevMatch *m = args.mrec + slot;
             m->index = idx;
             m->reserved = 0;
@@ -1009,9 +1032,10 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
                 u32 *o = args.dump + (size_t)vindex * NW;
 #pragma unroll
                 for (int i = 0; i < NW; i++) o[i] = live ? ple[i] : 0u;
-            } else if (live && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple))) {
-                const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-                if (slot < args.match_cap) {
+            } else {
+                const bool hit = live && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple));
+                const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
+                if (hit && slot < args.match_cap) {
                     DevMatch *m = args.mrec + slot;
                     m->index = vindex;
                     m->reserved = 0;
@@ -1030,9 +1054,10 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
         u32 *o = args.dump + (size_t)idx * NW;
 #pragma unroll
         for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
-    } else if (ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl))) {
-        const u32 slot = atomicAdd(&args.mhdr->count, 1u) - args.match_base;
-        if (slot < args.match_cap) {
+    } else {
+        const bool hit = ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl));
+        const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
+        if (hit && slot < args.match_cap) {
             DevMatch *m = args.mrec + slot;
             m->index = idx;
             m->reserved = 0;
