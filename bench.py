@@ -119,7 +119,8 @@ def cpu_model():
 
 
 def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
-    """The oracle's restatement of scan_range_cpu (reference src/scanner.rs:211-330) on this host's cores."""
+    """The oracle's restatements of scan_range_cpu (reference src/scanner.rs:211-330; `value`) and of the default random-key
+    loop scan_with_progress (src/scanner.rs:118-169; `random_loop`) on this host's cores, at nproc and on one thread."""
     from oracle import pyoracle as vo
     cores = usable_cores()
     fmt = FORMATS[fmt_name]
@@ -131,8 +132,24 @@ def cpu_baseline(fmt_name, pattern, ci, seconds_target=12.0):
     # and one thread (SURVEY 8(d) asks for both), on a sample of ~3 s
     n1 = int(max(20000, min(rate / cores * 3.0, 5e6)))
     one = vo.scan_range(fmt, pattern, start, start + n1 - 1, count=10**9, ci=ci, threads=1)
+    # The reference's DEFAULT CPU loop (scan_with_progress, src/scanner.rs:118-169: an independent random key per candidate,
+    # 10 000 per batch) beside the range loop, at nproc and on one thread (SURVEY.md 8(d) asks for both loops).  `value`
+    # stays the range loop so that the record is comparable across rounds.
+    random_loop = None
+    try:
+        nr = int(max(10000 * cores, min(rate * 6.0, 3e7)))
+        rr = vo.scan_random(fmt, pattern, 42, count=10**9, max_keys=nr, ci=ci, threads=cores)
+        nr1 = int(max(10000, min(rate / cores * 3.0, 5e6)))
+        r1 = vo.scan_random(fmt, pattern, 42, count=10**9, max_keys=nr1, ci=ci, threads=1)
+        random_loop = {"value": rr["operations"] / rr["elapsed_secs"] / 1e6, "single_thread_value": r1["operations"] / r1["elapsed_secs"] / 1e6,
+                       "unit": "Mkeys/sec", "cores": cores,
+                       "sample": f"oracle scan_random (src/scanner.rs:118-169 restated: a fresh random key per candidate — here the seeded counter-based "
+                                 f"stream —, full scalar mult + hash + encode + regex each, 10 000 per batch and thread): {rr['operations']} keys on {cores} "
+                                 f"threads in {rr['elapsed_secs']:.1f} s, {r1['operations']} keys on one thread in {r1['elapsed_secs']:.1f} s"}
+    except Exception as e:   # noqa: BLE001
+        random_loop = {"value": None, "error": f"{type(e).__name__}: {e}"}
     return {"value": res["operations"] / res["elapsed_secs"] / 1e6, "unit": "Mkeys/sec", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
-            "single_thread_value": one["operations"] / one["elapsed_secs"] / 1e6,
+            "single_thread_value": one["operations"] / one["elapsed_secs"] / 1e6, "random_loop": random_loop,
             "sample": f"oracle scan_range (full scalar mult + hash + encode + regex per key) over {res['operations']} "
                       f"consecutive keys from k0(seed=42), {cores} threads, {res['elapsed_secs']:.1f} s "
                       f"(single thread: {one['operations']} keys, {one['elapsed_secs']:.1f} s); "
@@ -147,27 +164,46 @@ class Pipeline:
         self.r, self.k0, self.world, self.rank = runner, k0, world, rank
         self.n, self.f = runner.batch_size, runner.frames
         self.next_step = 0
+        # host time of the last run_steps(host_times=True): seconds inside dispatch calls (base points + three launches + a
+        # copy through ctypes) and inside wait calls (blocked on the frame's stream + the return)
+        self.host_dispatch_s = self.host_wait_s = 0.0
 
-    def run_steps(self, n_steps, collect=False):
-        """Exactly n_steps dispatches, all completed on return.  -> (candidates, [seq_bwd ms])"""
+    def run_steps(self, n_steps, collect=False, host_times=False):
+        """Exactly n_steps dispatches, all completed on return.  -> (candidates, [seq_bwd ms]).  host_times: also sum the
+        wall time spent inside the dispatch and the wait calls (two clock reads per call, ~0.1 us each)."""
         r, F = self.r, self.f
         cand, kms, issued, done, fi, fw = 0, [], 0, 0, 0, 0
         first = self.next_step
+        clock = time.perf_counter
+        td = tw = 0.0
         while issued < min(F, n_steps):
+            if host_times:
+                t = clock()
             r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), fi)
+            if host_times:
+                td += clock() - t
             issued += 1
             fi = (fi + 1) % F
         while done < n_steps:
+            if host_times:
+                t = clock()
             n, _ = r.wait(fw)
+            if host_times:
+                tw += clock() - t
             if collect:
                 kms.append(r.kernel_ms(fw))
             cand += n
             done += 1
             if issued < n_steps:
+                if host_times:
+                    t = clock()
                 r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), fw)
+                if host_times:
+                    td += clock() - t
                 issued += 1
             fw = (fw + 1) % F
         self.next_step = first + n_steps
+        self.host_dispatch_s, self.host_wait_s = td, tw
         return cand, kms
 
     def run_seconds(self, seconds, min_steps=0, clock=False):
@@ -365,6 +401,156 @@ def dump_mode_configs(vg, batch, device, seconds):
     return out
 
 
+def parse_cpulist(text):
+    """'0-15,64-79' -> {0..15, 64..79} (sysfs cpulist format)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def format_cpulist(cpus):
+    out, run = [], []
+    for c in sorted(cpus) + [None]:
+        if run and (c is None or c != run[-1] + 1):
+            out.append(str(run[0]) if len(run) == 1 else f"{run[0]}-{run[-1]}")
+            run = []
+        if c is not None:
+            run.append(c)
+    return ",".join(out)
+
+
+def gpu_pci_addresses(sysfs="/sys"):
+    """PCI addresses of the GPUs in HIP device order, from the KFD topology — no HIP call, so it can run before torch or
+    libvgen_hip.so touch the runtime.  (ROCr enumerates its GPU agents in KFD node order and HIP keeps that order;
+    *_VISIBLE_DEVICES index lists are applied by the caller.)"""
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    out = []
+    for node in sorted(os.listdir(base), key=int):
+        props = {}
+        for line in open(os.path.join(base, node, "properties")):
+            k, _, v = line.strip().partition(" ")
+            props[k] = v
+        if int(props.get("simd_count", "0")) == 0:
+            continue   # a CPU node
+        loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        out.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+    return out
+
+
+def numa_pin(local_rank, sysfs="/sys"):
+    """Pins this process to the CPU cores of the NUMA node its GPU hangs off (VERDICT r03 #1b), BEFORE torch or HIP are
+    touched: the dispatch thread, the HIP runtime's own threads and the pinned host buffers they first touch then stay on
+    the socket the device's PCIe root belongs to — on an 8-GPU node four ranks per socket, instead of eight dispatch loops
+    wherever the scheduler puts them.  Never fatal: anything unreadable (no KFD topology, UUID-style *_VISIBLE_DEVICES, a
+    single-node box) leaves the affinity alone and says why.  -> dict for the result line."""
+    info = {"pinned": False, "numa_node": None, "cpus": format_cpulist(os.sched_getaffinity(0))}
+    try:
+        addrs = gpu_pci_addresses(sysfs)
+        vis = next((os.environ[v] for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(v)), None)
+        if vis:
+            addrs = [addrs[int(x)] for x in vis.split(",")]     # (UUIDs: ValueError -> left alone)
+        if not addrs:
+            raise RuntimeError("no GPU in the KFD topology")
+        bdf = addrs[local_rank % len(addrs)]                    # (rehearsals put several ranks on one device)
+        dev = os.path.join(sysfs, "bus/pci/devices", bdf)
+        node = int(open(os.path.join(dev, "numa_node")).read())
+        info.update({"numa_node": node, "pci": bdf})
+        cur = os.sched_getaffinity(0)
+        want = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read()) & cur
+        if node < 0 or not want:
+            info["why_not"] = "the device reports no NUMA node" if node < 0 else "none of the node's cores is in this process's affinity mask"
+        elif want == cur:
+            info["why_not"] = "already confined to the node's cores"
+        else:
+            os.sched_setaffinity(0, want)
+            info.update({"pinned": True, "cpus": format_cpulist(want)})
+    except Exception as e:   # noqa: BLE001  (pinning is an optimisation, never a reason to fail)
+        info["why_not"] = f"{type(e).__name__}: {e}"
+    return info
+
+
+def rank_report(per_rank):
+    """The N > 1 line's per-rank arrays and what they say together (VERDICT r03 #1a), from the dicts the ranks gathered:
+    a sub-linear point of the 1 -> 2 -> 4 -> 8 curve must name its cause from ONE run.
+      value / sustained        a slow RANK (its device, its socket) shows as one low entry; a slow NODE as all low
+      region_mhz / sustained_mhz   the shader clock each device held: a power / thermal cap shows here, not in the host times
+      host_dispatch_us / host_wait_us  per step: the dispatch call growing with N = the host is the bottleneck (cores, memory,
+                               runtime locks); wait shrinking to ~0 with a low rate = the device starves
+      t0_us / t1_us            start and finish offsets from the earliest start: start_skew_us large against the region =
+                               the opening barrier released the ranks unevenly (the job's elapsed time counts it)"""
+    per_rank = sorted(per_rank, key=lambda r: r["rank"])
+    t0 = min(r["t0"] for r in per_rank)
+    cols = {}
+    for r in per_rank:
+        r = dict(r, t0_us=round((r["t0"] - t0) * 1e6, 1), t1_us=round((r["t1"] - t0) * 1e6, 1))
+        for k, v in r.items():
+            if k not in ("t0", "t1"):
+                cols.setdefault(k, []).append(v)
+    timing = {"start_skew_us": round((max(r["t0"] for r in per_rank) - t0) * 1e6, 1),
+              "finish_skew_us": round((max(r["t1"] for r in per_rank) - min(r["t1"] for r in per_rank)) * 1e6, 1)}
+    return cols, timing
+
+
+def multi_leg_child(seconds, batch, frames):
+    """Runs in a CHILD process of rank 0 (bench.py --multi-leg-child): the product's own multi-device path — vgen_scan_multi,
+    what `vgen-hip --devices all` calls: one process, one context and one host thread per device, 12 streams each — over ALL
+    visible devices for `seconds` of wall time, on a pattern nothing matches.  Prints one JSON object."""
+    import ctypes
+    import threading
+    import vgen_amd as vg
+    n = vg.device_count()
+    fmt = vg.AddressFormat.P2pkh
+    t0 = time.perf_counter()
+    runners = [vg.GpuRunner(batch_size=batch, fmt=fmt, device=i, frames=frames, timing=False) for i in range(n)]
+    t_create = time.perf_counter() - t0
+    stop = ctypes.c_int32(0)
+    timer = threading.Timer(seconds, lambda: setattr(stop, "value", 1))
+    timer.start()
+    res = vg.scan_gpu_with_runner("^1ZZZZZZZZZZZZ", vg.ScanConfig(format=fmt, count=None, seed=42), runners, stop=stop, force_multi=True)
+    timer.cancel()
+    for r in runners:
+        r.close()
+    rss_kb = 0
+    try:
+        rss_kb = int(next(l for l in open("/proc/self/status") if l.startswith("VmHWM")).split()[1])
+    except Exception:   # noqa: BLE001
+        pass
+    print(json.dumps({"value": round(res.operations / res.elapsed_secs / 1e6, 1), "unit": "Mkeys/sec", "n_devices": n,
+                      "failed_shards": res.failed_shards, "seconds": round(res.elapsed_secs, 3), "operations": res.operations,
+                      "matches": len(res.matches), "frames_per_device": frames, "create_s": round(t_create, 3),
+                      "peak_rss_gib": round(rss_kb / 2**20, 2),
+                      "what": "vgen_scan_multi over all visible devices in ONE process (a context and a host thread per device; pattern "
+                              "'^1ZZZZZZZZZZZZ', seed 42, stopped by the host's stop flag); includes the ramp-up of the frames' streams"}), flush=True)
+
+
+def in_process_multi(seconds, batch, frames, affinity=None):
+    """Rank 0, after every rank has closed its context: the leg above in a child process with a deadline — a failure, a hang
+    or a crash of the in-process path costs this entry, never the headline line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                            "MASTER_ADDR", "MASTER_PORT", "VGEN_BENCH_REHEARSE") and not k.startswith("TORCHELASTIC")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--multi-leg-child", "--multi-leg-seconds", str(seconds), "--batch", str(batch), "--frames", str(frames)]
+
+    def unpin():   # the child drives every device of the node: the whole box's cores, not this rank's socket
+        if affinity:
+            try:
+                os.sched_setaffinity(0, affinity)
+            except OSError:
+                pass
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=seconds + 120, preexec_fn=unpin)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"value": None, "error": f"child exited with {p.returncode}: {p.stderr.strip()[-300:]}"}
+        return json.loads(lines[-1])
+    except Exception as e:   # noqa: BLE001  (TimeoutExpired included: subprocess.run has killed the child)
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:400]}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a child process
     (rendezvous on 127.0.0.1, a free port), pass the same arguments on, relay the one JSON line of rank 0.
@@ -406,7 +592,15 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="wall time of the `sustained` leg (0 = skip)")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-numa-pin", action="store_true", help="leave the CPU affinity alone (default: every rank pins itself to the cores of its GPU's NUMA node)")
+    ap.add_argument("--multi-leg-seconds", type=float, default=3.0, help="wall time of the in-process vgen_scan_multi leg over all visible devices "
+                                                                         "(N > 1, or N = 1 on a multi-GPU box; 0 = skip)")
+    ap.add_argument("--multi-leg-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.multi_leg_child:
+        multi_leg_child(args.multi_leg_seconds, args.batch, args.frames)
+        return
 
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -421,6 +615,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (one rank per GPU: they must agree)")
+    # before torch or HIP are touched: the cores of this rank's GPU's NUMA node (reported in config.cpu_affinity / per_rank)
+    affinity0 = os.sched_getaffinity(0)
+    pin = {"pinned": False, "why_not": "--no-numa-pin", "cpus": format_cpulist(affinity0), "numa_node": None} if args.no_numa_pin else numa_pin(local_rank)
 
     import torch   # first: the process then shares torch's HIP runtime with libvgen_hip.so
     import torch.distributed as dist
@@ -503,10 +700,11 @@ def main():
     # 20-step region would see ----
     sustained = None
     shader_mhz = None
+    n_s = own_dt_s = 0
     if args.sustained_seconds > 0:
         barrier()
         ts = time.perf_counter()
-        n_s, _ = pipe.run_seconds(args.sustained_seconds, clock=True)
+        n_s, own_dt_s = pipe.run_seconds(args.sustained_seconds, clock=True)
         barrier()
         dt_s = max_over_ranks(time.perf_counter() - ts)
         if world > 1:   # every rank stops on its own clock: sum the dispatches
@@ -528,7 +726,7 @@ def main():
     # gloo barrier itself (hundreds of microseconds against a 2 ms region).  At N = 1 this is the plain bracket.
     barrier()
     t0 = time.perf_counter()
-    cand, _ = pipe.run_steps(args.steps)
+    cand, _ = pipe.run_steps(args.steps, host_times=True)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -551,6 +749,18 @@ def main():
             region_mhz = round(sum(c for c, _ in cs) / sum(t for _, t in cs) * 100.0)
     except Exception:   # noqa: BLE001  (dump-mode runs carry no clock sample)
         pass
+
+    # What this rank saw, gathered from all ranks for the N > 1 line (rank_report): its own rate over the region and over the
+    # sustained leg, the clocks its device held, the host's time inside the dispatch / wait calls, when it started and finished.
+    mine = {"rank": rank, "device": local_rank, "value": round(args.steps * N * K6 / (t1 - t0) / 1e6, 1),
+            "sustained": round(n_s * N * K6 / own_dt_s / 1e6, 1) if own_dt_s else None,
+            "region_mhz": region_mhz, "sustained_mhz": round(shader_mhz) if shader_mhz else None,
+            "host_dispatch_us": round(pipe.host_dispatch_s / args.steps * 1e6, 2), "host_wait_us": round(pipe.host_wait_s / args.steps * 1e6, 2),
+            "numa_node": pin.get("numa_node"), "cpus": pin.get("cpus"), "pinned": pin.get("pinned"), "t0": t0, "t1": t1}
+    per_rank = None
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     w_key = work_per_key(args.format, args.endo)
     # the dominant kernel (seq_bwd_kernel) does everything except the per-lane prefix products of
@@ -630,13 +840,17 @@ def main():
                                   else f"{N} keys/dispatch, compressed pubkey, sequential-range mode"),
                    "keys_per_dispatch": N, "frames_in_flight": F, "topology": runner.topology(),
                    "parallelism": f"range-striped x{world}" + (" (REHEARSAL: ranks share a GPU)" if rehearse else ""),
-                   "device_filter_kind": pat.device_kind, "candidates_reported": cand},
+                   "device_filter_kind": pat.device_kind, "candidates_reported": cand,
+                   "cpu_affinity": {k: pin.get(k) for k in ("pinned", "numa_node", "cpus", "pci", "why_not") if pin.get(k) is not None},
+                   "host_us_per_step": {"dispatch": mine["host_dispatch_us"], "wait": mine["host_wait_us"]}},
         "sustained": sustained,
         "roofline": roofline,
     }
     if world > 1:
+        cols, skew = rank_report(per_rank)
+        out["per_rank"] = cols
         out["timing"] = {"elapsed_ms": round(elapsed * 1e3, 4), "slowest_rank_ms": round(slowest_rank_s * 1e3, 4),
-                         "closing_barrier_ms_rank0": round((t_barrier - t1) * 1e3, 4),
+                         "closing_barrier_ms_rank0": round((t_barrier - t1) * 1e3, 4), **skew,
                          "how": "elapsed = latest finish - earliest start over the ranks (one node, system-wide monotonic clock); "
                                 "start: after the opening barrier + synchronize, finish: after the rank's closing synchronize; "
                                 "the closing barrier follows the clock"}
@@ -677,6 +891,15 @@ def main():
         except Exception as e:   # noqa: BLE001
             out["time_to_first_match"] = {"error": f"{type(e).__name__}: {e}"}
     runner.close()
+    # ---- the product's own multi-device path, once, over ALL visible devices in ONE process (vgen_scan_multi: what
+    # `vgen-hip --devices all` runs; bench.py's ranks are N processes).  After every rank has closed its context; rank 0
+    # starts it as a child process with a deadline, the other ranks wait at the barrier.  Never part of `value`.
+    if args.multi_leg_seconds > 0 and (world > 1 or torch.cuda.device_count() > 1):
+        barrier()
+        if rank == 0:
+            out["in_process_multi"] = in_process_multi(args.multi_leg_seconds, args.batch, args.frames, affinity0)
+        if world > 1:
+            dist.barrier()
     if rank == 0 and world == 1 and not args.no_other_configs:
         sec = 1.0
         # every auxiliary leg stands alone: a failure there is recorded in its entry and never costs the headline line
@@ -711,6 +934,7 @@ def main():
         out["other_configs"] = oc
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
+            os.sched_setaffinity(0, affinity0)      # the CPU baseline is the whole box's cores, not this rank's socket
             out["cpu_baseline"] = cpu_baseline(args.format, args.pattern, args.ci)
         except Exception as e:   # noqa: BLE001  (the oracle library missing or failing must not cost the line)
             out["cpu_baseline"] = {"value": None, "unit": "Mkeys/sec", "cores": usable_cores(), "cpu_model": cpu_model(), "kind": "port", "sample": None,

@@ -24,8 +24,10 @@
 extern "C" {
 #endif
 
-#define VGEN_ABI_VERSION 2   /* 2: frames = 0 selects 12; vgen_get_topology reports streams / priority levels; vgen_dispatch_random;
-                                  vgen_scan_multi returns partial results beside an error */
+#define VGEN_ABI_VERSION 3   /* 2: frames = 0 selects 12; vgen_get_topology reports streams / priority levels; vgen_dispatch_random;
+                                  vgen_scan_multi returns partial results beside an error
+                                  3: vgen_get_resources; the fault-injection entry point left the library (test build only);
+                                  random-key streams take a 24-byte seed (vgen_dispatch_random_seed / vgen_random_key_seed) */
 
 typedef enum vgen_status {
     VGEN_OK = 0,
@@ -126,6 +128,23 @@ int vgen_get_info(const vgen_ctx *ctx, uint32_t *batch_size, uint32_t *frames, u
 int vgen_get_topology(const vgen_ctx *ctx, uint32_t *streams, uint32_t *hw_queues, uint32_t *priority_levels,
                       int32_t *oversubscribed);
 
+/* What the context has — or will get — of two resources it sizes itself (the reference's GpuRunner allocates fixed
+ * buffers for its two frames, src/gpu.rs:391-500, and has no tables).  Any pointer may be NULL.
+ *   *dump_frames        frames that can be dispatched in DUMP mode (vgen_set_filter(NULL), or a filter of device kind 0):
+ *                       all of them unless their pinned host mirrors would pass ~1 GiB (never fewer than 2) — e.g. 8 of 12
+ *                       on a VGEN_FLAG_ENDO context at 2^20 keys per dispatch (6 x 20 MB per frame).  vgen_dispatch* on a
+ *                       frame >= *dump_frames in dump mode is VGEN_E_STATE; vgen_scan drives only the frames that have a buffer.
+ *   *table_bits         window width of the fixed-base generator table the scalar-multiplication paths (P2TR, vgen_dispatch_keys,
+ *                       vgen_dispatch_random) use: 0 = none built yet (first use builds it), 8 = the 8-bit table only,
+ *                       16 / 20 / 22 / 24 / 26 = the wide table in use (shared by all contexts of the process on this device).
+ *   *table_bits_wanted  the width asked for (VGEN_GTAB_BITS, default 24).  *table_bits < *table_bits_wanted after a dispatch
+ *                       means the allocation or build of the wider tables failed and the context stepped down (24 -> 22 ->
+ *                       20 -> 16 -> 8): same keys, fewer per second (10 / 11 / 12 / 15 / 31 additions per multiplication).
+ *   note                why it stepped down ("" when it did not), NUL-terminated, truncated to note_cap.
+ * A step-down is not an error: the dispatch that caused it returned VGEN_OK and vgen_last_error is untouched. */
+int vgen_get_resources(const vgen_ctx *ctx, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted,
+                       char *note, size_t note_cap);
+
 /* ---- pattern: Pattern::new / Pattern::matches (src/pattern.rs:21-45) -------------------------------- */
 
 /* Compiles `pattern` (prefixed with "(?i)" when case_insensitive, pattern.rs:26-30) into (a) a DFA
@@ -161,7 +180,8 @@ int vgen_pattern_difficulty(const char *pattern, int case_insensitive, uint32_t 
 /* AddressFormat::charset_name (src/address.rs:39-45): "Base58" | "Bech32" | "Hex"; NULL for an unknown format. */
 const char *vgen_format_charset_name(uint32_t format);
 /* Selects the filter for subsequent dispatches; NULL = dump mode (every payload is written,
- * index order — the reference kernel's behaviour, src/shaders/search.wgsl:2-31). */
+ * index order — the reference kernel's behaviour, src/shaders/search.wgsl:2-31).  Dump mode serves the first
+ * *dump_frames frames of the context (vgen_get_resources): its pinned host mirrors are bounded to ~1 GiB. */
 int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 
 /* Resizes the match rings of all frames to match_cap records per dispatch (clamped to [256, batch_size], 6 x batch_size on a
@@ -169,13 +189,6 @@ int vgen_set_filter(vgen_ctx *ctx, const vgen_filter *f);
  * no dispatch is in flight.  vgen_scan uses it to keep permissive patterns on the device filter: the reference hands
  * EVERY hash to the host (src/gpu.rs:602-658); here the ring grows to hold the expected candidates instead. */
 int vgen_set_match_cap(vgen_ctx *ctx, uint32_t match_cap);
-
-/* ---- fault injection (tests) --------------------------------------------------------------------------------- */
-
-/* Makes the context's dispatches fail with VGEN_E_HIP after `after_dispatches` more of them have been accepted (as a device
- * that drops off the bus would); UINT64_MAX disarms.  The reference has no fault injection; the multi-device
- * failure semantics above are tested through this. */
-int vgen_debug_fail_after(vgen_ctx *ctx, uint64_t after_dispatches);
 
 /* ---- measurement aid -------------------------------------------------------------------------------------- */
 
@@ -202,12 +215,19 @@ int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, ui
 /* Independent random keys — the shape of the reference's CPU hot loop, which draws 32 fresh bytes per candidate
  * (rng.fill, src/scanner.rs:144-152) — without any upload: lane i of the dispatch tests candidate first_index + i of
  * the counter-based scalar stream
- *     key(seed, stream, index) = SHA-256("vgen-mi355x-rand" || u64le(seed) || u32le(stream) || u64le(index)),
+ *     key(seed, stream, index) = SHA-256("vgen-mi355x-rand" || seed[24] || u32le(stream) || u64le(index)),
  * computed on the device (one SHA-256 compression per lane); draws that are 0 or >= n yield no result, as the
- * reference skips them (src/address.rs:93).  A match reports index i: vgen_random_key re-derives its key on the host.
- * `stream` separates scanners that share a seed (one per GPU / shard).  Always batch_size candidates. */
+ * reference skips them (src/address.rs:93).  A match reports index i: vgen_random_key_seed re-derives its key on the host.
+ * `stream` separates scanners that share a seed (one per GPU / shard).  Always batch_size candidates.
+ * THE SEED IS ALL THE SECRET THERE IS: stream and index are small, so a key found by this mode is exactly as hard to
+ * recover from its address as the seed is to guess.  Real searches use the 24-byte form with 24 bytes of OS entropy
+ * (vgen_scan does when vgen_scan_config.seed == 0; the reference seeds a 256-bit StdRng from the OS, src/scanner.rs:144);
+ * 24 rather than 32 bytes keep the message in one SHA-256 block.  The uint64_t forms stand for seed = u64le(seed) ||
+ * sixteen zero bytes and exist for reproducible runs and tests — never for keys that will hold value. */
+int vgen_dispatch_random_seed(vgen_ctx *ctx, uint32_t frame, const uint8_t seed[24], uint32_t stream, uint64_t first_index);
 int vgen_dispatch_random(vgen_ctx *ctx, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index);
-/* The key vgen_dispatch_random's lane (index - first_index) tests; VGEN_E_RANGE when that draw is not a valid scalar. */
+/* The key vgen_dispatch_random*'s lane (index - first_index) tests; VGEN_E_RANGE when that draw is not a valid scalar. */
+int vgen_random_key_seed(const uint8_t seed[24], uint32_t stream, uint64_t index, uint8_t key_be[32]);
 int vgen_random_key(uint64_t seed, uint32_t stream, uint64_t index, uint8_t key_be[32]);
 /* GpuRunner::await_result(frame) (src/gpu.rs:602-658): blocks until the frame's dispatch is done.
  * Filter mode: copies up to cap records to out (ascending index), stores the number found in
@@ -218,7 +238,8 @@ int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint
 /* Dump mode only, after vgen_wait: copies the frame's payloads (batch_size * 20 bytes, or * 32 for
  * P2TR; zeroed for invalid keys) — the Vec<[u8;20]> await_result returns (src/gpu.rs:644-650). */
 int vgen_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
-/* The same payloads without the copy: a dump-mode dispatch ends with its own asynchronous transfer into pinned
+/* (Both dump readers: frames 0 .. dump_frames-1 only, see vgen_get_resources.)
+ * The same payloads without the copy: a dump-mode dispatch ends with its own asynchronous transfer into pinned
  * host memory, and this returns that buffer (valid until the frame is dispatched again) — what the host-side
  * filter loop of scan_gpu_with_runner reads (src/gpu.rs:1030-1093). */
 int vgen_dump_view(vgen_ctx *ctx, uint32_t frame, const uint8_t **ptr, size_t *len);
@@ -300,7 +321,9 @@ typedef struct vgen_scan_config {
 /* vgen_scan_config.flags */
 #define VGEN_SCAN_RANDOM_KEYS 1u   /* scan_with_progress's shape (src/scanner.rs:118-169): every candidate an independent random key
                                       (vgen_dispatch_random: batch b tests candidates b * batch_size .. of stream `shard` under
-                                      `seed`; seed 0 = OS entropy) instead of the reference GPU path's walk from one base key.
+                                      `seed`; seed 0 = 24 bytes of OS entropy, the only setting for keys that will hold value: a
+                                      nonzero 64-bit seed makes the run reproducible and its keys guessable, see
+                                      vgen_dispatch_random_seed) instead of the reference GPU path's walk from one base key.
                                       A full scalar multiplication per key: ~10x slower than the walk.  No start / end; a
                                       checkpoint records the seed and the batches done per stream.  With a fixed seed (and without VGEN_FLAG_ENDO) the matches are those of
                                       the oracle's scan_random walk of the same stream, in the same order.  On a VGEN_FLAG_ENDO

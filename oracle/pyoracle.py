@@ -169,10 +169,13 @@ def seed_key(seed, shard=0):
 
 def random_key(seed, stream, index):
     """The oracle's counter-based candidate stream (vo_scan.c: random_key, the keys vo_scan_random's worker `stream`
-    walks): SHA-256("vgen-mi355x-rand" || u64le(seed) || u32le(stream) || u64le(index)) as a big-endian integer.
+    walks): SHA-256("vgen-mi355x-rand" || seed[24] || u32le(stream) || u64le(index)) as a big-endian integer; seed: the 24
+    bytes themselves, or an integer < 2^64 standing for u64le(seed) || sixteen zero bytes (the C ABI's 64-bit seeds).
     Restated here with hashlib, independently of both C implementations.  Invalid draws (0, >= n) yield no key."""
     import hashlib
-    return int.from_bytes(hashlib.sha256(b"vgen-mi355x-rand" + seed.to_bytes(8, "little") + stream.to_bytes(4, "little")
+    sb = bytes(seed) if isinstance(seed, (bytes, bytearray)) else seed.to_bytes(8, "little") + bytes(16)
+    assert len(sb) == 24
+    return int.from_bytes(hashlib.sha256(b"vgen-mi355x-rand" + sb + stream.to_bytes(4, "little")
                                          + index.to_bytes(8, "little")).digest(), "big")
 
 

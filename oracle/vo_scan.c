@@ -216,10 +216,12 @@ typedef struct {
 } rnd_arg;
 
 static void random_key(uint64_t seed, uint32_t tid, uint64_t i, uint8_t out[32]) {
-    uint8_t buf[16 + 8 + 4 + 8];
+    /* 24 seed bytes: the u64 little-endian, then sixteen zero bytes (the product's unseeded scans fill all 24 from the OS) */
+    uint8_t buf[16 + 24 + 4 + 8];
     size_t n = 16;
     memcpy(buf, "vgen-mi355x-rand", 16);
     for (int k = 0; k < 8; k++) buf[n++] = (uint8_t)(seed >> (8 * k));
+    for (int k = 0; k < 16; k++) buf[n++] = 0;
     for (int k = 0; k < 4; k++) buf[n++] = (uint8_t)(tid >> (8 * k));
     for (int k = 0; k < 8; k++) buf[n++] = (uint8_t)(i >> (8 * k));
     vo_sha256(buf, n, out);

@@ -43,6 +43,15 @@ void core_fe_inv_fermat(const u32 *a, u32 *r) {
     for (int i = 0; i < 9; i++) r[i] = z.n[i];
 }
 // One batch of 29 divsteps on given low words (unit test of the matrix against the textbook recurrence).
+// the inversion's final lift: signed limbs of d in (-2p, p), the sign word of f -> canonical sign(f) * d mod p
+void core_fe_divsteps_lift(const int *d, int f_top, u32 *r) {
+    fe_sgn ds;
+    for (int i = 0; i < 9; i++) ds.n[i] = d[i];
+    fe o;
+    fe_divsteps_lift_(o, ds, f_top);
+    for (int i = 0; i < 9; i++) r[i] = o.n[i];
+}
+
 int core_fe_divsteps29(int zeta, u32 f, u32 g, int *t) {
     int32_t tt[4];
     const int32_t z = fe_divsteps29_(zeta, f, g, tt);

@@ -18,7 +18,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/vgen_hip.h"
+#include "vgen_hip_hooks.h"   // include/vgen_hip.h + the test build's fault-injection entry point
 #include "../../oracle/vgen_oracle.h"
 
 static int g_fail = 0;

@@ -397,7 +397,7 @@ int rt_dispatch_keys(vgen_ctx *c0, uint32_t frame, const uint8_t *keys_be, uint3
     }, endo);
 }
 
-int rt_dispatch_random(vgen_ctx *c0, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
+int rt_dispatch_random(vgen_ctx *c0, uint32_t frame, const RndSeed &seed, uint32_t stream, uint64_t first_index) {
     FakeCtx *c = fc(c0);
     if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
     if (first_index > UINT64_MAX - (c->batch - 1)) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
@@ -409,7 +409,7 @@ int rt_dispatch_random(vgen_ctx *c0, uint32_t frame, uint64_t seed, uint32_t str
         for (uint32_t i = 0; i < c->batch; i++) {
             Scalar k;
             const uint64_t idx = first_index + i;
-            rnd_scalar((uint32_t)seed, (uint32_t)(seed >> 32), stream, (uint32_t)idx, (uint32_t)(idx >> 32), k.w);
+            rnd_scalar(seed, stream, (uint32_t)idx, (uint32_t)(idx >> 32), k.w);
             emit_images(c, ff, dump, i, k, endo);
         }
     }, endo);
@@ -473,5 +473,12 @@ int rt_frame_clock(vgen_ctx *, uint32_t, uint32_t *cycles, uint32_t *ticks) {
 }
 int rt_clock_probe_start(vgen_ctx *c, uint32_t) { return c->fail(VGEN_E_UNSUPPORTED, "fake runtime: no clock probe"); }
 int rt_clock_probe_read(vgen_ctx *c, double *) { return c->fail(VGEN_E_UNSUPPORTED, "fake runtime: no clock probe"); }
+int rt_get_resources(const vgen_ctx *c, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note) {
+    if (dump_frames) *dump_frames = c->dump_frames ? c->dump_frames : c->frames;
+    if (table_bits) *table_bits = 0;      // (the stand-in multiplies on the host: no generator table)
+    if (table_bits_wanted) *table_bits_wanted = 0;
+    if (note) note->clear();
+    return VGEN_OK;
+}
 
 }  // namespace vg

@@ -21,11 +21,35 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "vgen_amd", "libvgen_hip.so"))
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.vgen_abi_version() == 2
+    assert lib.vgen_abi_version() == 3
     # ... and INTEGRATION.md shows the reference-side binding of every one of them
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     undocumented = [n for n in sorted(names) if n not in doc]
     assert not undocumented, undocumented
+
+
+def test_fault_injection_is_not_part_of_the_shipped_library():
+    """vgen_debug_fail_after and the VGEN_DEBUG_GTAB_FAIL switch exist only in the test build (tests/native/
+    libvgen_hip_hooks.so, the same sources with -DVGEN_TEST_HOOKS): the shipped library exports no debug symbol, reads no
+    debug variable, and neither the header nor the reference-side binding in INTEGRATION.md declares one."""
+    from conftest import HOOKS_SO
+    lib = ctypes.CDLL(os.path.join(ROOT, "vgen_amd", "libvgen_hip.so"))
+    assert not hasattr(lib, "vgen_debug_fail_after")
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "vgen_amd", "libvgen_hip.so")], capture_output=True, text=True).stdout
+    assert "debug" not in syms.lower()
+    blob = open(os.path.join(ROOT, "vgen_amd", "libvgen_hip.so"), "rb").read()
+    assert b"VGEN_DEBUG" not in blob and b"injected device failure" not in blob
+    assert "vgen_debug" not in open(os.path.join(ROOT, "include", "vgen_hip.h")).read()
+    assert "vgen_debug" not in open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    # the environment variables the shipped library does read are the documented ones
+    env = set(re.findall(rb"VGEN_[A-Z0-9_]+", blob))
+    read = {b"VGEN_SEQ_S", b"VGEN_GTAB_BITS", b"VGEN_TRACE_CREATE"}                         # getenv'ed (INTEGRATION.md lists them)
+    named_in_messages = {b"VGEN_FLAG_ENDO", b"VGEN_FLAG_TIMING", b"VGEN_SCAN_RANDOM_KEYS"}    # ABI constants quoted in error texts
+    assert read <= env <= read | named_in_messages, env
+    # ... and the test build has both hooks
+    hooks = ctypes.CDLL(HOOKS_SO)
+    assert hasattr(hooks, "vgen_debug_fail_after") and b"VGEN_DEBUG_GTAB_FAIL" in open(HOOKS_SO, "rb").read()
+    assert hooks.vgen_abi_version() == lib.vgen_abi_version()
 
 
 def test_no_device_is_a_loud_error_not_a_cpu_fallback():
@@ -66,9 +90,20 @@ def test_random_key_stream_is_the_oracles():
     rng = random.Random(3)
     cases = [(42, 0, 0), (42, 0, 1), (2**64 - 1, 2**32 - 1, 2**64 - 1), (0, 0, 0), (1, 2**31, 2**32), (7, 3, 2**40 + 5)]
     cases += [(rng.getrandbits(64), rng.getrandbits(32), rng.getrandbits(64)) for _ in range(2000)]
+    # the 24-byte seeds of real (unseeded) searches — vgen_random_key_seed —, and their relation to the 64-bit ones
+    cases += [(rng.randbytes(24), rng.getrandbits(32), rng.getrandbits(64)) for _ in range(2000)]
+    cases += [(bytes(24), 0, 0), (b"\xff" * 24, 2**32 - 1, 2**64 - 1), (bytes(23) + b"\x01", 0, 0), (b"\x01" + bytes(23), 0, 0)]
     for seed, stream, index in cases:
         want = vo.random_key(seed, stream, index)
         assert vg.random_key(seed, stream, index) == (want if 0 < want < n else None)
+    for s in (0, 1, 42, 2**64 - 1, rng.getrandbits(64)):
+        assert vg.random_key(s, 3, 99) == vg.random_key(s.to_bytes(8, "little") + bytes(16), 3, 99)    # u64 = bytes 0..7, rest zero
+    assert vg.random_key(bytes(23) + b"\x01", 0, 0) != vg.random_key(bytes(24), 0, 0)                    # every seed byte counts
+    assert len({vg.random_key(bytes(i) + b"\x80" + bytes(23 - i), 1, 2) for i in range(24)}) == 24
+    # known answer, computed by hand with hashlib: pins the message layout (tag, 24 seed bytes, stream, index; 52 bytes)
+    import hashlib
+    kat = hashlib.sha256(b"vgen-mi355x-rand" + bytes(range(24)) + (7).to_bytes(4, "little") + (2**40 + 5).to_bytes(8, "little")).digest()
+    assert vg.random_key(bytes(range(24)), 7, 2**40 + 5) == int.from_bytes(kat, "big")
     # the C oracle's single worker walks stream 0 in index order: its matches are candidates of that stream, ascending
     res = vo.scan_random(0, "^1A", 42, count=4, threads=1)
     keys = [m["key"] for m in res["matches"]]

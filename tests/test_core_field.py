@@ -155,6 +155,34 @@ def test_inv(core):
     assert val(r) % P == 0
 
 
+def test_inversion_final_lift_over_the_whole_range_of_d(core):
+    """The last step of fe_inv turns d, anywhere in (-2p, p) as signed 9 x 29 limbs, into the canonical sign(f) * d.  The
+    inversion itself practically never produces a d near -2p, so the lift is driven directly: both ends of the interval and
+    their neighbourhoods (round 3's lift by 2p wrapped limb 8 for f > 0 and d within ~2^233 of -2p), zero, +-1, +-p and
+    random values, for both signs of f."""
+    import ctypes
+    I9 = ctypes.c_int * 9
+
+    def signed_limbs(d):
+        # limbs 0..7 in [0, 2^29), limb 8 carries the sign: d = sum n_i 2^(29 i)
+        n = [(d >> (29 * i)) & 0x1FFFFFFF for i in range(8)]
+        n.append(d >> 232)          # arithmetic shift: floor division, negative for negative d
+        assert sum(x << (29 * i) for i, x in enumerate(n)) == d and -2**26 < n[8] < 2**26
+        return n
+    rng = random.Random(77)
+    ds = [0, 1, -1, P - 1, P - 2, -P, -P + 1, -P - 1, -2 * P + 1, -2 * P + 2, -2 * P + 2**40, -2 * P + 2**232, -2 * P + 2**233 + 12345,
+          -2 * P + 2**240, -(1 << 256), -(1 << 256) - 977, -(1 << 256) + 1, 2**255, -2**255]
+    ds += [rng.randrange(-2 * P + 1, P) for _ in range(3000)] + [-2 * P + 1 + rng.randrange(2**234) for _ in range(500)]
+    ds += [P - 1 - rng.randrange(2**200) for _ in range(200)]
+    for d in ds:
+        assert -2 * P < d < P
+        for f_top in (0x00FFFFFF, 1, 0, -1, -0x01000000):      # sign word of f: >= 0 or < 0
+            r = A9()
+            core.core_fe_divsteps_lift(I9(*signed_limbs(d)), f_top, r)
+            check_mag1(list(r))
+            assert val(r) == (d if f_top >= 0 else -d) % P, (hex(d), f_top)
+
+
 def test_divsteps_batch_is_the_textbook_recurrence(core):
     """One batch of 29 divsteps (masks, low 32 bits only) against the definition on Python integers: the matrix t must
     satisfy t [f, g] = 2^29 [f', g'] for the (f', g') the recurrence reaches, and delta must agree."""

@@ -1078,7 +1078,10 @@ def test_random_dispatch_tests_exactly_the_oracles_candidates(vg, vo):
     r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2)
     r.set_filter(None)
     corners = [(42, 0, 0, range(0, 3000)), (42, 0, batch, [0, 1, batch - 1]), (2**64 - 1, 2**32 - 1, 2**64 - batch, [0, 1, 4095, batch - 2, batch - 1]),
-               (0, 0, 2**32 - 5, [0, 4, 5, 6, batch - 1]), (7, 3, 2**40 + 5, [0, 63, 64, 255, 256, batch - 1])]
+               (0, 0, 2**32 - 5, [0, 4, 5, 6, batch - 1]), (7, 3, 2**40 + 5, [0, 63, 64, 255, 256, batch - 1]),
+               # the 24-byte seeds real searches use (vgen_dispatch_random_seed): every seed word must reach the hash
+               (bytes(range(1, 25)), 2, 12345, range(0, 1000)), (b"\xff" * 24, 2**32 - 1, 2**64 - batch, [0, 1, batch - 1]),
+               (bytes(20) + b"\x01\x02\x03\x04", 0, 0, [0, 1, 2, batch - 1]), (hashlib.sha256(b"seed").digest()[:24], 9, 2**33, range(0, 500))]
     for seed, stream, first, lanes in corners:
         r.dispatch_random(seed, stream, first, 0)
         blob, _, tested = r.await_result(0)
@@ -1148,12 +1151,13 @@ def test_random_key_scan_finds_what_the_oracles_random_walk_finds(vg, vo):
 
 # ---- a device that fails mid-scan (failure detection / recovery) -------------------------------------------
 
-def test_multi_context_scan_survives_a_failing_context(vg, vo, tmp_path):
+def test_multi_context_scan_survives_a_failing_context(vgh, vo, tmp_path):
     """Three contexts stripe one range; one of them starts failing after a few dispatches (vgen_debug_fail_after: what a
     device dropping off the bus looks like to the host loop).  The batches it had finished keep their matches, a surviving
     context takes its stripe over from the last finished batch, and the result is the oracle's scan of the WHOLE range —
     nothing lost, nothing twice.  The reference's answer to a failing GPU is its CPU fallback (src/lib.rs:727-746,1185-1198);
-    here the other GPUs are the fallback."""
+    here the other GPUs are the fallback.  (Fault injection exists only in the test build of the library: `vgh`.)"""
+    vg = vgh
     batch = 8192
     lo, hi = 0x20000, 0x20000 + 30 * batch - 1
     want = [(x["address"], x["wif"]) for x in vo.scan_range(0, "^1[A-D]", lo, hi, count=10**9)["matches"]]
@@ -1373,17 +1377,30 @@ def test_random_keys_on_an_endomorphism_context_test_six_keys_per_draw(vg, vo):
         r.close()
 
 
-def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vg, vo, monkeypatch):
+def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vgh, vo, monkeypatch):
     """The taproot and arbitrary-scalar paths multiply over a multi-gigabyte table built at first use.  When that table cannot
-    be allocated or built (here: injected through VGEN_DEBUG_GTAB_FAIL) the dispatch must not fail: the context says why in
-    vgen_last_error and carries on with the always-present 8-bit table — slower, same keys."""
-    from vgen_amd import api
-    monkeypatch.setenv("VGEN_DEBUG_GTAB_FAIL", "1")
+    be allocated or built (here: injected through VGEN_DEBUG_GTAB_FAIL, which only the test build of the library reads) the
+    dispatch must not fail: the context steps down through the narrower widths — and, when none can be had, carries on with the
+    always-present 8-bit table — slower, same keys; vgen_get_resources says what it got and why, vgen_last_error stays clean."""
+    vg = vgh
     batch = 8192
-    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2tr, frames=2)
     start = vo.seed_key(77, 3)
+    # 24 bits "fail", 22 can be had: one step down
+    monkeypatch.setenv("VGEN_DEBUG_GTAB_FAIL", "23")
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2tr, frames=2)
+    assert r.resources()["table_bits"] == 0 and r.resources()["note"] == ""       # nothing built before the first dispatch
     assert dump(r, start) == vo.payload_seq(3, start, batch)
-    assert b"wide generator table unavailable" in api._L.vgen_last_error(r._h)
+    res = r.resources()
+    assert res["table_bits"] == 22 and res["table_bits_wanted"] == 24 and "continuing on a 22-bit table" in res["note"], res
+    assert vg._L.vgen_last_error(r._h) in (None, b"")                               # a step-down is not an error
+    r.close()
+    # nothing wide can be had: the 8-bit table
+    monkeypatch.setenv("VGEN_DEBUG_GTAB_FAIL", "1")
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2tr, frames=2)
+    assert dump(r, start) == vo.payload_seq(3, start, batch)
+    res = r.resources()
+    assert res["table_bits"] == 8 and res["table_bits_wanted"] == 24 and "wide generator table unavailable" in res["note"] and "8-bit" in res["note"]
+    assert vg._L.vgen_last_error(r._h) in (None, b"")
     assert dump(r, start + batch, frame=1) == vo.payload_seq(3, start + batch, batch)     # and again: no retry storm, still right
     r.close()
     r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2)
@@ -1396,12 +1413,77 @@ def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vg, vo, monke
     # the command line says so too (what a scan absorbs must not pass unseen), and only then
     import os
     import subprocess
-    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgen_amd", "vgen-hip")
-    p = subprocess.run([cli, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120)
+    from conftest import HOOKS_CLI
+    p = subprocess.run([HOOKS_CLI, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "Warning: device 0: wide generator table unavailable" in p.stderr and len(p.stdout.split()) == 1
     env = {k: v for k, v in os.environ.items() if k != "VGEN_DEBUG_GTAB_FAIL"}
-    q = subprocess.run([cli, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120, env=env)
+    q = subprocess.run([HOOKS_CLI, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120, env=env)
     assert q.returncode == 0 and "Warning: device" not in q.stderr and q.stdout == p.stdout
+    # the SHIPPED command line does not know the switch at all
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgen_amd", "vgen-hip")
+    s = subprocess.run([cli, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120)
+    assert s.returncode == 0 and "Warning: device" not in s.stderr and s.stdout == p.stdout
+
+
+def test_contexts_on_one_device_share_the_wide_generator_table(vg, vo):
+    """The wide table (11.8 GB at the default width) is built once per device and shared by the process's contexts there,
+    reference-counted: a second context's first dispatch builds nothing, both compute the oracle's keys, and the table goes
+    away with its last user (device memory in use returns to where it was)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+    batch = 8192
+    start = vo.seed_key(5, 5)
+    warm = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=1)     # (the runtime's own one-time allocations first)
+    warm.close()
+    free0 = free_bytes()
+    a = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2tr, frames=2)
+    assert dump(a, start) == vo.payload_seq(3, start, batch)
+    ra = a.resources()
+    assert ra["table_bits"] == ra["table_bits_wanted"] == 24 and ra["note"] == ""
+    free1 = free_bytes()
+    assert free0 - free1 > 11 * 2**30                      # the table is there
+    b = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=2)
+    b.set_filter(None)
+    b.dispatch_random(3, 0, 0, 0)
+    blob, _, _ = b.await_result(0)
+    for i in range(0, batch, 97):
+        assert blob[20 * i:20 * i + 20] == vo.payload(0, vo.random_key(3, 0, i))
+    assert b.resources()["table_bits"] == 24
+    free2 = free_bytes()
+    assert free1 - free2 < 2 * 2**30                       # ... and was not built a second time
+    a.close()                                              # the first user goes: the second keeps computing on the shared table
+    b.dispatch_random(3, 0, batch, 1)
+    blob, _, _ = b.await_result(1)
+    for i in range(0, batch, 97):
+        assert blob[20 * i:20 * i + 20] == vo.payload(0, vo.random_key(3, 0, batch + i))
+    b.close()
+    assert free0 - free_bytes() < 2**30                     # the last user took the table with it
+
+
+def test_dump_mode_serves_the_frames_vgen_get_resources_names(vg, vo):
+    """Dump mode's pinned host mirrors are bounded (~1 GiB): vgen_get_resources reports how many frames it serves, a
+    dispatch beyond them is VGEN_E_STATE (not a crash, not a silent allocation), one below works."""
+    batch = 1 << 20
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat.P2pkh, frames=12, endo=True)      # 6 x 20 MB per frame
+    n = r.resources()["dump_frames"]
+    assert n == 8, n
+    r.set_filter(None)
+    start = vo.seed_key(8, 1)
+    r.dispatch(start, n - 1)
+    blob, _, tested = r.await_result(n - 1)
+    assert tested == 6 * batch and blob[:20 * 64] == vo.payload_seq(0, start, 64)
+    with pytest.raises(vg.VgenError) as e:
+        r.dispatch(start, n)
+    assert e.value.status == -5 and "vgen_get_resources" in str(e.value)
+    r.close()
+    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=12)
+    assert r.resources()["dump_frames"] == 12
+    r.close()
 
 
 def test_cli_progress_line_only_on_a_terminal(vg):
@@ -1437,8 +1519,27 @@ def test_random_key_scan_resumes_through_a_checkpoint(vg, vo, tmp_path):
         for m in whole.matches[::17]:
             assert vo.generate(0, int(m.hex, 16))["address"] == m.address
         text = open(ck).read()
-        assert "mode=random" in text and ("%016x" % 21) in text
+        # base = eight zero bytes, then the 24 seed bytes: the u64 21 little-endian, sixteen zero bytes
+        assert "mode=random-seed24" in text and ("base=" + "00" * 8 + "15" + "00" * 23) in text
         with pytest.raises(vg.VgenError):   # another seed: not this scan's file
             vg.scan_gpu_with_runner("^1[A-D][a-k]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, seed=22, random_keys=True, max_batches=1, checkpoint_path=ck), r)
         r.close()
+    # An UNSEEDED random-key scan: the seed is all the secret its keys have, so it is 24 bytes of OS entropy, not 64 bits —
+    # the file shows it; the found keys are candidates of that very seed; a second leg adopts it from the file.
+    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, frames=2)
+    ck = str(tmp_path / "unseeded.ckpt")
+    a = vg.scan_gpu_with_runner("^1[A-D]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, random_keys=True, max_batches=1, checkpoint_path=ck), r)
+    base = bytes.fromhex(re.search(r"^base=([0-9a-f]{64})$", open(ck).read(), re.M).group(1))
+    seed = base[8:]
+    assert base[:8] == bytes(8) and any(seed[8:16]) and any(seed[16:24])          # entropy beyond the first 64 bits
+    assert len(a.matches) > 100
+    cand = {vo.random_key(seed, 0, i) for i in range(8192)}
+    assert all(int(m.hex, 16) in cand for m in a.matches)
+    b = vg.scan_gpu_with_runner("^1[A-D]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=None, random_keys=True, max_batches=1, checkpoint_path=ck), r)
+    cand2 = {vo.random_key(seed, 0, 8192 + i) for i in range(8192)}
+    assert len(b.matches) > len(a.matches) and all(int(m.hex, 16) in cand | cand2 for m in b.matches)
+    # two unseeded scans never share a seed
+    c = vg.scan_gpu_with_runner("^1[A-D]", vg.ScanConfig(format=vg.AddressFormat.P2pkh, count=5, random_keys=True), r)
+    assert not {int(m.hex, 16) for m in c.matches} & (cand | cand2)
+    r.close()
 

@@ -154,7 +154,7 @@ def test_register_and_scratch_budgets_against_the_committed_table(isa):
     assert len(table) >= 45
     for sym, k in isa.items():
         short = sym.replace("_ZN2vg", "", 1)
-        assert short in table, f"{sym}: not in profiles/r04_kernel_resources.txt (tools/kernel_resources.sh regenerates it)"
+        assert short in table, f"{sym}: not in profiles/r04_kernel_resources.txt (tools/kernel_resources.py regenerates it)"
         v, s = table[short]
         assert k["vgpr"] <= v, f"{sym}: {k['vgpr']} VGPRs, committed {v}"
         assert k["scratch"] <= s, f"{sym}: {k['scratch']} B scratch, committed {s}"

@@ -17,7 +17,10 @@ from dataclasses import dataclass, field
 from typing import Callable, List, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libvgen_hip.so")
+# (_SO_OVERRIDE: a second instance of this module bound to the TEST build of the library — the same sources with the
+#  fault-injection hooks compiled in —, pre-set by tests/conftest.py: hooks_api() before it executes the module; never an
+#  environment variable, never set in the package itself)
+_SO = globals().get("_SO_OVERRIDE") or os.path.join(_HERE, "libvgen_hip.so")
 
 
 class VgenError(RuntimeError):
@@ -112,7 +115,11 @@ _L.vgen_clock_probe_start.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
 _L.vgen_clock_probe_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 _L.vgen_dispatch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p]
 _L.vgen_dispatch_keys.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
-_L.vgen_debug_fail_after.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+if hasattr(_L, "vgen_debug_fail_after"):   # only the test build (tests/native/libvgen_hip_hooks.so) has it
+    _L.vgen_debug_fail_after.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+_L.vgen_dispatch_random_seed.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64]
+_L.vgen_random_key_seed.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
+_L.vgen_get_resources.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint32)] * 3 + [ctypes.c_char_p, ctypes.c_size_t]
 _L.vgen_dispatch_random.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
 _L.vgen_random_key.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
 _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match), ctypes.c_uint32,
@@ -187,9 +194,14 @@ def key_add(key, amount):
 
 def random_key(seed, stream, index):
     """vgen_random_key: candidate `index` of stream `stream` under `seed` of the counter-based scalar stream
-    (vgen_dispatch_random); None when that draw is not a valid scalar."""
+    (vgen_dispatch_random); None when that draw is not a valid scalar.  seed: an integer < 2^64 (vgen_random_key) or the 24
+    seed bytes themselves (vgen_random_key_seed)."""
     out = ctypes.create_string_buffer(32)
-    rc = _L.vgen_random_key(seed, stream, index, out)
+    if isinstance(seed, (bytes, bytearray)):
+        assert len(seed) == 24
+        rc = _L.vgen_random_key_seed(bytes(seed), stream, index, out)
+    else:
+        rc = _L.vgen_random_key(seed, stream, index, out)
     if rc == -7:
         return None
     _check(rc)
@@ -388,13 +400,28 @@ class GpuRunner:
         _check(_L.vgen_dispatch_keys(self._h, frame, blob, n), self._h)
 
     def fail_after(self, dispatches: int):
-        """vgen_debug_fail_after: fault injection — dispatches fail with VGEN_E_HIP once `dispatches` more were accepted."""
+        """vgen_debug_fail_after: fault injection — dispatches fail with VGEN_E_HIP once `dispatches` more were accepted.
+        Exists only in the test build of the library (tests/conftest.py: hooks_api)."""
+        if not hasattr(_L, "vgen_debug_fail_after"):
+            raise RuntimeError("fault injection is not part of libvgen_hip.so: load tests/native/libvgen_hip_hooks.so (tests/conftest.py: hooks_api)")
         _check(_L.vgen_debug_fail_after(self._h, dispatches), self._h)
 
-    def dispatch_random(self, seed: int, stream: int, first_index: int, frame: int):
-        """vgen_dispatch_random: batch_size independent random keys drawn on the device from the counter-based stream."""
+    def resources(self):
+        """vgen_get_resources -> dict(dump_frames, table_bits, table_bits_wanted, note)."""
+        d, b, w = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        note = ctypes.create_string_buffer(256)
+        _check(_L.vgen_get_resources(self._h, ctypes.byref(d), ctypes.byref(b), ctypes.byref(w), note, 256), self._h)
+        return {"dump_frames": d.value, "table_bits": b.value, "table_bits_wanted": w.value, "note": note.value.decode()}
+
+    def dispatch_random(self, seed, stream: int, first_index: int, frame: int):
+        """vgen_dispatch_random: batch_size independent random keys drawn on the device from the counter-based stream.
+        seed: an integer < 2^64 or the 24 seed bytes (vgen_dispatch_random_seed)."""
         self._n_keys = self.batch_size
-        _check(_L.vgen_dispatch_random(self._h, frame, seed, stream, first_index), self._h)
+        if isinstance(seed, (bytes, bytearray)):
+            assert len(seed) == 24
+            _check(_L.vgen_dispatch_random_seed(self._h, frame, bytes(seed), stream, first_index), self._h)
+        else:
+            _check(_L.vgen_dispatch_random(self._h, frame, seed, stream, first_index), self._h)
 
     def await_result(self, frame: int):
         """Filter mode: (list of (index, payload20), n_found, keys_tested).  Dump mode: (bytes, 0, keys_tested)."""
@@ -441,10 +468,10 @@ class GpuRunner:
 
 
 def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
-                         progress_cb: Optional[Callable[[int], None]] = None, stop=None) -> ScanResult:
+                         progress_cb: Optional[Callable[[int], None]] = None, stop=None, force_multi: bool = False) -> ScanResult:
     """scan_gpu_with_runner (src/gpu.rs:920-926).  `stop` is an optional ctypes.c_int32 flag.
     `runner` may be a list of GpuRunners (one per GPU): the batches are then striped over them
-    (vgen_scan_multi)."""
+    (vgen_scan_multi; force_multi: also for a list of one)."""
     runners = list(runner) if isinstance(runner, (list, tuple)) else [runner]
     runner = runners[0]
     c = _ScanConfig()
@@ -466,7 +493,7 @@ def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
     res = _ScanResult()
     cb = _PROGRESS(lambda ops, _u: progress_cb(ops)) if progress_cb else ctypes.cast(None, _PROGRESS)
     stop_p = ctypes.byref(stop) if stop is not None else None
-    if len(runners) == 1:
+    if len(runners) == 1 and not force_multi:
         rc = _L.vgen_scan(runner._h, pattern.encode(), ctypes.byref(c), cb, None, stop_p, ctypes.byref(res))
     else:
         arr = (ctypes.c_void_p * len(runners))(*[r._h for r in runners])

@@ -63,6 +63,17 @@ int vgen_get_info(const vgen_ctx *ctx, uint32_t *batch_size, uint32_t *frames, u
     return VGEN_OK;
 }
 
+int vgen_get_resources(const vgen_ctx *ctx, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, char *note, size_t note_cap) {
+    if (!ctx) return VGEN_E_INVALID;
+    std::string why;
+    const int rc = vg::rt_get_resources(ctx, dump_frames, table_bits, table_bits_wanted, &why);
+    if (note && note_cap) {
+        strncpy(note, why.c_str(), note_cap - 1);
+        note[note_cap - 1] = 0;
+    }
+    return rc;
+}
+
 int vgen_filter_compile(const char *pattern, int case_insensitive, uint32_t format, vgen_filter **out) {
     if (!pattern || !out) return VGEN_E_INVALID;
     vgen_filter *f = new vgen_filter();
@@ -166,20 +177,33 @@ int vgen_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, ui
     return vg::rt_dispatch_keys(ctx, frame, keys_be, n);
 }
 
-int vgen_debug_fail_after(vgen_ctx *ctx, uint64_t after_dispatches) {
+#ifdef VGEN_TEST_HOOKS
+// Fault injection: only in the test build of the library (tests/native/libvgen_hip_hooks.so, tests/native/vgen_hip_hooks.h).
+extern "C" int vgen_debug_fail_after(vgen_ctx *ctx, uint64_t after_dispatches) {
     if (!ctx) return VGEN_E_INVALID;
     ctx->fail_after = after_dispatches;
     return VGEN_OK;
 }
+#endif
 
 int vgen_dispatch_random(vgen_ctx *ctx, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
     if (!ctx) return VGEN_E_INVALID;
-    return vg::rt_dispatch_random(ctx, frame, seed, stream, first_index);
+    return vg::rt_dispatch_random(ctx, frame, vg::rnd_seed_from_u64(seed), stream, first_index);
+}
+
+int vgen_dispatch_random_seed(vgen_ctx *ctx, uint32_t frame, const uint8_t seed[24], uint32_t stream, uint64_t first_index) {
+    if (!ctx || !seed) return VGEN_E_INVALID;
+    return vg::rt_dispatch_random(ctx, frame, vg::rnd_seed_from_bytes(seed), stream, first_index);
 }
 
 int vgen_random_key(uint64_t seed, uint32_t stream, uint64_t index, uint8_t key_be[32]) {
     if (!key_be) return VGEN_E_INVALID;
-    return vg::random_key_be(seed, stream, index, key_be) ? VGEN_OK : VGEN_E_RANGE;
+    return vg::random_key_be(vg::rnd_seed_from_u64(seed), stream, index, key_be) ? VGEN_OK : VGEN_E_RANGE;
+}
+
+int vgen_random_key_seed(const uint8_t seed[24], uint32_t stream, uint64_t index, uint8_t key_be[32]) {
+    if (!seed || !key_be) return VGEN_E_INVALID;
+    return vg::random_key_be(vg::rnd_seed_from_bytes(seed), stream, index, key_be) ? VGEN_OK : VGEN_E_RANGE;
 }
 
 int vgen_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,

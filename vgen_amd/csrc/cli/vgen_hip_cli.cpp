@@ -203,26 +203,42 @@ Opts parse(int argc, char **argv) {
     }
     o.cmd = argv[1];
     if (o.cmd == "range") o.count = 1;
-    // clap's spellings of one argument: --name=value, -nVALUE, and boolean shorts run together (-iq) — split up front
+    // clap's spellings of one argument: --name=value, -nVALUE, and boolean shorts run together (-iq) — split up front.  Only
+    // words in OPTION position are reinterpreted: the word after an option that takes a value is that value, verbatim, whatever
+    // it starts with (`-p -abc` is the pattern "-abc", not three flags).
+    static const char *const long_with_value[] = {"--pattern", "--format", "--count", "--output", "--file", "--gpu-batch-size", "--repeat",
+                                                  "--seed", "--devices", "--frames", "--checkpoint", "--range", "--puzzle", "--key", "--address",
+                                                  "--prefix-length", "--provider-table", "--threads", "--backend", "--cpu-batch-size"};
+    static const char short_with_value[] = "pfcorkaltT";
     std::vector<std::string> args;
+    bool next_is_value = false;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
+        if (next_is_value) {
+            args.push_back(a);
+            next_is_value = false;
+            continue;
+        }
         const size_t eq = a.find('=');
-        if (a.size() > 2 && a[0] == '-' && a[1] == '-' && eq != std::string::npos) {
-            args.push_back(a.substr(0, eq));
-            args.push_back(a.substr(eq + 1));
-        } else if (a.size() > 2 && a[0] == '-' && a[1] != '-') {
-            size_t k = 1;
-            for (; k < a.size(); k++) {
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            if (eq != std::string::npos) {
+                args.push_back(a.substr(0, eq));
+                args.push_back(a.substr(eq + 1));
+            } else {
+                args.push_back(a);
+                for (const char *name : long_with_value) next_is_value = next_is_value || a == name;
+            }
+        } else if (a.size() >= 2 && a[0] == '-' && a[1] != '-') {
+            for (size_t k = 1; k < a.size(); k++) {
                 const char ch = a[k];
-                if (strchr("pfcorkaltT", ch)) {   // shorts that take a value: the rest of the word (after an optional '=') is it
-                    args.push_back(std::string("-") + ch);
+                args.push_back(std::string("-") + ch);
+                if (strchr(short_with_value, ch)) {   // takes a value: the rest of the word (after an optional '=') is it, else the next word
                     std::string rest = a.substr(k + 1);
                     if (!rest.empty() && rest[0] == '=') rest = rest.substr(1);
                     if (!rest.empty()) args.push_back(rest);
+                    else next_is_value = true;
                     break;
                 }
-                args.push_back(std::string("-") + ch);
             }
         } else {
             args.push_back(a);
@@ -472,9 +488,11 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         // table that could not be had (the scan went on with the small one, at a third of the rate)
         if (res.failed_shards > 0)
             fprintf(stderr, "Warning: %d of %zu devices failed during the scan; the remaining ones took their ranges over\n", res.failed_shards, ctxs.size());
-        for (size_t i = 0; i < ctxs.size(); i++) {
-            const char *note = vgen_last_error(ctxs[i]);
-            if (rep == 0 && note && *note) fprintf(stderr, "Warning: device %zu: %s\n", i, note);
+        for (size_t i = 0; i < ctxs.size() && rep == 0; i++) {
+            uint32_t bits = 0, wanted = 0;
+            char note[256] = "";
+            if (vgen_get_resources(ctxs[i], nullptr, &bits, &wanted, note, sizeof note) == VGEN_OK && bits && bits < wanted && note[0])
+                fprintf(stderr, "Warning: device %zu: %s\n", i, note);
         }
         for (uint64_t i = 0; i < res.n_matches; i++) all.push_back(res.matches[i]);
         total_ops += res.operations;

@@ -508,6 +508,23 @@ VG_HD void fe_divsteps_apply_de_(fe_sgn &d, fe_sgn &e, const int32_t t[4]) {
     e.n[8] = (int32_t)ce;
 }
 
+// The last step of the inversion: a^-1 = sign(f) d with d anywhere in (-2p, p) — signed limbs: 0..7 in [0, 2^29), limb 8
+// from -2^25 (d near -2p) to 2^24.  Lifted by 3p LIMB-WISE, which keeps every limb non-negative for both signs:
+//   f > 0:  3 P_8 + d_8 >= 3 (2^24 - 1) - 2^25 > 0, the low limbs only grow;
+//   f < 0:  3 P_i - d_i >= 3 (2^29 - 977) - 2^29 > 0 for i < 8, 3 P_8 - d_8 >= 3 (2^24 - 1) - 2^24 > 0.
+// (Round 3 lifted by 2p: for f > 0 and d within ~2^233 of -2p limb 8 came out negative and wrapped as u32 — a silent wrong
+// inverse, however improbable; tests/test_core_field.py drives this function with exactly those d.)  All limbs stay below
+// 4 * 2^29: magnitude 4 into fe_normalize.
+VG_HD void fe_divsteps_lift_(fe &r, const fe_sgn &d, int32_t f_top) {
+    const u32 neg = (u32)(f_top >> 31);
+    r.n[0] = 3u * FE_P0 + (((u32)d.n[0] ^ neg) - neg);
+    r.n[1] = 3u * FE_P1 + (((u32)d.n[1] ^ neg) - neg);
+#pragma unroll
+    for (int i = 2; i < 8; i++) r.n[i] = 3u * FE_PM + (((u32)d.n[i] ^ neg) - neg);
+    r.n[8] = 3u * FE_P8 + (((u32)d.n[8] ^ neg) - neg);
+    fe_normalize(r);
+}
+
 // r = a^-1 (any magnitude <= 7 in; canonical out; inv(0) = 0).
 VG_HD void fe_inv(fe &r, const fe &a) {
     fe x = a;
@@ -535,14 +552,7 @@ VG_HD void fe_inv(fe &r, const fe &a) {
         fe_divsteps_apply_fg_(f, g, t);
         fe_divsteps_apply_de_(d, e, t);
     }
-    // a^-1 = sign(f) d, d in (-2p, p): lift by 2p limb-wise (no borrows: 2 P_i >= d_i), then the canonical representative
-    const u32 neg = (u32)(f.n[8] >> 31);
-    r.n[0] = 2u * FE_P0 + (((u32)d.n[0] ^ neg) - neg);
-    r.n[1] = 2u * FE_P1 + (((u32)d.n[1] ^ neg) - neg);
-#pragma unroll
-    for (int i = 2; i < 8; i++) r.n[i] = 2u * FE_PM + (((u32)d.n[i] ^ neg) - neg);
-    r.n[8] = 2u * FE_P8 + (((u32)d.n[8] ^ neg) - neg);
-    fe_normalize(r);
+    fe_divsteps_lift_(r, d, f.n[8]);   // a^-1 = sign(f) d, canonical
 }
 
 }  // namespace vg

@@ -858,20 +858,20 @@ __device__ __forceinline__ bool keys_load_scalar(const KeysArgs &args, u32 idx, 
 // 32-byte big-endian layout vgen_dispatch_keys uploads — so that the multiplication kernels are the very same code for both
 // (drawing the scalar inside keys_fwd_kernel kept the eight words live across its window loop and cost 15 %: 1.23 instead of
 // 1.44 Gkeys/s; this fill is 700 instructions and 32 B per key, ~3 % of the dispatch).
-__global__ void __launch_bounds__(256) rnd_fill_kernel(u32 *keys_be, u32 n, u32 seed_lo, u32 seed_hi, u32 stream, u32 index_lo, u32 index_hi) {
+__global__ void __launch_bounds__(256) rnd_fill_kernel(u32 *keys_be, u32 n, const RndSeed seed, u32 stream, u32 index_lo, u32 index_hi) {
     const u32 idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     const u64 index = ((u64)index_hi << 32 | index_lo) + idx;
     u32 k[8];
-    rnd_scalar(seed_lo, seed_hi, stream, (u32)index, (u32)(index >> 32), k);
+    rnd_scalar(seed, stream, (u32)index, (u32)(index >> 32), k);
     ec_u4 *o = reinterpret_cast<ec_u4 *>(keys_be + (size_t)idx * 8);
     o[0] = ec_u4{{bswap32(k[7]), bswap32(k[6]), bswap32(k[5]), bswap32(k[4])}};
     o[1] = ec_u4{{bswap32(k[3]), bswap32(k[2]), bswap32(k[1]), bswap32(k[0])}};
 }
 
-hipError_t launch_rnd_fill(uint8_t *keys_be, u32 n, unsigned long long seed, u32 stream, unsigned long long first_index, hipStream_t st) {
+hipError_t launch_rnd_fill(uint8_t *keys_be, u32 n, const RndSeed &seed, u32 stream, unsigned long long first_index, hipStream_t st) {
     if (!keys_be || n == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rnd_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<u32 *>(keys_be), n, (u32)seed, (u32)(seed >> 32),
+    hipLaunchKernelGGL(rnd_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<u32 *>(keys_be), n, seed,
                        stream, (u32)first_index, (u32)(first_index >> 32));
     return hipGetLastError();
 }

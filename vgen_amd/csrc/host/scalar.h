@@ -159,9 +159,17 @@ inline void scalar_variant(Scalar &r, const Scalar &k, uint32_t v) {
 
 // Candidate `index` of stream `stream` under `seed` of the counter-based scalar stream (core/rnd.h) as 32 big-endian
 // bytes; false when the draw is not a valid scalar (such candidates yield no key, as in the reference's CPU loop).
-inline bool random_key_be(uint64_t seed, uint32_t stream, uint64_t index, uint8_t be[32]) {
+inline RndSeed rnd_seed_from_bytes(const uint8_t b[24]) {
+    RndSeed s;
+    for (int i = 0; i < 6; i++) s.w[i] = (uint32_t)b[4 * i] | (uint32_t)b[4 * i + 1] << 8 | (uint32_t)b[4 * i + 2] << 16 | (uint32_t)b[4 * i + 3] << 24;
+    return s;
+}
+inline void rnd_seed_to_bytes(const RndSeed &s, uint8_t b[24]) {
+    for (int i = 0; i < 24; i++) b[i] = (uint8_t)(s.w[i / 4] >> (8 * (i % 4)));
+}
+inline bool random_key_be(const RndSeed &seed, uint32_t stream, uint64_t index, uint8_t be[32]) {
     Scalar k;
-    rnd_scalar((uint32_t)seed, (uint32_t)(seed >> 32), stream, (uint32_t)index, (uint32_t)(index >> 32), k.w);
+    rnd_scalar(seed, stream, (uint32_t)index, (uint32_t)(index >> 32), k.w);
     scalar_to_be(k, be);
     return scalar_is_valid(k);
 }

@@ -62,6 +62,8 @@ void fe_canon_neg(fe &r, const fe &a) {
 
 size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+void release_gtab(vgen_ctx *c);   // (defined with the generator-table cache below)
+
 // Frame i's stream, created on first use (a stream costs ~5-8 ms: a scan's first dispatches should be running while
 // the later streams are still being set up).
 //
@@ -427,8 +429,7 @@ void rt_destroy(vgen_ctx *c) {
     if (c->d_keys_slab) (void)hipFree(c->d_keys_slab);
     if (c->d_rtab) (void)hipFree(c->d_rtab);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
-    if (c->d_gtab16) (void)hipFree(c->d_gtab16);
-    if (c->d_gtab_small) (void)hipFree(c->d_gtab_small);
+    release_gtab(c);                              // the wide table is shared per device: freed with its last user
     if (c->d_chk_lut) (void)hipFree(c->d_chk_lut);
     if (c->d_dfa) (void)hipFree(c->d_dfa);
     if (c->d_filter) (void)hipFree(c->d_filter);
@@ -484,15 +485,18 @@ int alloc_dump_piece(vgen_ctx *c, uint32_t first, uint32_t n, uint8_t **d_out, u
     return VGEN_OK;
 }
 
+// Frames that dump mode serves.  Pinned host memory is the scarce part (an ENDO context at the CLI's defaults would pin
+// 1.5 GB, 24 GB at 2^24 keys per dispatch): at most ~1 GiB worth of frames, never fewer than two — the host-side filter
+// behind a dump runs at a few Mkeys/s, so two dumps in flight already keep it fed.  Reported by vgen_get_resources.
+uint32_t dump_frames_for(const vgen_ctx *c) {
+    const size_t per = up256((size_t)c->batch * (c->endo ? 6 : 1) * c->payload_words * sizeof(uint32_t));
+    const size_t budget = (size_t)1 << 30;
+    return (uint32_t)std::min<size_t>(c->frames, std::max<size_t>(2, budget / per));
+}
+
 int ensure_dump_slab(vgen_ctx *c) {
     if (c->d_dump_slab) return VGEN_OK;
-    const size_t per = up256((size_t)c->batch * (c->endo ? 6 : 1) * c->payload_words * sizeof(uint32_t));
-    // Pinned host memory is the scarce part (an ENDO context at the CLI's defaults would pin 1.5 GB, 24 GB at 2^24 keys
-    // per dispatch): dump mode serves at most ~1 GiB worth of frames, never fewer than two — the host-side filter behind
-    // it runs at a few Mkeys/s, so two dumps in flight already keep it fed.  vgen_get_info / rt_dump_frames report it.
-    const size_t budget = (size_t)1 << 30;
-    uint32_t n = (uint32_t)std::min<size_t>(c->frames, std::max<size_t>(2, budget / per));
-    n = std::min(n, c->frames);
+    const uint32_t n = dump_frames_for(c);
     if (int rc = alloc_dump_piece(c, 0, std::min<uint32_t>(n, 2), &c->d_dump_slab, &c->h_dump_slab)) return rc;
     c->dump_frames = n;
     return VGEN_OK;
@@ -502,7 +506,7 @@ int ensure_dump_slab(vgen_ctx *c) {
 int ensure_dump_frame(vgen_ctx *c, uint32_t frame) {
     if (int rc = ensure_dump_slab(c)) return rc;   // (a context that never called vgen_set_filter)
     if (frame >= c->dump_frames)
-        return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget)");
+        return c->fail(VGEN_E_STATE, "dump mode serves frames 0.." + std::to_string(c->dump_frames - 1) + " of this context (pinned-memory budget; vgen_get_resources reports the limit)");
     if (c->fr[frame].d_dump) return VGEN_OK;
     return alloc_dump_piece(c, 2, c->dump_frames - 2, &c->d_dump_slab2, &c->h_dump_slab2);
 }
@@ -587,11 +591,50 @@ int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys, b
     return VGEN_OK;
 }
 
+// Wide generator tables are shared by the contexts of a process that sit on the same device (tests, multi-tenant hosts,
+// several scans in one host application): 11.8 GB at the default width is paid once per device, not once per context.
+// Reference-counted; the last context to go frees the table.  The lock is held across a build (~20 ms, once).
+struct GtabShared {
+    int device;
+    uint32_t bits;
+    uint32_t *wide, *small;    // small: the half-width table the wide one was combined from (kept: freeing it would synchronise the device)
+    uint32_t refs;
+};
+struct GtabCache {
+    std::mutex mu;
+    std::vector<GtabShared> tabs;
+};
+GtabCache &gtab_cache() {
+    static GtabCache *g = new GtabCache();   // (never destroyed: contexts may outlive static teardown order)
+    return *g;
+}
+
+// Drops the context's reference on its wide table (rt_destroy).
+void release_gtab(vgen_ctx *c) {
+    if (!c->d_gtab16) return;
+    GtabCache &g = gtab_cache();
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (size_t i = 0; i < g.tabs.size(); i++) {
+        GtabShared &t = g.tabs[i];
+        if (t.device != c->device || t.wide != c->d_gtab16) continue;
+        if (--t.refs == 0) {
+            (void)hipFree(t.wide);
+            (void)hipFree(t.small);
+            g.tabs.erase(g.tabs.begin() + (long)i);
+        }
+        break;
+    }
+    c->d_gtab16 = nullptr;
+    c->gtab_bits = 0;
+}
+
 // Generator tables of the paths that multiply a scalar per key.  `wide`: the dispatch is worth the wide-window table
 // (every P2TR dispatch, arbitrary-scalar dispatches of a few thousand keys or more); a handful of keys, or the rare
 // sequential batch that touches the group order, runs on the always-present 8-bit table instead of paying 11.8 GB and
-// ~19 ms for it.  A wide table that cannot be had (allocation or build failure) is not an error either: the context
-// notes why (vgen_last_error) and stays on the 8-bit table.
+// ~19 ms for it.  A wide table that cannot be had (allocation or build failure) is not an error either: the context steps
+// down through the narrower widths (24 -> 22 -> 20 -> 16 bits: 10 / 11 / 12 / 15 additions per multiplication) before it
+// settles on the 8-bit table (31), and says what it got through vgen_get_resources (never through vgen_last_error: the
+// call succeeded).
 int ensure_gtab(vgen_ctx *c, bool wide) {
     const bool trace = getenv("VGEN_TRACE_CREATE") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -609,7 +652,7 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
         }
         lap("upload");
     }
-    // The wide-window table, built on the device from the 8-bit one, once per context: 24-bit windows by default (11 windows,
+    // The wide-window table, built on the device from the 8-bit one, once per DEVICE: 24-bit windows by default (11 windows,
     // 10 additions per multiplication instead of the 8-bit table's 31; 11.8 GB of the 288 GB).  Every entry is the affine sum
     // of two entries of a table of half the width, eight entries per lane sharing an inversion (gen_table_combine_kernel).
     // Measured in round 3 (profiles/r03_gtab26.txt; random-key mode Mkeys/s, build incl. allocation): 22 bits (3.2 GB) 1272,
@@ -617,14 +660,40 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
     // to show (VALU-busy 0.97).  The paths are issue-bound (profiles/pmc_keys.json), so the rate follows the additions saved.
     // VGEN_GTAB_BITS = 8 | 16 | 20 | 22 | 24 | 26 selects.
     if (wide && !c->d_gtab16 && !c->gtab_wide_failed) {
-        const uint32_t bits = env_u32("VGEN_GTAB_BITS", 24);
-        if (bits == 8) {
+        const uint32_t want = env_u32("VGEN_GTAB_BITS", 24);
+        if (want != 8 && want != 16 && want != 20 && want != 22 && want != 24 && want != 26)
+            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22, 24 or 26");
+        c->gtab_bits_wanted = want;
+        if (want == 8) {
             c->gtab_wide_failed = true;   // (asked for: nothing to build)
-        } else if (bits == 16 || bits == 20 || bits == 22 || bits == 24 || bits == 26) {
+            return VGEN_OK;
+        }
+#ifdef VGEN_TEST_HOOKS
+        // fault injection (test build only): widths >= VGEN_DEBUG_GTAB_FAIL behave as if their allocation had failed
+        const uint32_t hook_fail_from = env_u32("VGEN_DEBUG_GTAB_FAIL", 0);
+#else
+        const uint32_t hook_fail_from = 0;
+#endif
+        static const uint32_t widths[] = {26, 24, 22, 20, 16};
+        GtabCache &g = gtab_cache();
+        std::lock_guard<std::mutex> lk(g.mu);
+        std::string why;
+        for (uint32_t bits : widths) {
+            if (bits > want) continue;
+            // somebody on this device has it already
+            bool shared = false;
+            for (GtabShared &t : g.tabs)
+                if (t.device == c->device && t.bits == bits) {
+                    t.refs++;
+                    c->d_gtab16 = t.wide;
+                    c->gtab_bits = bits;
+                    shared = true;
+                    break;
+                }
+            if (shared) break;
             uint32_t *wide_tab = nullptr, *small = nullptr;   // small: the half-width table the wide one is combined from
-            // (VGEN_DEBUG_GTAB_FAIL: fault injection for the fallback below — behave as if the allocation had failed)
-            hipError_t e = getenv("VGEN_DEBUG_GTAB_FAIL") ? hipErrorOutOfMemory
-                                                          : hipMalloc((void **)&wide_tab, (size_t)ec_wide_words(bits) * sizeof(uint32_t));
+            hipError_t e = hook_fail_from && bits >= hook_fail_from ? hipErrorOutOfMemory
+                                                                    : hipMalloc((void **)&wide_tab, (size_t)ec_wide_words(bits) * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_wide_words(bits / 2) * sizeof(uint32_t));
             lap("hipMalloc wide + scratch");
             hipStream_t st0 = nullptr;
@@ -632,20 +701,21 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
             if (e == hipSuccess) e = launch_gen_table_wide(c->d_gtab, wide_tab, small, bits, st0);
             if (e == hipSuccess) e = hipStreamSynchronize(st0);
             lap("two kernels + sync");
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                if (wide_tab) (void)hipFree(wide_tab);
-                if (small) (void)hipFree(small);
-                c->gtab_wide_failed = true;
-                c->err = std::string("wide generator table unavailable (") + hipGetErrorString(e) + "): continuing on the 8-bit table";
-            } else {
+            if (e == hipSuccess) {
+                g.tabs.push_back(GtabShared{c->device, bits, wide_tab, small, 1});
                 c->d_gtab16 = wide_tab;
-                c->d_gtab_small = small;   // kept until vgen_destroy: freeing it here would synchronise the device under the other frames
                 c->gtab_bits = bits;
+                break;
             }
-        } else {
-            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22, 24 or 26");
+            (void)hipGetLastError();
+            if (wide_tab) (void)hipFree(wide_tab);
+            if (small) (void)hipFree(small);
+            if (why.empty()) why = std::string(hipGetErrorString(e)) + " at " + std::to_string(bits) + " bits";
         }
+        if (!c->d_gtab16) c->gtab_wide_failed = true;
+        if (!why.empty())
+            c->gtab_note = "wide generator table unavailable (" + why + "): continuing on " +
+                           (c->d_gtab16 ? "a " + std::to_string(c->gtab_bits) + "-bit table" : std::string("the 8-bit table"));
     }
     return VGEN_OK;
 }
@@ -847,7 +917,7 @@ int rt_dispatch_keys(vgen_ctx *c, uint32_t frame, const uint8_t *keys_be, uint32
 
 // Independent random keys (the reference CPU path's shape, src/scanner.rs:144-155) with no upload: lane i draws
 // key(seed, stream, first_index + i) from the counter-based stream of core/rnd.h on the device.
-int rt_dispatch_random(vgen_ctx *c, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index) {
+int rt_dispatch_random(vgen_ctx *c, uint32_t frame, const RndSeed &seed, uint32_t stream, uint64_t first_index) {
     if (frame >= c->frames) return c->fail(VGEN_E_INVALID, "bad frame index");
     if (first_index > UINT64_MAX - (c->batch - 1)) return c->fail(VGEN_E_RANGE, "vgen_dispatch_random: index range wraps 2^64");
     vgen_ctx::Frame &f = c->fr[frame];
@@ -948,6 +1018,16 @@ int rt_read_dump(vgen_ctx *c, uint32_t frame, uint8_t *out, size_t out_len) {
     if (int rc = rt_dump_view(c, frame, &src, &need)) return rc;
     if (out_len < need) return c->fail(VGEN_E_INVALID, "output buffer too small");
     memcpy(out, src, need);
+    return VGEN_OK;
+}
+
+// What dump mode and the scalar-multiplication paths have (or will get) of what they ask for: vgen_get_resources.
+int rt_get_resources(const vgen_ctx *c, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note) {
+    if (dump_frames) *dump_frames = dump_frames_for(c);
+    // 0 = no generator table yet (no P2TR / arbitrary-scalar dispatch so far); 8 = the 8-bit table only
+    if (table_bits) *table_bits = c->d_gtab16 ? c->gtab_bits : c->d_gtab ? 8u : 0u;
+    if (table_bits_wanted) *table_bits_wanted = c->gtab_bits_wanted ? c->gtab_bits_wanted : env_u32("VGEN_GTAB_BITS", 24);
+    if (note) *note = c->gtab_note;
     return VGEN_OK;
 }
 

@@ -31,10 +31,12 @@ struct vgen_ctx {
 
     uint32_t *d_rtab = nullptr;          // [18][lanes]
     uint32_t *d_gtab = nullptr;          // 8-bit fixed-window generator table (arbitrary-scalar path, P2TR), built on first use
-    uint32_t *d_gtab16 = nullptr;        // wide fixed-window generator table (gtab_bits bits), built on the device from d_gtab at first use
-    uint32_t *d_gtab_small = nullptr;    // the half-width table the wide one was combined from (scratch, freed with the context)
-    uint32_t gtab_bits = 0;
-    bool gtab_wide_failed = false;       // the wide table could not be had (or VGEN_GTAB_BITS=8): stay on the 8-bit one
+    uint32_t *d_gtab16 = nullptr;        // wide fixed-window generator table (gtab_bits bits): built on the device from d_gtab at first use and
+                                         // SHARED by the process's contexts on this device (runtime.cpp: GtabCache; a reference, not owned)
+    uint32_t gtab_bits = 0;              // width of d_gtab16
+    uint32_t gtab_bits_wanted = 0;       // width asked for (VGEN_GTAB_BITS, default 24) once a dispatch wanted a wide table
+    bool gtab_wide_failed = false;       // no wide table could be had (or VGEN_GTAB_BITS=8): stay on the 8-bit one
+    std::string gtab_note;               // why the table in use is narrower than the one asked for (vgen_get_resources)
     vg::DevFilter *d_filter = nullptr;   // current device filter program
     uint32_t *d_dfa = nullptr;           // DEVF_DFA automaton of the current filter
     uint32_t *d_chk_lut = nullptr;       // Bech32 checksum tables of the current filter (when it tests the checksum)
@@ -92,16 +94,22 @@ struct vgen_ctx {
     hipStream_t probe_stream = nullptr;          // shader-clock probe (vgen_clock_probe_*)
     unsigned long long *d_probe = nullptr;
     bool probe_running = false;
-    uint64_t fail_after = UINT64_MAX;            // fault injection (vgen_debug_fail_after): dispatches still accepted
     std::string err;
 
-    // false once the injected fault has struck: every later dispatch fails
+    // Fault injection exists only in the test build of the library (-DVGEN_TEST_HOOKS: tests/native/libvgen_hip_hooks.so,
+    // tests/native/vgen_hip_hooks.h); the shipped libvgen_hip.so has neither the field nor the entry point.
+#ifdef VGEN_TEST_HOOKS
+    uint64_t fail_after = UINT64_MAX;            // vgen_debug_fail_after: dispatches still accepted
+    // true once the injected fault has struck: every later dispatch fails
     bool injected_fault() {
         if (fail_after == UINT64_MAX) return false;
         if (fail_after == 0) return true;
         fail_after--;
         return false;
     }
+#else
+    static constexpr bool injected_fault() { return false; }
+#endif
 
     int fail(int status, const std::string &msg) {
         err = msg;
@@ -130,7 +138,7 @@ int rt_set_filter(vgen_ctx *ctx, const vgen_filter *f);
 int rt_set_match_cap(vgen_ctx *ctx, uint32_t cap);
 int rt_dispatch(vgen_ctx *ctx, uint32_t frame, const uint8_t start_key_be[32]);
 int rt_dispatch_keys(vgen_ctx *ctx, uint32_t frame, const uint8_t *keys_be, uint32_t n);
-int rt_dispatch_random(vgen_ctx *ctx, uint32_t frame, uint64_t seed, uint32_t stream, uint64_t first_index);
+int rt_dispatch_random(vgen_ctx *ctx, uint32_t frame, const RndSeed &seed, uint32_t stream, uint64_t first_index);
 int rt_wait(vgen_ctx *ctx, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t *n_matches,
             uint64_t *keys_tested);
 int rt_read_dump(vgen_ctx *ctx, uint32_t frame, uint8_t *out, size_t out_len);
@@ -139,5 +147,6 @@ int rt_frame_times(vgen_ctx *ctx, uint32_t frame, float *kernel_ms, float *total
 int rt_frame_clock(vgen_ctx *ctx, uint32_t frame, uint32_t *cycles, uint32_t *ticks);
 int rt_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
 int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);
+int rt_get_resources(const vgen_ctx *ctx, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note);
 
 }  // namespace vg

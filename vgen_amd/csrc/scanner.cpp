@@ -81,9 +81,21 @@ void random_valid_key(Scalar &k) {
 struct BatchKeys {
     Scalar start{};
     bool random = false;
-    uint64_t seed = 0, first_index = 0;
+    RndSeed seed{};
+    uint64_t first_index = 0;
     uint32_t stream = 0;
 };
+
+// The seed of a random-key scan (core/rnd.h): the caller's 64-bit one — reproducible runs and tests, NOT for keys that will
+// hold value — or, unseeded, 192 bits of OS entropy (every key the mode returns is a function of seed, stream and index:
+// the seed is all the secret there is; the reference seeds a 256-bit StdRng from the OS, src/scanner.rs:144).
+RndSeed scan_rnd_seed(uint64_t cfg_seed) {
+    if (cfg_seed) return rnd_seed_from_u64(cfg_seed);
+    std::random_device rd;   // (getrandom / /dev/urandom on this platform)
+    RndSeed s;
+    for (int i = 0; i < 6; i++) s.w[i] = rd();
+    return s;
+}
 
 bool make_match(const vgen_filter &flt, uint32_t format, const BatchKeys &bk, uint32_t index,
                 const uint8_t *payload, const Scalar *end, vgen_generated &g, uint32_t batch = 0, uint32_t images = 1) {
@@ -139,7 +151,7 @@ bool generated_from_key(uint32_t format, const uint8_t kb[32], vgen_generated &g
 // File (text, mode 0600 — it holds the private keys of the matches; rewritten atomically through <path>.tmp,
 // fsync, rename):
 //   vgen-hip checkpoint v1 / pattern_hex= / case_insensitive= / format= / batch_size= / n_shards= /
-//   first_shard= / base= / end= / operations= / done=<per slot> / complete= / mode=range|random / match=<key hex> ...
+//   first_shard= / base= / end= / operations= / done=<per slot> / complete= / mode=range|random-seed24 / match=<key hex> ...
 struct Checkpoint {
     std::string path;
     std::string pattern;
@@ -147,7 +159,7 @@ struct Checkpoint {
     uint32_t format = 0, batch = 0, n_shards = 1, first_shard = 0;
     uint8_t base[32] = {0}, end[32] = {0};
     bool has_end = false;
-    bool random = false;                   // a random-key scan: `base` holds its seed (last eight bytes), done[] counts batches of the streams
+    bool random = false;                   // a random-key scan: `base` holds its 24-byte seed (bytes 8..31), done[] counts batches of the streams
     double interval_s = 10.0;
 
     std::mutex mu;
@@ -212,7 +224,8 @@ struct Checkpoint {
         if (differs("end", has_end ? hex(end, 32) : "none")) return bad("end");
         {
             const std::string *m = get("mode");   // (files written before the field existed are key-range scans')
-            if ((m ? *m : std::string("range")) != (random ? "random" : "range")) return bad("mode");
+            // ("random" without the suffix: a file of round 3's 64-bit-seeded stream function, which no longer exists)
+            if ((m ? *m : std::string("range")) != (random ? "random-seed24" : "range")) return bad("mode");
         }
         std::vector<uint8_t> b;
         const std::string *bs = get("base");
@@ -264,7 +277,7 @@ struct Checkpoint {
                 hex((const uint8_t *)pattern.data(), pattern.size()).c_str(), ci, format, batch, n_shards, first_shard,
                 hex(base, 32).c_str(), has_end ? hex(end, 32).c_str() : "none", (unsigned long long)operations);
         for (size_t i = 0; i < done.size(); i++) fprintf(f, "%s%llu", i ? " " : "", (unsigned long long)done[i]);
-        fprintf(f, "\ncomplete=%d\nmode=%s\n", complete ? 1 : 0, random ? "random" : "range");
+        fprintf(f, "\ncomplete=%d\nmode=%s\n", complete ? 1 : 0, random ? "random-seed24" : "range");
         for (auto &g : ledger) fprintf(f, "match=%s\n", hex(g.key, 32).c_str());
         bool ok = fflush(f) == 0 && fsync(fd) == 0;
         ok = (fclose(f) == 0) && ok;
@@ -365,7 +378,7 @@ struct SlotProgress {
 int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cfg, vgen_progress_cb cb, void *user,
                volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
                std::vector<vgen_generated> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
-               bool *range_done = nullptr, SlotProgress *slot = nullptr) {
+               bool *range_done = nullptr, SlotProgress *slot = nullptr, const RndSeed *scan_seed = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
     const bool random_keys = (cfg->flags & VGEN_SCAN_RANDOM_KEYS) != 0;
     if (ctx->endo && !random_keys && (cfg->has_start || cfg->has_end || cfg->seed || cfg->n_shards > 1 || cfg->checkpoint_path))
@@ -375,7 +388,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     //  shards keep their meaning there, they name streams of candidates, not ranges)
     if (random_keys && (cfg->has_start || cfg->has_end))
         return ctx->fail(VGEN_E_INVALID, "VGEN_SCAN_RANDOM_KEYS draws an independent key per candidate: no start / end");
-    if (random_keys && ck && !cfg->seed) return ctx->fail(VGEN_E_INVALID, "a checkpointed random-key scan needs its seed (open_checkpoint sets it)");
+    if (random_keys && ck && !scan_seed) return ctx->fail(VGEN_E_INVALID, "a checkpointed random-key scan needs its seed (open_checkpoint sets it)");
 
     const uint32_t N = ctx->batch;
     const size_t pbytes = (size_t)ctx->payload_words * 4;
@@ -408,11 +421,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     if (rc != VGEN_OK) return rc;
 
     // independent random keys: candidate index = batch number x N within stream `shard` of the seed
-    uint64_t rnd_seed = cfg->seed;
-    if (random_keys && !rnd_seed) {
-        std::random_device rd;
-        while (!rnd_seed) rnd_seed = ((uint64_t)rd() << 32) | rd();
-    }
+    // (the seed of the whole scan when the caller resolved one — all shards of a multi-device scan and a resumed checkpoint
+    //  share it —, else this call's own)
+    const RndSeed rnd_seed = !random_keys ? RndSeed{} : scan_seed ? *scan_seed : scan_rnd_seed(cfg->seed);
     Scalar current;
     if (random_keys) {
         memset(&current, 0, sizeof current);
@@ -488,7 +499,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                 exhausted = true;
                 return ctx->fail(VGEN_E_RANGE, "random-key stream exhausted (2^64 candidates)");
             }
-            int r = vgen_dispatch_random(ctx, frame, rnd_seed, shard, first);
+            uint8_t sb[24];
+            rnd_seed_to_bytes(rnd_seed, sb);
+            int r = vgen_dispatch_random_seed(ctx, frame, sb, shard, first);
             if (r != VGEN_OK) return r;
             pend[frame] = BatchKeys{};
             pend[frame].random = true;
@@ -701,18 +714,15 @@ void resolve_base(vgen_scan_config &c) {
 // Sets up the checkpoint of a scan over `slots` shards starting at shard `first_shard`; resumes from the
 // file when there is one (adopting its base key for an unseeded random scan).  VGEN_OK / error.
 int open_checkpoint(vgen_ctx *ctx, Checkpoint &ck, const char *pattern, vgen_scan_config &c, uint32_t batch, uint32_t n_shards,
-                    uint32_t first_shard, uint32_t slots) {
+                    uint32_t first_shard, uint32_t slots, RndSeed &rnd_seed) {
     const bool random_keys = (c.flags & VGEN_SCAN_RANDOM_KEYS) != 0;
     const bool pin_base = c.has_start || c.seed;
     if (random_keys) {
         // the scan is named by its seed (OS entropy when the caller gave none: the file then carries it to the next run);
         // `done` counts the batches of each stream
-        while (!c.seed) {
-            std::random_device rd;
-            c.seed = ((uint64_t)rd() << 32) | rd();
-        }
+        rnd_seed = scan_rnd_seed(c.seed);
         memset(c.start, 0, 32);
-        for (int i = 0; i < 8; i++) c.start[31 - i] = (uint8_t)(c.seed >> (8 * i));
+        rnd_seed_to_bytes(rnd_seed, c.start + 8);
     } else {
         resolve_base(c);
     }
@@ -733,10 +743,8 @@ int open_checkpoint(vgen_ctx *ctx, Checkpoint &ck, const char *pattern, vgen_sca
     if (r < 0) return ctx->fail(VGEN_E_INVALID, ck.error);
     memcpy(c.start, ck.base, 32);
     if (random_keys) {   // (the file's seed when the caller gave none)
-        c.seed = 0;
-        for (int i = 0; i < 8; i++) c.seed = (c.seed << 8) | ck.base[24 + i];
+        rnd_seed = rnd_seed_from_bytes(ck.base + 8);
         memset(c.start, 0, 32);
-        if (!c.seed) return ctx->fail(VGEN_E_INVALID, "checkpoint file '" + ck.path + "' carries no seed");
     }
     return VGEN_OK;
 }
@@ -784,12 +792,13 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     vgen_scan_config c = *cfg;
     Checkpoint ck;
     const uint32_t shards = c.n_shards > 1 ? c.n_shards : 1;
-    int rc = open_checkpoint(ctx, ck, pattern, c, ctx->batch, shards, c.n_shards > 1 ? c.shard : 0, 1);
+    RndSeed rnd_seed{};
+    int rc = open_checkpoint(ctx, ck, pattern, c, ctx->batch, shards, c.n_shards > 1 ? c.shard : 0, 1, rnd_seed);
     if (rc != VGEN_OK) return rc;
     matches = ck.ledger;   // what earlier runs found counts towards `count` (committed batches keep all their matches)
     if (matches.size() > c.count) matches.resize((size_t)c.count);
     if (!ck.complete && matches.size() < c.count)
-        rc = scan_shard(ctx, flt, &c, cb, user, stop, nullptr, nullptr, matches, ops, &ck, 0, &range_done);
+        rc = scan_shard(ctx, flt, &c, cb, user, stop, nullptr, nullptr, matches, ops, &ck, 0, &range_done, nullptr, &rnd_seed);
     {
         std::lock_guard<std::mutex> g(ck.mu);
         ck.complete = ck.complete || (rc == VGEN_OK && range_done);
@@ -845,11 +854,14 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     // the walk of an endomorphism context starts from a random base of its own per device; random-key scans stripe by
     // stream (shard i walks stream i) whatever the context
     const bool own_bases = endo && !random_keys;   // no slots to stripe or adopt: every context walks from its own random base
+    RndSeed rnd_seed{};   // random-key scans: one seed for all streams (shard i walks stream i of it)
     if (cfg->checkpoint_path) {
-        int rc = open_checkpoint(ctxs[0], ck, pattern, base, ctxs[0]->batch, n_ctx, 0, n_ctx);
+        int rc = open_checkpoint(ctxs[0], ck, pattern, base, ctxs[0]->batch, n_ctx, 0, n_ctx, rnd_seed);
         if (rc != VGEN_OK) return rc;
         ckp = &ck;
-    } else if (!own_bases && !random_keys) {
+    } else if (random_keys) {
+        rnd_seed = scan_rnd_seed(cfg->seed);
+    } else if (!own_bases) {
         resolve_base(base);   // all shards must walk the same base key
     }
     std::atomic<uint64_t> found{0}, ops_shared{0};
@@ -894,7 +906,7 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
                 std::vector<vgen_generated> got;
                 uint64_t o = 0;
                 const int rc = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
-                                          got, o, ckp, slot, &rd, own_bases ? nullptr : &progress[slot]);
+                                          got, o, ckp, slot, &rd, own_bases ? nullptr : &progress[slot], random_keys ? &rnd_seed : nullptr);
                 std::unique_lock<std::mutex> lk(q_mu);
                 part[slot].insert(part[slot].end(), got.begin(), got.end());
                 ops[slot] += o;
