@@ -625,6 +625,7 @@ def main():
         sys.exit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
     # VGEN_BENCH_REHEARSE=1: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share
     # devices).  Never the measured configuration: one rank per GPU is.
+    frames_asked = args.frames      # (a rehearsal splits the frames between the ranks of a device; the in-process leg runs alone)
     rehearse = world > 1 and os.environ.get("VGEN_BENCH_REHEARSE") == "1"
     # A launcher may also pin ONE device per rank through HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES: every rank then sees a single
     # device 0.  Accepted — and checked below, like every N > 1 run: the ranks must sit on N DIFFERENT devices.
@@ -897,7 +898,7 @@ def main():
     if args.multi_leg_seconds > 0 and (world > 1 or torch.cuda.device_count() > 1):
         barrier()
         if rank == 0:
-            out["in_process_multi"] = in_process_multi(args.multi_leg_seconds, args.batch, args.frames, affinity0)
+            out["in_process_multi"] = in_process_multi(args.multi_leg_seconds, args.batch, frames_asked, affinity0)
         if world > 1:
             dist.barrier()
     if rank == 0 and world == 1 and not args.no_other_configs:

@@ -186,6 +186,106 @@ def test_two_rank_batch_striping_equals_single_range_scan(tmp_path):
     assert got["keys"] == [hex(m["key"]) for m in ref["matches"]]
 
 
+RANK_REPORT_WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import bench
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+pin = bench.numa_pin(rank, sysfs=sys.argv[2])                  # a fake sysfs tree: two GPUs on two NUMA nodes
+dist.barrier()
+t0 = time.perf_counter()
+time.sleep(0.05 * (rank + 1))                                  # rank 1 is the slow one
+t1 = time.perf_counter()
+mine = {"rank": rank, "device": rank, "value": 1000.0 / (rank + 1), "sustained": 1100.0, "region_mhz": 2300 + rank, "sustained_mhz": 2350,
+        "host_dispatch_us": 10.5 + rank, "host_wait_us": 70.0, "numa_node": pin.get("numa_node"), "cpus": pin.get("cpus"), "pinned": pin.get("pinned"),
+        "t0": t0, "t1": t1}
+per_rank = [None] * world
+dist.all_gather_object(per_rank, mine)
+if rank == 0:
+    cols, timing = bench.rank_report(per_rank)
+    print(json.dumps({"per_rank": cols, "timing": timing, "affinity_now": sorted(os.sched_getaffinity(0))}))
+dist.destroy_process_group()
+"""
+
+
+def _fake_sysfs(root, cpus_by_gpu):
+    """A KFD topology with one CPU node and len(cpus_by_gpu) GPU nodes, each GPU on a NUMA node of its own."""
+    nodes = root / "class/kfd/kfd/topology/nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 16\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, cpus in enumerate(cpus_by_gpu):
+        (nodes / str(i + 1)).mkdir()
+        bus = 0x05 + 0x20 * i
+        (nodes / str(i + 1) / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+        dev = root / "bus/pci/devices" / ("0000:%02x:00.0" % bus)
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{i}\n")
+        (dev / "local_cpulist").write_text(cpus + "\n")
+
+
+def test_numa_pinning_reads_the_kfd_topology_and_never_fails(tmp_path):
+    """bench.numa_pin: HIP device order from the KFD topology (no HIP call), the device's NUMA node and its cores from the PCI
+    device's sysfs entry; anything unreadable leaves the affinity alone and says why."""
+    import bench
+    before = os.sched_getaffinity(0)
+    try:
+        cpus = sorted(before)
+        half = max(1, len(cpus) // 2)
+        a, b = bench.format_cpulist(cpus[:half]), bench.format_cpulist(cpus[half:] or cpus[:1])
+        _fake_sysfs(tmp_path, [a, b])
+        assert bench.gpu_pci_addresses(str(tmp_path)) == ["0000:05:00.0", "0000:25:00.0"]
+        pin = bench.numa_pin(1, sysfs=str(tmp_path))
+        if len(cpus) > 1:
+            assert pin["pinned"] and pin["numa_node"] == 1 and pin["pci"] == "0000:25:00.0" and pin["cpus"] == b
+            assert os.sched_getaffinity(0) == bench.parse_cpulist(b)
+        os.sched_setaffinity(0, before)
+        # a launcher's index list is honoured; UUIDs, a missing topology or a device without a node change nothing
+        os.environ["HIP_VISIBLE_DEVICES"] = "1,0"
+        assert bench.numa_pin(0, sysfs=str(tmp_path))["pci"] == "0000:25:00.0"
+        os.sched_setaffinity(0, before)
+        os.environ["HIP_VISIBLE_DEVICES"] = "GPU-deadbeef"
+        pin = bench.numa_pin(0, sysfs=str(tmp_path))
+        assert not pin["pinned"] and "ValueError" in pin["why_not"] and os.sched_getaffinity(0) == before
+        del os.environ["HIP_VISIBLE_DEVICES"]
+        pin = bench.numa_pin(0, sysfs=str(tmp_path / "nowhere"))
+        assert not pin["pinned"] and "why_not" in pin and os.sched_getaffinity(0) == before
+        (tmp_path / "bus/pci/devices/0000:05:00.0/numa_node").write_text("-1\n")
+        pin = bench.numa_pin(0, sysfs=str(tmp_path))
+        assert not pin["pinned"] and pin["numa_node"] == -1 and os.sched_getaffinity(0) == before
+        assert bench.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and bench.format_cpulist({0, 1, 2, 3, 8, 10, 11}) == "0-3,8,10-11"
+    finally:
+        os.environ.pop("HIP_VISIBLE_DEVICES", None)
+        os.sched_setaffinity(0, before)
+
+
+def test_two_ranks_gather_the_per_rank_arrays_of_the_n_gt_1_line(tmp_path):
+    """The N > 1 bench line's per-rank arrays (bench.rank_report) over two gloo ranks on the CPU: every field arrives in rank
+    order, the skews are measured against the earliest start on the node's shared monotonic clock, and every rank pinned
+    itself to its own GPU's NUMA node before anything else (here: a fake sysfs tree with two GPUs on two nodes)."""
+    import json
+    import bench
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 2:
+        pytest.skip("needs two CPU cores")
+    half = len(cpus) // 2
+    _fake_sysfs(tmp_path, [bench.format_cpulist(cpus[:half]), bench.format_cpulist(cpus[half:])])
+    script = tmp_path / "rank_report_worker.py"
+    script.write_text(RANK_REPORT_WORKER)
+    out = _torchrun(script, [ROOT, str(tmp_path)], 29523)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    pr, t = got["per_rank"], got["timing"]
+    assert set(pr) == {"rank", "device", "value", "sustained", "region_mhz", "sustained_mhz", "host_dispatch_us", "host_wait_us", "numa_node", "cpus",
+                       "pinned", "t0_us", "t1_us"}
+    assert pr["rank"] == [0, 1] and pr["value"] == [1000.0, 500.0] and pr["region_mhz"] == [2300, 2301] and pr["host_dispatch_us"] == [10.5, 11.5]
+    assert pr["numa_node"] == [0, 1] and pr["pinned"] == [True, True]
+    assert pr["cpus"] == [bench.format_cpulist(cpus[:half]), bench.format_cpulist(cpus[half:])] and got["affinity_now"] == cpus[:half]
+    assert min(pr["t0_us"]) == 0.0 and 0 <= t["start_skew_us"] == max(pr["t0_us"]) < 20000          # both left the barrier within milliseconds
+    assert 40000 < pr["t1_us"][0] < pr["t1_us"][1] and 30000 < t["finish_skew_us"] < 90000             # rank 1 slept 50 ms longer
+
+
 GPU_WORKER = r"""
 import json, os, sys
 sys.path.insert(0, sys.argv[1])
@@ -227,7 +327,7 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     """bench.py's N>1 path (torchrun, gloo barrier / max over ranks, batch striping) run for real: two ranks
     sharing the one GPU of the test box (VGEN_BENCH_REHEARSE=1), rank 0 prints the single JSON line."""
     import json
-    out = _torchrun(os.path.join(ROOT, "bench.py"), ["--gpus", "2", "--steps", "64", "--warmup", "8", "--sustained-seconds", "0.3"],
+    out = _torchrun(os.path.join(ROOT, "bench.py"), ["--gpus", "2", "--steps", "64", "--warmup", "8", "--sustained-seconds", "0.3", "--multi-leg-seconds", "1"],
                     29521, env_extra={"VGEN_BENCH_REHEARSE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()
@@ -238,6 +338,16 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     assert "cpu_baseline" not in d and "other_configs" not in d
     t = d["timing"]   # whole-job wall time: latest finish - earliest start over the ranks, never less than the slowest rank's own time
     assert t["elapsed_ms"] >= t["slowest_rank_ms"] > 0 and abs(t["elapsed_ms"] / 64 - d["ms_per_step"]) < 1e-3
+    # per-rank arrays: a sub-linear point must name its cause from one run
+    pr = d["per_rank"]
+    assert pr["rank"] == [0, 1] and all(v > 500 for v in pr["value"]) and all(v > 500 for v in pr["sustained"])
+    assert all(1000 < m < 2600 for m in pr["region_mhz"]) and all(0 < h < 200 for h in pr["host_dispatch_us"]) and all(h >= 0 for h in pr["host_wait_us"])
+    assert min(pr["t0_us"]) == 0.0 and t["start_skew_us"] == max(pr["t0_us"]) and t["finish_skew_us"] >= 0
+    assert abs((max(pr["t1_us"]) - 0.0) / 1e3 - t["elapsed_ms"]) < 0.01                       # latest finish - earliest start
+    assert "cpu_affinity" in d["config"] and "cpus" in d["config"]["cpu_affinity"]
+    # the in-process multi-device path ran once over every visible device (one here), in a child, after the ranks' contexts closed
+    m = d["in_process_multi"]
+    assert m.get("error") is None and m["n_devices"] >= 1 and m["failed_shards"] == 0 and m["value"] > 1000 and m["matches"] == 0
 
 
 def _bench(args, env_extra=None, timeout=900):
@@ -277,7 +387,7 @@ def test_bench_plain_gpus_2_prints_n_gpus_2():
     switch a box with fewer GPUs than ranks is refused instead of silently measuring something else."""
     import json
     import vgen_amd as vg
-    args = ["--gpus", "2", "--steps", "64", "--warmup", "8", "--sustained-seconds", "0.3"]
+    args = ["--gpus", "2", "--steps", "64", "--warmup", "8", "--sustained-seconds", "0.3", "--multi-leg-seconds", "0"]
     out = _bench(args, {"VGEN_BENCH_REHEARSE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()

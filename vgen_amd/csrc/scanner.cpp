@@ -551,12 +551,21 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     std::unique_ptr<HostFilterPool> pool;   // created with the first dumped batch / the first batch with thousands of candidates
     bool cut_any = false;      // (no checkpoint) some batch had matches beyond `count` dropped: the range was not covered
 
+#ifdef VGEN_SCAN_PROFILE
+    double prof_wait = 0, prof_pool = 0, prof_merge = 0, prof_dispatch = 0;
+    uint64_t prof_cand = 0;
+    auto pnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#define PROF(var, stmt) { const double t_ = pnow(); stmt; var += pnow() - t_; }
+#else
+#define PROF(var, stmt) { stmt; }
+#endif
     while (status == VGEN_OK && !order.empty()) {
         const uint32_t frame = order.front();
         order.pop_front();
         uint32_t n_found = 0;
         uint64_t tested = 0;
-        if ((status = vgen_wait(ctx, frame, recs.data(), (uint32_t)recs.size(), &n_found, &tested)) != VGEN_OK) break;
+        PROF(prof_wait, status = vgen_wait(ctx, frame, recs.data(), (uint32_t)recs.size(), &n_found, &tested));
+        if (status != VGEN_OK) break;
         in_flight--;
         const BatchKeys batch_start = pend[frame];
         const bool dumped = ctx->fr[frame].dumped;
@@ -610,7 +619,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         bool dispatched_next = false;
         bool ramp_later = false;
         if (may_launch()) {
-            if (!launch(frame)) break;
+            bool ok_launch = true;
+            PROF(prof_dispatch, ok_launch = launch(frame));
+            if (!ok_launch) break;
             dispatched_next = true;
             // ramp up: one more frame per batch — at once when its stream exists; frames that still need their stream
             // (a hardware queue, ~8 ms to create) join as a helper thread gets the streams made, which is asked for
@@ -654,15 +665,18 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                 if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
                 const unsigned nt = pool->size();
                 std::vector<std::vector<vgen_generated>> part(nt);
-                pool->run([&](unsigned t) {
+                PROF(prof_pool, pool->run([&](unsigned t) {
                     const uint32_t lo = (uint32_t)((uint64_t)n_found * t / nt), hi = (uint32_t)((uint64_t)n_found * (t + 1) / nt);
                     vgen_generated gg;
                     for (uint32_t k = lo; k < hi; k++)
                         if (make_match(flt, cfg->format, batch_start, recs[k].index, recs[k].payload, end, gg, N, images)) part[t].push_back(gg);
-                });
-                for (auto &p : part)
+                }));
+                PROF(prof_merge, for (auto &p : part)
                     for (auto &gg : p)
-                        if (!push(gg)) cut = true;
+                        if (!push(gg)) cut = true;);
+#ifdef VGEN_SCAN_PROFILE
+                prof_cand += n_found;
+#endif
             } else {
                 for (; i < n_found && (ck || found() < count); i++)
                     if (make_match(flt, cfg->format, batch_start, recs[i].index, recs[i].payload, end, g, N, images)) (void)push(g);
@@ -686,6 +700,10 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             if (!launch(active++)) break;
         }
     }
+#ifdef VGEN_SCAN_PROFILE
+    fprintf(stderr, "[scan profile] wait %.3f s  pool %.3f s  merge %.3f s  dispatch %.3f s  candidates %llu  matches %zu  ops %llu\n", prof_wait, prof_pool,
+            prof_merge, prof_dispatch, (unsigned long long)prof_cand, matches.size(), (unsigned long long)total_ops);
+#endif
     // A scan that fails between examining a batch and committing it (in dump mode the host filter runs BEFORE the frame is
     // dispatched again, and that dispatch is where a dead device shows) must not keep that batch's matches: the batch is not
     // counted as done, so whoever resumes or takes over the slot will produce them again.
