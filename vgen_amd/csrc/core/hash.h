@@ -29,6 +29,18 @@ VG_HD u32 bswap32(u32 x) {
 #define VG_BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
 #else
 VG_HD u32 vg_bitop3_host(u32 a, u32 b, u32 c, u32 tt) {
+    // the tables this file uses, as plain expressions (the generic evaluation below costs ~40 operations per call and made the
+    // host's SHA-256 four times slower than it needs to be: every match is hashed four times on the host)
+    switch (tt) {
+    case 0x96: return a ^ b ^ c;                    // xor3
+    case 0xCA: return (a & b) | (~a & c);           // SHA-256 Ch, RIPEMD F2
+    case 0xE8: return (a & b) | (c & (a | b));      // SHA-256 Maj
+    case 0x59: return (a | ~b) ^ c;                 // RIPEMD F3
+    case 0xE4: return (a & c) | (b & ~c);           // RIPEMD F4
+    case 0x2D: return a ^ (b | ~c);                 // RIPEMD F5
+    case 0xD2: return a ^ (~b & c);                 // Keccak chi
+    default: break;
+    }
     u32 r = 0;
     for (int i = 0; i < 8; i++)
         if ((tt >> i) & 1) r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);

@@ -18,19 +18,24 @@ namespace vg {
 void host_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
     u32 st[8];
     for (int i = 0; i < 8; i++) st[i] = SHA256_IV[i];
-    std::vector<uint8_t> buf(msg, msg + len);
-    buf.push_back(0x80);
-    while (buf.size() % 64 != 56) buf.push_back(0);
-    uint64_t bits = (uint64_t)len * 8;
-    for (int i = 7; i >= 0; i--) buf.push_back((uint8_t)(bits >> (8 * i)));
-    for (size_t off = 0; off < buf.size(); off += 64) {
+    // Whole blocks straight from the message, the tail (with its padding: one or two blocks) from a buffer on the stack: every
+    // match is hashed four times on the host (two Base58Check checksums), and a heap buffer per call was a third of that cost.
+    auto block = [&](const uint8_t *p) {
         u32 w[16];
-        for (int i = 0; i < 16; i++) {
-            const uint8_t *p = &buf[off + 4 * i];
-            w[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | p[3];
-        }
+        for (int i = 0; i < 16; i++) w[i] = ((u32)p[4 * i] << 24) | ((u32)p[4 * i + 1] << 16) | ((u32)p[4 * i + 2] << 8) | p[4 * i + 3];
         sha256_compress(st, w);
-    }
+    };
+    size_t off = 0;
+    for (; off + 64 <= len; off += 64) block(msg + off);
+    uint8_t tail[128];
+    const size_t rest = len - off, padded = rest < 56 ? 64 : 128;
+    memset(tail, 0, sizeof tail);
+    if (rest) memcpy(tail, msg + off, rest);
+    tail[rest] = 0x80;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[padded - 1 - i] = (uint8_t)(bits >> (8 * i));
+    block(tail);
+    if (padded == 128) block(tail + 64);
     for (int i = 0; i < 8; i++) {
         out[4 * i] = (uint8_t)(st[i] >> 24);
         out[4 * i + 1] = (uint8_t)(st[i] >> 16);

@@ -957,15 +957,22 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
             if (!frame_owns_stream(c)) HIP_TRY(c, hipEventRecord(f.ev_done, f.s));
             if (int rc = wait_done(c, f)) return rc;
         }
-        DevMatch *rec = reinterpret_cast<DevMatch *>(f.h_match + sizeof(DevMatchHeader));
-        // ascending index, the order the reference's par_iter().enumerate() collect yields (gpu.rs:1030-1093)
-        std::sort(rec, rec + stored, [](const DevMatch &x, const DevMatch &y) { return x.index < y.index; });
+        const DevMatch *rec = reinterpret_cast<const DevMatch *>(f.h_match + sizeof(DevMatchHeader));
+        // ascending index, the order the reference's par_iter().enumerate() collect yields (gpu.rs:1030-1093).  The device hands
+        // out slots in arrival order; what is sorted is one 64-bit word per record (index, slot) — a permissive pattern brings
+        // tens of thousands of 40-byte records per dispatch, and sorting those in place was most of this call — and the
+        // records are then copied out once, in order.
         if (out) {
-            uint32_t n = std::min(stored, cap);
+            std::vector<uint64_t> &order = c->sort_scratch;
+            order.resize(stored);
+            for (uint32_t i = 0; i < stored; i++) order[i] = (uint64_t)rec[i].index << 32 | i;
+            std::sort(order.begin(), order.end());
+            const uint32_t n = std::min(stored, cap);
             for (uint32_t i = 0; i < n; i++) {
-                out[i].index = rec[i].index;
+                const DevMatch &r = rec[(uint32_t)order[i]];
+                out[i].index = r.index;
                 out[i].reserved = 0;
-                memcpy(out[i].payload, rec[i].payload, 32);
+                memcpy(out[i].payload, r.payload, 32);
             }
         }
     }

@@ -10,6 +10,7 @@
 // are confirmed with the exact DFA (the reference encodes and regex-matches all batch_size hashes on
 // rayon); the base key can be seeded; batches can be striped over several contexts (multi-GPU).
 #include <fcntl.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -97,10 +98,20 @@ RndSeed scan_rnd_seed(uint64_t cfg_seed) {
     return s;
 }
 
+// A confirmed match as the scan loop carries it: the private key and the address string.  WIF and hex are rendered when
+// the match is handed to the caller (finish_result), in parallel and only for the matches that survive `count` — the
+// reference, too, builds its WIF per MATCH, not per candidate (src/gpu.rs:1080-1088).  [Round 3 carried the 276-byte ABI
+// record with everything rendered: on a permissive pattern (`^1C`: one key in 23) more than half of a scan was the serial
+// hand-over of those records and their second Base58Check, profiles/r04_permissive.txt.]
+struct LiteMatch {
+    uint8_t key[32];
+    char address[64];     // NUL-terminated (longest: a 62-character bech32m address)
+};
+
 bool make_match(const vgen_filter &flt, uint32_t format, const BatchKeys &bk, uint32_t index,
-                const uint8_t *payload, const Scalar *end, vgen_generated &g, uint32_t batch = 0, uint32_t images = 1) {
+                const uint8_t *payload, const Scalar *end, LiteMatch &g, uint32_t batch = 0, uint32_t images = 1) {
     std::string addr = address_from_payload(format, payload);
-    if (addr.empty() || !flt.dfa.is_match(addr)) return false;          // pattern.matches, gpu.rs:1069
+    if (addr.empty() || addr.size() >= sizeof g.address || !flt.dfa.is_match(addr)) return false;          // pattern.matches, gpu.rs:1069
     Scalar k;
     const uint32_t variant = images > 1 ? index / batch : 0;
     if (images > 1) index %= batch;
@@ -117,29 +128,47 @@ bool make_match(const vgen_filter &flt, uint32_t format, const BatchKeys &bk, ui
         k = kv;
     }
     if (end && scalar_cmp(k, *end) > 0) return false;                   // gpu.rs:1074-1078
-    uint8_t kb[32];
-    scalar_to_be(k, kb);
-    memset(&g, 0, sizeof g);
-    std::string wif = key_to_wif(format, kb), hex = hex_lower(kb, 32);
-    strncpy(g.address, addr.c_str(), sizeof g.address - 1);
-    strncpy(g.wif, wif.c_str(), sizeof g.wif - 1);
-    strncpy(g.hex, hex.c_str(), sizeof g.hex - 1);
-    g.format = format;
-    memcpy(g.key, kb, 32);
+    scalar_to_be(k, g.key);
+    memcpy(g.address, addr.c_str(), addr.size() + 1);
     return true;
 }
 
-bool generated_from_key(uint32_t format, const uint8_t kb[32], vgen_generated &g) {
-    uint8_t payload[32];
-    if (!payload_from_key(format, kb, payload)) return false;
+// GeneratedAddress (src/address.rs:63-72) of a match: address, WIF (src/gpu.rs:1080-1088), hex, format, key.
+void render_match(uint32_t format, const LiteMatch &m, vgen_generated &g) {
     memset(&g, 0, sizeof g);
-    std::string addr = address_from_payload(format, payload), wif = key_to_wif(format, kb), hex = hex_lower(kb, 32);
-    strncpy(g.address, addr.c_str(), sizeof g.address - 1);
+    const std::string wif = key_to_wif(format, m.key), hex = hex_lower(m.key, 32);
+    strncpy(g.address, m.address, sizeof g.address - 1);
     strncpy(g.wif, wif.c_str(), sizeof g.wif - 1);
     strncpy(g.hex, hex.c_str(), sizeof g.hex - 1);
     g.format = format;
+    memcpy(g.key, m.key, 32);
+}
+
+// a recorded match (checkpoint file: keys only) back into the loop's form
+bool lite_from_key(uint32_t format, const uint8_t kb[32], LiteMatch &g) {
+    uint8_t payload[32];
+    if (!payload_from_key(format, kb, payload)) return false;
+    const std::string addr = address_from_payload(format, payload);
+    if (addr.empty() || addr.size() >= sizeof g.address) return false;
     memcpy(g.key, kb, 32);
+    memcpy(g.address, addr.c_str(), addr.size() + 1);
     return true;
+}
+
+// Threads for host-side work (candidate confirmation, rendering): the cores this process may really use — affinity mask,
+// capped by a cgroup-v2 CPU quota —, not the machine's thread count (a 256-thread host with a 16-core quota ran 256 workers).
+unsigned host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n ? n : 1024, (unsigned)CPU_COUNT(&set));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            n = std::min<unsigned>(n, (unsigned)std::max(1L, atol(quota) / period));
+        fclose(f);
+    }
+    return std::max(1u, std::min(n, 64u));
 }
 
 // Checkpoint of one scan (the reference has none): which batches of every shard are
@@ -164,7 +193,7 @@ struct Checkpoint {
 
     std::mutex mu;
     std::vector<uint64_t> done;            // per slot (slot = shard - first_shard)
-    std::vector<vgen_generated> ledger;    // matches of committed batches, commit order
+    std::vector<LiteMatch> ledger;         // matches of committed batches, commit order
     uint64_t operations = 0;               // over all runs
     uint64_t resumed_operations = 0;       // as loaded
     bool complete = false;
@@ -249,8 +278,8 @@ struct Checkpoint {
         complete = *c == "1";
         for (auto &e : kv) {
             if (e.first != "match") continue;
-            vgen_generated g;
-            if (!unhex(e.second, b) || b.size() != 32 || !generated_from_key(format, b.data(), g)) return bad("match");
+            LiteMatch g;
+            if (!unhex(e.second, b) || b.size() != 32 || !lite_from_key(format, b.data(), g)) return bad("match");
             ledger.push_back(g);
         }
         return 1;
@@ -287,7 +316,7 @@ struct Checkpoint {
     }
 
     // One finished batch of `slot`: its matches and the shard's counter move together.
-    void commit(uint32_t slot, const std::vector<vgen_generated> &batch_matches, uint64_t ops) {
+    void commit(uint32_t slot, const std::vector<LiteMatch> &batch_matches, uint64_t ops) {
         std::lock_guard<std::mutex> g(mu);
         ledger.insert(ledger.end(), batch_matches.begin(), batch_matches.end());
         done[slot]++;
@@ -377,7 +406,7 @@ struct SlotProgress {
 // *range_done: the shard stopped because its range ran out.
 int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cfg, vgen_progress_cb cb, void *user,
                volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
-               std::vector<vgen_generated> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
+               std::vector<LiteMatch> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
                bool *range_done = nullptr, SlotProgress *slot = nullptr, const RndSeed *scan_seed = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
     const bool random_keys = (cfg->flags & VGEN_SCAN_RANDOM_KEYS) != 0;
@@ -463,12 +492,12 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     total_ops = 0;
     const uint64_t count = cfg->count;
     auto found = [&]() -> uint64_t { return shared_found ? shared_found->load(std::memory_order_relaxed) : matches.size(); };
-    std::vector<vgen_generated> batch_matches;   // matches of the batch being processed (checkpoint commit unit)
+    std::vector<LiteMatch> batch_matches;        // matches of the batch being processed (checkpoint commit unit)
     // A confirmed match: into the result while `count` is not reached; with a checkpoint ALWAYS into the batch's
     // ledger entry, so that a committed batch is recorded with all of its matches and a later run with a larger
     // count loses none.  Returns false when the match was dropped (no checkpoint, count reached).
     uint64_t taken_uncommitted = 0;   // matches taken from the batch in hand, not yet committed (rolled back if the scan fails first)
-    auto push = [&](const vgen_generated &g) -> bool {
+    auto push = [&](const LiteMatch &g) -> bool {
         const bool take = found() < count;
         if (take) {
             matches.push_back(g);
@@ -477,6 +506,27 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         }
         if (ck) batch_matches.push_back(g);
         return take || ck;
+    };
+    // The workers' confirmed matches of one batch (index order: part 0, part 1, ...), handed over in bulk: as many as `count`
+    // still has room for, all of them into the checkpoint's batch record.  Returns true when some were dropped.
+    auto push_parts = [&](std::vector<std::vector<LiteMatch>> &part) -> bool {
+        size_t total = 0;
+        for (auto &p : part) total += p.size();
+        const uint64_t have = found();
+        const uint64_t room = have < count ? count - have : 0;
+        size_t take = (size_t)std::min<uint64_t>(total, room);
+        if (ck) batch_matches.reserve(batch_matches.size() + total);
+        matches.reserve(matches.size() + take);
+        const size_t taken = take;
+        for (auto &p : part) {
+            const size_t k = std::min(take, p.size());
+            matches.insert(matches.end(), p.begin(), p.begin() + (long)k);
+            take -= k;
+            if (ck) batch_matches.insert(batch_matches.end(), p.begin(), p.end());
+        }
+        taken_uncommitted += taken;
+        if (shared_found && taken) shared_found->fetch_add(taken, std::memory_order_relaxed);
+        return taken < total && !ck;
     };
     // frames this scan drives: all of them, or — filtering full dumps on the host — those that have a dump buffer
     // (runtime.cpp: ensure_dump_slab bounds the pinned memory; the host filter is the bottleneck there anyway)
@@ -592,25 +642,23 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                 uint64_t len = total - pos;
                 if (!ck && need < total / 8) len = std::min<uint64_t>(len, std::max<uint64_t>(need * 4, 64) << std::min(2 * round, 24u));
                 if (len < 1024) {
-                    vgen_generated g;
+                    LiteMatch g;
                     const uint32_t stop_at = pos + (uint32_t)len;
                     for (; pos < stop_at && (ck || found() < count); pos++)
                         if (make_match(flt, cfg->format, batch_start, pos, dump + (size_t)pos * pbytes, end, g, N, images)) (void)push(g);
                     continue;
                 }
-                if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
+                if (!pool) pool.reset(new HostFilterPool(host_threads()));
                 const unsigned nt = pool->size();
-                std::vector<std::vector<vgen_generated>> part(nt);
+                std::vector<std::vector<LiteMatch>> part(nt);
                 const uint32_t base = pos, span = (uint32_t)len;
                 pool->run([&](unsigned t) {
                     const uint32_t lo = base + (uint32_t)((uint64_t)span * t / nt), hi = base + (uint32_t)((uint64_t)span * (t + 1) / nt);
-                    vgen_generated g;
+                    LiteMatch g;
                     for (uint32_t i = lo; i < hi; i++)
                         if (make_match(flt, cfg->format, batch_start, i, dump + (size_t)i * pbytes, end, g, N, images)) part[t].push_back(g);
                 });
-                for (auto &p : part)
-                    for (auto &g : p)
-                        if (!push(g)) cut = true;
+                if (push_parts(part)) cut = true;
                 pos += span;
             }
             if (pos < total) cut = true;   // keys left unexamined (conservative: they may not all be matches)
@@ -658,22 +706,20 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
                 prime();
                 continue;
             }
-            vgen_generated g;
+            LiteMatch g;
             uint32_t i = 0;
             if (n_found >= 2048) {
                 // many candidates (a permissive pattern on a grown ring): confirm them on the worker pool, in index order
-                if (!pool) pool.reset(new HostFilterPool(std::thread::hardware_concurrency()));
+                if (!pool) pool.reset(new HostFilterPool(host_threads()));
                 const unsigned nt = pool->size();
-                std::vector<std::vector<vgen_generated>> part(nt);
+                std::vector<std::vector<LiteMatch>> part(nt);
                 PROF(prof_pool, pool->run([&](unsigned t) {
                     const uint32_t lo = (uint32_t)((uint64_t)n_found * t / nt), hi = (uint32_t)((uint64_t)n_found * (t + 1) / nt);
-                    vgen_generated gg;
+                    LiteMatch gg;
                     for (uint32_t k = lo; k < hi; k++)
                         if (make_match(flt, cfg->format, batch_start, recs[k].index, recs[k].payload, end, gg, N, images)) part[t].push_back(gg);
                 }));
-                PROF(prof_merge, for (auto &p : part)
-                    for (auto &gg : p)
-                        if (!push(gg)) cut = true;);
+                PROF(prof_merge, if (push_parts(part)) cut = true;);
 #ifdef VGEN_SCAN_PROFILE
                 prof_cand += n_found;
 #endif
@@ -767,15 +813,31 @@ int open_checkpoint(vgen_ctx *ctx, Checkpoint &ck, const char *pattern, vgen_sca
     return VGEN_OK;
 }
 
-int finish_result(vgen_ctx *ctx, std::vector<vgen_generated> &matches, uint64_t ops, double secs, vgen_scan_result *out) {
+// Hands the matches to the caller as GeneratedAddress records: this is where WIF and hex are rendered — for the matches that
+// survived `count`, straight into the result array, on several threads when there are thousands.
+int finish_result(vgen_ctx *ctx, uint32_t format, std::vector<LiteMatch> &matches, uint64_t ops, double secs, vgen_scan_result *out) {
     out->n_matches = matches.size();
     out->operations = ops;
-    out->elapsed_secs = secs;
     if (!matches.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
         out->matches = (vgen_generated *)malloc(matches.size() * sizeof(vgen_generated));
         if (!out->matches) return ctx->fail(VGEN_E_NOMEM, "out of memory");
-        memcpy(out->matches, matches.data(), matches.size() * sizeof(vgen_generated));
+        const size_t n = matches.size();
+        const unsigned nt = n >= 4096 ? host_threads() : 1;
+        auto work = [&](unsigned t) {
+            for (size_t i = n * t / nt, hi = n * (t + 1) / nt; i < hi; i++) render_match(format, matches[i], out->matches[i]);
+        };
+        if (nt == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();   // rendering is part of the scan's time
     }
+    out->elapsed_secs = secs;
     return VGEN_OK;
 }
 
@@ -790,7 +852,7 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     std::string err;
     if (!filter_compile(pattern, cfg->case_insensitive != 0, cfg->format, flt, err))
         return ctx->fail(VGEN_E_PATTERN, err);
-    std::vector<vgen_generated> matches;
+    std::vector<LiteMatch> matches;
     uint64_t ops = 0;
     bool range_done = false;
     if (!cfg->checkpoint_path) {
@@ -799,13 +861,13 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
             // the error, AND what the batches finished before it had found (complete = 0): a host that falls back to
             // another backend (the reference's run_search does, src/lib.rs:727-746,1185-1198) keeps those matches
             const std::string why = ctx->err;
-            (void)finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+            (void)finish_result(ctx, cfg->format, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
             out->failed_shards = 1;
             ctx->err = why;
             return rc;
         }
         out->complete = range_done;
-        return finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+        return finish_result(ctx, cfg->format, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
     }
     vgen_scan_config c = *cfg;
     Checkpoint ck;
@@ -824,13 +886,13 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     }
     if (rc != VGEN_OK) {
         const std::string why = ctx->err;
-        std::vector<vgen_generated> all;
+        std::vector<LiteMatch> all;
         {
             std::lock_guard<std::mutex> g(ck.mu);
             all = ck.ledger;   // every batch committed before the failure, earlier runs included (the file holds the same)
         }
         if (all.size() > c.count) all.resize((size_t)c.count);
-        (void)finish_result(ctx, all, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+        (void)finish_result(ctx, cfg->format, all, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
         out->resumed_operations = ck.resumed_operations;
         out->failed_shards = 1;
         ctx->err = why;
@@ -838,7 +900,7 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     }
     out->complete = ck.complete;
     out->resumed_operations = ck.resumed_operations;
-    return finish_result(ctx, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+    return finish_result(ctx, cfg->format, matches, ops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
 }
 
 // Multi-device scan: one host thread per context, batches striped over the contexts (context i takes
@@ -891,7 +953,7 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     // adapter and falls back to its CPU path instead, src/lib.rs:727-746,1185-1198; SURVEY.md 5: "per-GPU worker failure =>
     // re-queue its range on surviving GPUs").  Batches in flight on the failed context were never committed: the adopter
     // redoes them.  Contexts that finish while others are still running wait for a possible orphan instead of exiting.
-    std::vector<std::vector<vgen_generated>> part(n_ctx);
+    std::vector<std::vector<LiteMatch>> part(n_ctx);
     std::vector<uint64_t> ops(n_ctx, 0);
     std::vector<int> rcs(n_ctx, VGEN_OK);
     std::vector<char> range_done(n_ctx, 0), slot_finished(n_ctx, 0);
@@ -921,7 +983,7 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
                 c.shard = own_bases ? 0 : slot;
                 c.n_shards = own_bases ? 0 : n_ctx;
                 bool rd = false;
-                std::vector<vgen_generated> got;
+                std::vector<LiteMatch> got;
                 uint64_t o = 0;
                 const int rc = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
                                           got, o, ckp, slot, &rd, own_bases ? nullptr : &progress[slot], random_keys ? &rnd_seed : nullptr);
@@ -977,17 +1039,17 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     }
     out->complete = ckp ? ck.complete : all_done;
     out->failed_shards = (int32_t)failed_ctx;
-    std::vector<vgen_generated> all;
+    std::vector<LiteMatch> all;
     uint64_t total = 0;
     if (ckp) all = ck.ledger;   // earlier runs' matches + every batch committed by this one
     for (uint32_t i = 0; i < n_ctx; i++) {
         if (!ckp) all.insert(all.end(), part[i].begin(), part[i].end());
         total += ops[i];
     }
-    std::sort(all.begin(), all.end(), [](const vgen_generated &a, const vgen_generated &b) { return memcmp(a.key, b.key, 32) < 0; });
+    std::sort(all.begin(), all.end(), [](const LiteMatch &a, const LiteMatch &b) { return memcmp(a.key, b.key, 32) < 0; });
     if (all.size() > cfg->count) all.resize((size_t)cfg->count);
     const std::string why = first_err != VGEN_OK ? ctxs[first_err_ctx]->err : std::string();
-    const int frc = finish_result(ctxs[0], all, total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
+    const int frc = finish_result(ctxs[0], cfg->format, all, total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), out);
     if (first_err != VGEN_OK && !absorbed) {
         out->complete = 0;
         ctxs[first_err_ctx]->err = why;
