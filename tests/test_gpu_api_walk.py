@@ -111,7 +111,7 @@ def test_random_walk_over_dispatch_wait_and_filter_changes(vg, vo, fmt, endo, se
             expect = [s for s in slots if want(s) is not None and ore.matches(addr(want(s)))]
             assert confirmed == expect, (kind, len(confirmed), len(expect))
 
-    for _ in range(int(os.environ.get("VGEN_WALK_STEPS", "70"))):
+    for _ in range(int(os.environ.get("VGEN_WALK_STEPS", "70" if os.environ.get("VGEN_TEST_FULL") == "1" else "45"))):
         free = [f for f in range(F) if f not in in_flight]
         x = rng.random()
         if in_flight and (not free or x < 0.4):

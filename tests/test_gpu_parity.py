@@ -254,7 +254,7 @@ def test_generated_patterns_on_the_device(vg, vo, fmt):
         fmt, "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz")
     kinds = {}
     import os
-    for _ in range(int(os.environ.get("VGEN_PATTERN_WALK", "60"))):
+    for _ in range(int(os.environ.get("VGEN_PATTERN_WALK", "60" if os.environ.get("VGEN_TEST_FULL") == "1" else "36"))):
         a = rng.choice(addrs)
         pattern, ci = generalise(rng, a, head, alphabet, fmt)
         p = vg.Pattern(pattern, ci, vg.AddressFormat(fmt))

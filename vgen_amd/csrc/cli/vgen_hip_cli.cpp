@@ -182,6 +182,8 @@ void usage() {
             "                    [--gpu-batch-size N] [--repeat N] [-q] [--seed S] [--devices 0,1,..|all] [--frames F]\n"
             "                    [--frames F]          (dispatches in flight, default 12; several searches on ONE device share it\n"
             "                                           evenly as long as their frames add up to twenty or fewer: 2 x 8, 3 x 6 ...)\n"
+            "                    [--seed S]            (a reproducible search: base key / candidate stream derived from the 64-bit S —\n"
+            "                                           for tests and benchmarks; keys found this way are only as secret as S)\n"
             "                    [--checkpoint FILE]   (resume an interrupted scan from FILE; written as the scan runs)\n"
             "                    [--no-endo]           (unseeded searches, any format but P2TR, test six keys per curve\n"
             "                                           point — k, lambda k, lambda^2 k and their negations; this walks k0 + i only)\n"
@@ -459,6 +461,10 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
     cfg.count = o.count == 0 ? UINT64_MAX : o.count;   // lib.rs:524
     cfg.case_insensitive = o.ignore_case;
     cfg.seed = o.seed;
+    // every key a seeded search returns is a function of the 64-bit seed and a small counter: whoever learns the address can
+    // replay the search (unseeded searches draw 256 / 192 bits from the OS, as the reference does: src/gpu.rs:936-945, scanner.rs:144)
+    if (o.seed && !has_range && !o.quiet)
+        fprintf(stderr, "Warning: --seed makes this search reproducible and its keys guessable (64 bits of secret): do not fund what it finds\n");
     if (has_range) {
         cfg.has_start = cfg.has_end = 1;
         memcpy(cfg.start, start, 32);

@@ -70,7 +70,7 @@ struct vgen_ctx {
         uint32_t last_clk_cycles = 0, last_clk_ticks = 0;   // ... and what the last dispatch added to them
     };
     std::vector<Frame> fr;
-    std::vector<uint64_t> sort_scratch;          // rt_wait: (index, slot) words of the records being put in index order
+    std::vector<uint64_t> sort_scratch, sort_scratch2;   // rt_wait: (index, slot) words of the records being put in index order
     // One stream per frame, created at first use (a hardware queue each, ~8 ms) or, once a scan has asked for them
     // (rt_prepare_streams), by a helper thread while the scan runs on the frames it already has.
     std::vector<hipStream_t> streams;            // [frames]

@@ -108,6 +108,63 @@ struct LiteMatch {
     char address[64];     // NUL-terminated (longest: a 62-character bech32m address)
 };
 
+// The matches of a scan in hand-over order, kept as the BLOCKS they arrive in (the worker threads' per-batch results, moved in whole): a
+// permissive pattern yields millions, and copying them into one growing vector — reallocations and first-touch page faults, all on the
+// scanning thread — was a third of such a scan even after the records had shrunk to 96 bytes (profiles/r04_permissive.txt).
+class MatchList {
+public:
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    void push_back(const LiteMatch &m) {
+        if (blocks_.empty() || blocks_.back().size() == blocks_.back().capacity()) {
+            blocks_.emplace_back();
+            blocks_.back().reserve(1024);
+        }
+        blocks_.back().push_back(m);
+        n_++;
+    }
+    // the first k entries of v, without copying them
+    void take(std::vector<LiteMatch> &&v, size_t k) {
+        if (k == 0) return;
+        if (k < v.size()) v.resize(k);
+        n_ += v.size();
+        blocks_.push_back(std::move(v));
+    }
+    void append_copy(const std::vector<LiteMatch> &v) {
+        if (v.empty()) return;
+        n_ += v.size();
+        blocks_.push_back(v);
+    }
+    void append(MatchList &&o) {
+        for (auto &b : o.blocks_) {
+            n_ += b.size();
+            blocks_.push_back(std::move(b));
+        }
+        o.blocks_.clear();
+        o.n_ = 0;
+    }
+    void truncate(size_t n) {   // keep the first n
+        while (n_ > n) {
+            auto &b = blocks_.back();
+            const size_t drop = std::min(n_ - n, b.size());
+            b.resize(b.size() - drop);
+            n_ -= drop;
+            if (b.empty()) blocks_.pop_back();
+        }
+    }
+    std::vector<LiteMatch> flatten() const {
+        std::vector<LiteMatch> out;
+        out.reserve(n_);
+        for (auto &b : blocks_) out.insert(out.end(), b.begin(), b.end());
+        return out;
+    }
+    const std::vector<std::vector<LiteMatch>> &blocks() const { return blocks_; }
+
+private:
+    std::vector<std::vector<LiteMatch>> blocks_;
+    size_t n_ = 0;
+};
+
 bool make_match(const vgen_filter &flt, uint32_t format, const BatchKeys &bk, uint32_t index,
                 const uint8_t *payload, const Scalar *end, LiteMatch &g, uint32_t batch = 0, uint32_t images = 1) {
     std::string addr = address_from_payload(format, payload);
@@ -406,7 +463,7 @@ struct SlotProgress {
 // *range_done: the shard stopped because its range ran out.
 int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cfg, vgen_progress_cb cb, void *user,
                volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
-               std::vector<LiteMatch> &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
+               MatchList &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
                bool *range_done = nullptr, SlotProgress *slot = nullptr, const RndSeed *scan_seed = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
     const bool random_keys = (cfg->flags & VGEN_SCAN_RANDOM_KEYS) != 0;
@@ -515,14 +572,12 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         const uint64_t have = found();
         const uint64_t room = have < count ? count - have : 0;
         size_t take = (size_t)std::min<uint64_t>(total, room);
-        if (ck) batch_matches.reserve(batch_matches.size() + total);
-        matches.reserve(matches.size() + take);
         const size_t taken = take;
         for (auto &p : part) {
-            const size_t k = std::min(take, p.size());
-            matches.insert(matches.end(), p.begin(), p.begin() + (long)k);
-            take -= k;
             if (ck) batch_matches.insert(batch_matches.end(), p.begin(), p.end());
+            const size_t k = std::min(take, p.size());
+            matches.take(std::move(p), k);     // the worker's vector itself becomes a block of the result: nothing is copied
+            take -= k;
         }
         taken_uncommitted += taken;
         if (shared_found && taken) shared_found->fetch_add(taken, std::memory_order_relaxed);
@@ -754,7 +809,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     // dispatched again, and that dispatch is where a dead device shows) must not keep that batch's matches: the batch is not
     // counted as done, so whoever resumes or takes over the slot will produce them again.
     if (status != VGEN_OK && taken_uncommitted) {
-        matches.resize(matches.size() - (size_t)taken_uncommitted);
+        matches.truncate(matches.size() - (size_t)taken_uncommitted);
         if (shared_found) shared_found->fetch_sub(taken_uncommitted, std::memory_order_relaxed);
     }
     // drain anything still in flight (the reference drops its runner; we must not leave frames busy)
@@ -815,7 +870,7 @@ int open_checkpoint(vgen_ctx *ctx, Checkpoint &ck, const char *pattern, vgen_sca
 
 // Hands the matches to the caller as GeneratedAddress records: this is where WIF and hex are rendered — for the matches that
 // survived `count`, straight into the result array, on several threads when there are thousands.
-int finish_result(vgen_ctx *ctx, uint32_t format, std::vector<LiteMatch> &matches, uint64_t ops, double secs, vgen_scan_result *out) {
+int finish_result(vgen_ctx *ctx, uint32_t format, const MatchList &matches, uint64_t ops, double secs, vgen_scan_result *out) {
     out->n_matches = matches.size();
     out->operations = ops;
     if (!matches.empty()) {
@@ -824,8 +879,17 @@ int finish_result(vgen_ctx *ctx, uint32_t format, std::vector<LiteMatch> &matche
         if (!out->matches) return ctx->fail(VGEN_E_NOMEM, "out of memory");
         const size_t n = matches.size();
         const unsigned nt = n >= 4096 ? host_threads() : 1;
+        const auto &blocks = matches.blocks();
         auto work = [&](unsigned t) {
-            for (size_t i = n * t / nt, hi = n * (t + 1) / nt; i < hi; i++) render_match(format, matches[i], out->matches[i]);
+            // entries [lo, hi) of the list, walked block by block
+            const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            size_t base = 0;
+            for (auto &b : blocks) {
+                const size_t from = std::max(lo, base), to = std::min(hi, base + b.size());
+                for (size_t i = from; i < to; i++) render_match(format, b[i - base], out->matches[i]);
+                base += b.size();
+                if (base >= hi) break;
+            }
         };
         if (nt == 1) {
             work(0);
@@ -841,6 +905,12 @@ int finish_result(vgen_ctx *ctx, uint32_t format, std::vector<LiteMatch> &matche
     return VGEN_OK;
 }
 
+int finish_result(vgen_ctx *ctx, uint32_t format, std::vector<LiteMatch> &matches, uint64_t ops, double secs, vgen_scan_result *out) {
+    MatchList l;
+    l.take(std::move(matches), matches.size());
+    return finish_result(ctx, format, l, ops, secs, out);
+}
+
 }  // namespace
 
 extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
@@ -852,7 +922,7 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     std::string err;
     if (!filter_compile(pattern, cfg->case_insensitive != 0, cfg->format, flt, err))
         return ctx->fail(VGEN_E_PATTERN, err);
-    std::vector<LiteMatch> matches;
+    MatchList matches;
     uint64_t ops = 0;
     bool range_done = false;
     if (!cfg->checkpoint_path) {
@@ -875,8 +945,8 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
     RndSeed rnd_seed{};
     int rc = open_checkpoint(ctx, ck, pattern, c, ctx->batch, shards, c.n_shards > 1 ? c.shard : 0, 1, rnd_seed);
     if (rc != VGEN_OK) return rc;
-    matches = ck.ledger;   // what earlier runs found counts towards `count` (committed batches keep all their matches)
-    if (matches.size() > c.count) matches.resize((size_t)c.count);
+    matches.append_copy(ck.ledger);   // what earlier runs found counts towards `count` (committed batches keep all their matches)
+    if (matches.size() > c.count) matches.truncate((size_t)c.count);
     if (!ck.complete && matches.size() < c.count)
         rc = scan_shard(ctx, flt, &c, cb, user, stop, nullptr, nullptr, matches, ops, &ck, 0, &range_done, nullptr, &rnd_seed);
     {
@@ -953,7 +1023,7 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     // adapter and falls back to its CPU path instead, src/lib.rs:727-746,1185-1198; SURVEY.md 5: "per-GPU worker failure =>
     // re-queue its range on surviving GPUs").  Batches in flight on the failed context were never committed: the adopter
     // redoes them.  Contexts that finish while others are still running wait for a possible orphan instead of exiting.
-    std::vector<std::vector<LiteMatch>> part(n_ctx);
+    std::vector<MatchList> part(n_ctx);
     std::vector<uint64_t> ops(n_ctx, 0);
     std::vector<int> rcs(n_ctx, VGEN_OK);
     std::vector<char> range_done(n_ctx, 0), slot_finished(n_ctx, 0);
@@ -983,12 +1053,12 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
                 c.shard = own_bases ? 0 : slot;
                 c.n_shards = own_bases ? 0 : n_ctx;
                 bool rd = false;
-                std::vector<LiteMatch> got;
+                MatchList got;
                 uint64_t o = 0;
                 const int rc = scan_shard(ctxs[i], flt, &c, cb ? (vgen_progress_cb)locked_cb : nullptr, &cbc, stop, &found, &ops_shared,
                                           got, o, ckp, slot, &rd, own_bases ? nullptr : &progress[slot], random_keys ? &rnd_seed : nullptr);
                 std::unique_lock<std::mutex> lk(q_mu);
-                part[slot].insert(part[slot].end(), got.begin(), got.end());
+                part[slot].append(std::move(got));
                 ops[slot] += o;
                 if (rc != VGEN_OK) {
                     // this context retires; the slot it was working on is up for adoption (never for endomorphism contexts:
@@ -1043,7 +1113,10 @@ extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *patt
     uint64_t total = 0;
     if (ckp) all = ck.ledger;   // earlier runs' matches + every batch committed by this one
     for (uint32_t i = 0; i < n_ctx; i++) {
-        if (!ckp) all.insert(all.end(), part[i].begin(), part[i].end());
+        if (!ckp) {
+            const std::vector<LiteMatch> flat = part[i].flatten();
+            all.insert(all.end(), flat.begin(), flat.end());
+        }
         total += ops[i];
     }
     std::sort(all.begin(), all.end(), [](const LiteMatch &a, const LiteMatch &b) { return memcmp(a.key, b.key, 32) < 0; });
