@@ -168,6 +168,11 @@ extern "C" {
 // Compiles pattern for `format`; evaluates the DEVICE prefilter program (the same filter_eval the
 // kernel runs) and the exact DFA on the encoded address of `payload`.
 // returns: bit0 = device prefilter hit, bit1 = exact match, or -1 on pattern error. kind_out = device kind.
+// host_sha256 of an arbitrary message, by the portable block function (0) or with the SHA extensions allowed (1)
+void core_host_sha256(const unsigned char *msg, unsigned long len, unsigned char *out32, int allow_sha_ni) {
+    host_sha256_with(msg, len, out32, allow_sha_ni != 0);
+}
+
 int core_filter_check(const char *pattern, int ci, unsigned format, const unsigned char *payloads, int n,
                       unsigned char *out_flags, int *kind_out, double *sel_out) {
     vgen_filter f;

@@ -13,6 +13,8 @@
 namespace vg {
 
 void host_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+// the same with the choice of block function exposed (tests: the portable path against the SHA-extension path)
+void host_sha256_with(const uint8_t *msg, size_t len, uint8_t out[32], bool allow_sha_ni);
 void host_ripemd160(const uint8_t *msg, size_t len, uint8_t out[20]);
 void host_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]);
 void host_hash160(const uint8_t *msg, size_t len, uint8_t out[20]);
