@@ -51,3 +51,20 @@ def test_keccak_address(core):
         out = ctypes.create_string_buffer(20)
         core.core_keccak_addr(p[1:33], p[33:65], out)
         assert out.raw == vo.keccak256(p[1:])[12:]
+
+
+def test_host_sha256_portable_and_sha_extension_paths_agree_with_hashlib(core):
+    """host_sha256 (host/encode.cpp) — what the host's Base58Check checksums run through, four blocks per match — by both of its
+    block functions: the portable one (the single-source core/hash.h, with the host's plain-expression truth tables) and the x86 SHA
+    extensions where the CPU has them (run-time CPUID; the call with allow = 1 falls back by itself elsewhere).  Every length
+    around the one- and two-block padding boundaries, and long messages."""
+    import hashlib
+    rng = random.Random(5)
+    for length in list(range(0, 200)) + [255, 256, 257, 1000, 4096, 65537]:
+        for _ in range(3):
+            m = rng.randbytes(length)
+            want = hashlib.sha256(m).digest()
+            for allow in (0, 1):
+                out = ctypes.create_string_buffer(32)
+                core.core_host_sha256(m, ctypes.c_ulong(length), out, allow)
+                assert out.raw == want, (length, allow)
