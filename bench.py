@@ -537,14 +537,12 @@ def in_process_multi(seconds, batch, frames, affinity=None):
                                                             "MASTER_ADDR", "MASTER_PORT", "VGEN_BENCH_REHEARSE") and not k.startswith("TORCHELASTIC")}
     cmd = [sys.executable, os.path.abspath(__file__), "--multi-leg-child", "--multi-leg-seconds", str(seconds), "--batch", str(batch), "--frames", str(frames)]
 
-    def unpin():   # the child drives every device of the node: the whole box's cores, not this rank's socket
-        if affinity:
-            try:
-                os.sched_setaffinity(0, affinity)
-            except OSError:
-                pass
+    # the child drives every device of the node: it gets the whole box's cores back (it widens its own mask at start — no
+    # preexec_fn: running Python between fork and exec of a process full of runtime threads can deadlock)
+    if affinity:
+        cmd += ["--multi-leg-cpus", format_cpulist(affinity)]
     try:
-        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=seconds + 120, preexec_fn=unpin)
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=seconds + 120)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if p.returncode != 0 or not lines:
             return {"value": None, "error": f"child exited with {p.returncode}: {p.stderr.strip()[-300:]}"}
@@ -598,9 +596,15 @@ def main():
     ap.add_argument("--multi-leg-seconds", type=float, default=3.0, help="wall time of the in-process vgen_scan_multi leg over all visible devices "
                                                                          "(N > 1, or N = 1 on a multi-GPU box; 0 = skip)")
     ap.add_argument("--multi-leg-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--multi-leg-cpus", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.multi_leg_child:
+        if args.multi_leg_cpus:
+            try:
+                os.sched_setaffinity(0, parse_cpulist(args.multi_leg_cpus))
+            except (OSError, ValueError):
+                pass
         multi_leg_child(args.multi_leg_seconds, args.batch, args.frames)
         return
 
