@@ -732,6 +732,16 @@ def main():
     # the wall time of the whole job, a little MORE than the maximum of the per-rank times, without the latency of the
     # gloo barrier itself (hundreds of microseconds against a 2 ms region).  At N = 1 this is the plain bracket.
     barrier()
+    if world > 1:
+        # The gloo barrier releases its ranks tens to hundreds of microseconds apart — against a 2 ms region that alone would read as
+        # 2-10 % of "scaling loss" in elapsed = latest finish - earliest start.  So the ranks agree on a start INSTANT on the node's
+        # shared monotonic clock (rank 0's "now + 3 ms", broadcast) and each spins until it: the brackets stay barrier + synchronize on
+        # both sides, the start is simply tight.  A rank that learns the instant too late starts at once; per_rank.t0_us shows it.
+        go = torch.tensor([time.perf_counter() + 0.003], dtype=torch.float64)
+        dist.broadcast(go, src=0)
+        t_go = float(go.item())
+        while time.perf_counter() < t_go:
+            pass
     t0 = time.perf_counter()
     cand, _ = pipe.run_steps(args.steps, host_times=True)
     torch.cuda.synchronize()
@@ -859,8 +869,9 @@ def main():
         out["timing"] = {"elapsed_ms": round(elapsed * 1e3, 4), "slowest_rank_ms": round(slowest_rank_s * 1e3, 4),
                          "closing_barrier_ms_rank0": round((t_barrier - t1) * 1e3, 4), **skew,
                          "how": "elapsed = latest finish - earliest start over the ranks (one node, system-wide monotonic clock); "
-                                "start: after the opening barrier + synchronize, finish: after the rank's closing synchronize; "
-                                "the closing barrier follows the clock"}
+                                "start: after the opening barrier + synchronize, at an instant the ranks agreed on (rank 0's now + 3 ms, broadcast; "
+                                "each rank spins until it, so the barrier's uneven release does not count as work time); finish: after the rank's "
+                                "closing synchronize; the closing barrier follows the clock"}
     if rank == 0 and world == 1:
         # the kernel alone: frames = 1, so every launch has the chip to itself (one wave per SIMD), HIP events
         # recorded on the launch's own stream immediately before and after seq_bwd_kernel
