@@ -658,7 +658,10 @@ def main():
         # the max of the elapsed time, so it runs over gloo — no RCCL communicator, no extra device queues beside
         # the frames' own.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        # (a rank that dies must fail the job within minutes, not leave the others at a barrier for gloo's default half hour;
+        #  the longest legitimate wait is rank 0's in-process leg: its seconds + a 120 s deadline)
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
         if not rehearse:
             # one rank per GPU, verified: N ranks on fewer than N devices would print an aggregate that is not N GPUs' worth
             pr = torch.cuda.get_device_properties(local_rank)
@@ -668,6 +671,20 @@ def main():
             if len(set(idents)) < world:
                 sys.exit(f"bench.py: --gpus {world} but the ranks sit on {len(set(idents))} device(s) — one rank per GPU is the measured configuration "
                          "(VGEN_BENCH_REHEARSE=1 for a rehearsal on fewer devices)")
+
+    # ---- the product's own multi-device path, once, over ALL visible devices in ONE process (vgen_scan_multi: what
+    # `vgen-hip --devices all` runs; bench.py's ranks are N processes).  FIRST, before any rank has created a stream: a
+    # device's hardware queues belong to the processes that made them until those exit, and a rank's twelve idle queues
+    # beside the leg's twelve busy ones are the oversubscription that collapses throughput (measured in the rehearsal:
+    # 0.54 instead of 11.9 Gkeys/s when the leg ran after the ranks had used their frames).  Rank 0 starts it as a child
+    # process with a deadline, the other ranks wait at a (gloo-only) barrier; when the child has exited its queues are
+    # gone and the measured run starts on a clean device.  Never part of `value`.
+    multi_leg = None
+    if args.multi_leg_seconds > 0 and (world > 1 or torch.cuda.device_count() > 1):
+        if rank == 0:
+            multi_leg = in_process_multi(args.multi_leg_seconds, args.batch, frames_asked, affinity0)
+        if world > 1:
+            dist.barrier()
 
     import vgen_amd as vg
     fmt = vg.AddressFormat(FORMATS[args.format])
@@ -909,15 +926,8 @@ def main():
         except Exception as e:   # noqa: BLE001
             out["time_to_first_match"] = {"error": f"{type(e).__name__}: {e}"}
     runner.close()
-    # ---- the product's own multi-device path, once, over ALL visible devices in ONE process (vgen_scan_multi: what
-    # `vgen-hip --devices all` runs; bench.py's ranks are N processes).  After every rank has closed its context; rank 0
-    # starts it as a child process with a deadline, the other ranks wait at the barrier.  Never part of `value`.
-    if args.multi_leg_seconds > 0 and (world > 1 or torch.cuda.device_count() > 1):
-        barrier()
-        if rank == 0:
-            out["in_process_multi"] = in_process_multi(args.multi_leg_seconds, args.batch, frames_asked, affinity0)
-        if world > 1:
-            dist.barrier()
+    if multi_leg is not None:
+        out["in_process_multi"] = multi_leg
     if rank == 0 and world == 1 and not args.no_other_configs:
         sec = 1.0
         # every auxiliary leg stands alone: a failure there is recorded in its entry and never costs the headline line
