@@ -34,6 +34,15 @@
 #include "host/scalar.h"
 #include "runtime.h"
 
+// -DVGEN_SCAN_PROFILE (tools/permissive_probe.py, profiles/r04_permissive.txt): seconds the scanning thread spends in vgen_wait, in the
+// worker pool's confirmation pass, in the hand-over of the workers' matches and in dispatch calls, printed when a shard ends.
+#ifdef VGEN_SCAN_PROFILE
+static inline double prof_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define PROF(var, stmt) { const double t_ = prof_now(); stmt; var += prof_now() - t_; }
+#else
+#define PROF(var, stmt) { stmt; }
+#endif
+
 namespace vg {
 
 // k0(seed, shard) = SHA-256("vgen-mi355x" || u64le(seed) || u32le(shard)) mod n, re-drawn if 0
@@ -659,10 +668,6 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
 #ifdef VGEN_SCAN_PROFILE
     double prof_wait = 0, prof_pool = 0, prof_merge = 0, prof_dispatch = 0;
     uint64_t prof_cand = 0;
-    auto pnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-#define PROF(var, stmt) { const double t_ = pnow(); stmt; var += pnow() - t_; }
-#else
-#define PROF(var, stmt) { stmt; }
 #endif
     while (status == VGEN_OK && !order.empty()) {
         const uint32_t frame = order.front();
