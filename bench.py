@@ -359,6 +359,33 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, en
                      "32 MB host-to-device upload of every dispatch")}
 
 
+def wide_table_configs(vg, batch, frames, device, seconds):
+    """The scalar-multiplication paths over the 29-bit SIGNED-window generator table (8 additions per multiplication instead of the
+    24-bit table's 10; 138 of the device's 288 GB; 2.3 s to allocate and build): what vgen_scan selects by itself for scans it
+    expects to run a minute or more (scanner.cpp), forced here through VGEN_GTAB_BITS for the length of the leg."""
+    old = os.environ.get("VGEN_GTAB_BITS")
+    os.environ["VGEN_GTAB_BITS"] = "29"
+    out = []
+    try:
+        t0 = time.perf_counter()
+        e = keys_mode_config(vg, batch, frames, device, seconds, random_stream=True)
+        e["config"] += " — 29-bit signed-window table (8 additions)"
+        e["seconds_incl_table_build"] = round(time.perf_counter() - t0, 2)
+        e["chip_frac"] = e["roofline"] = None      # (the committed counter pass is of the 24-bit table's instruction count)
+        e["note"] = ("as the entry over the default table, with VGEN_GTAB_BITS=29: windows of 29 bits with signed digits, a table of magnitudes "
+                     "(m * 2^(29 w) * G, m <= 2^28; negative digits take (x, p - y)), 9 windows = 8 mixed additions; profiles/r04_gtab_signed.txt")
+        out.append(e)
+        e = timed_config(vg, "p2tr", "^bc1pqqq", False, batch, frames, device, seconds, "P2TR (taproot tweak on the device) — 29-bit signed-window table (8 additions)")
+        e["chip_frac"] = e["roofline"] = None
+        out.append(e)
+    finally:
+        if old is None:
+            os.environ.pop("VGEN_GTAB_BITS", None)
+        else:
+            os.environ["VGEN_GTAB_BITS"] = old
+    return out
+
+
 def dump_mode_configs(vg, batch, device, seconds):
     """The reference's own mode (every payload back to the host, src/gpu.rs:602-658,1030-1093): (a) the device +
     PCIe side alone, (b) a whole scan whose pattern is too permissive for the match ring, filtered on the host."""
@@ -958,6 +985,7 @@ def main():
         oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec)
         oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec, random_stream=True)
         oc += leg(keys_mode_config, vg, args.batch, min(F, 8), local_rank, sec, random_stream=True, endo=True)
+        oc += leg(wide_table_configs, vg, args.batch, min(F, 8), local_rank, sec)
         oc += leg(dump_mode_configs, vg, args.batch, local_rank, sec)
         out["other_configs"] = oc
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

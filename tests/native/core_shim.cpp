@@ -369,3 +369,66 @@ int core_mul_w16(const unsigned char *key_be, unsigned char *xy) {
     return 1;
 }
 }
+
+#include <sys/mman.h>
+extern "C" {
+// ec_mul_gen_signed<ST> (core/ec.h: signed windows of 25 / 27 / 29 bits, the device algorithm behind VGEN_GTAB_BITS = 25 | 27 | 29) on
+// the host: the table (5.9 / 21.5 / 138 GB) is mapped without backing store and only the entries this key walks are filled
+// in — m * 2^(ST w) * G by the generic host multiplication, the top window's 2^256 taken mod n as the device builder does.
+// result x||y big-endian.  Returns 0 for an invalid key, -1 when the table cannot be mapped.
+int core_mul_signed(int st, const unsigned char *key_be, unsigned char *xy) {
+    static uint32_t *tabs[32] = {nullptr};
+    if (st != 25 && st != 27 && st != 29) return -1;
+    if (!tabs[st]) {
+        void *p = mmap(nullptr, (size_t)ec_table_words((u32)st) * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) return -1;
+        tabs[st] = (uint32_t *)p;
+    }
+    uint32_t *tab = tabs[st];
+    Scalar k;
+    scalar_from_be(k, key_be);
+    if (!scalar_is_valid(k)) return 0;
+    const u32 nw = ec_signed_windows((u32)st);
+    u32 carry = 0;
+    for (u32 w = 0; w < nw; w++) {
+        const u32 v = ec_wide_digit(k.w, w, (u32)st) + carry;
+        const bool neg = v > (1u << (st - 1));
+        const u32 m = neg ? (1u << st) - v : v;
+        carry = neg ? 1u : 0u;
+        if (!m) continue;
+        // scalar m * 2^(st w), as 9 words; exactly 2^256 -> 2^256 - n
+        const u32 bit = (u32)st * w;
+        uint32_t e9[10] = {0};
+        const unsigned long long lo = (unsigned long long)m << (bit & 31u);
+        e9[bit >> 5] = (uint32_t)lo;
+        e9[(bit >> 5) + 1] = (uint32_t)(lo >> 32);
+        Scalar e;
+        for (int i = 0; i < 8; i++) e.w[i] = e9[i];
+        if (e9[8]) {
+            if (e9[8] != 1) return -1;
+            for (int i = 0; i < 8; i++) if (e9[i]) return -1;
+            static const uint32_t r[8] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u, 0, 0, 0};
+            for (int i = 0; i < 8; i++) e.w[i] = r[i];
+        }
+        ge p;
+        if (!host_ec_mul_gen(e, p)) return 0;
+        uint32_t *o = tab + ((size_t)w * ec_signed_per((u32)st) + (m - 1)) * 16;
+        fe_to_words(p.x, o);
+        fe_to_words(p.y, o + 8);
+    }
+    if (carry) return -1;   // cannot happen for k < 2^256
+    gej acc;
+    if (st == 25) ec_mul_gen_signed<25>(acc, k.w, tab);
+    else if (st == 27) ec_mul_gen_signed<27>(acc, k.w, tab);
+    else ec_mul_gen_signed<29>(acc, k.w, tab);
+    ge r;
+    if (!ge_from_gej(r, acc)) return 0;
+    u32 wv[8];
+    fe_to_words(r.x, wv);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[4 * (7 - i) + j] = (unsigned char)(wv[i] >> (24 - 8 * j));
+    fe_to_words(r.y, wv);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) xy[32 + 4 * (7 - i) + j] = (unsigned char)(wv[i] >> (24 - 8 * j));
+    return 1;
+}
+}
+

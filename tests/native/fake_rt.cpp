@@ -473,6 +473,7 @@ int rt_frame_clock(vgen_ctx *, uint32_t, uint32_t *cycles, uint32_t *ticks) {
 }
 int rt_clock_probe_start(vgen_ctx *c, uint32_t) { return c->fail(VGEN_E_UNSUPPORTED, "fake runtime: no clock probe"); }
 int rt_clock_probe_read(vgen_ctx *c, double *) { return c->fail(VGEN_E_UNSUPPORTED, "fake runtime: no clock probe"); }
+void rt_prefer_table_bits(vgen_ctx *c, uint32_t bits) { c->gtab_bits_pref = bits; }   // (the stand-in multiplies on the host: nothing to build)
 int rt_get_resources(const vgen_ctx *c, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note) {
     if (dump_frames) *dump_frames = c->dump_frames ? c->dump_frames : c->frames;
     if (table_bits) *table_bits = 0;      // (the stand-in multiplies on the host: no generator table)

@@ -876,24 +876,48 @@ def test_permissive_pattern_grows_the_match_ring_instead_of_dumping(vg, vo):
     r.close()
 
 
-@pytest.mark.parametrize("bits", [8, 16, 20, 22, 24, 26])
+# (29 bits: a 138 GB table — part of the full suite: VGEN_TEST_FULL=1)
+TABLE_WIDTHS = [8, 16, 20, 22, 24, 26, 25, 27] + ([29] if os.environ.get("VGEN_TEST_FULL") == "1" else [])
+
+
+@pytest.mark.parametrize("bits", TABLE_WIDTHS)
 def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypatch):
     """The arbitrary-scalar and taproot paths multiply through a fixed-window table of VGEN_GTAB_BITS-bit windows
     (8: the host-built 653 KB table; 16 / 20 / 22 / 24: built on the device from it, every entry as the sum of two
     entries of a table of half the width).  Every width must reproduce the oracle: explicit scalars incl. the
     extremes, one-digit scalars that hit the special entries of the two-level build in every window (low half zero,
-    high half zero, all ones, group boundaries), and the P2TR tweak multiplication."""
+    high half zero, all ones, group boundaries), and the P2TR tweak multiplication.  Odd widths (25 / 27 / 29) are SIGNED windows
+    (core/ec.h: ec_mul_gen_signed — a table of magnitudes, negative digits take (x, p - y); 29 bits: 8 additions, 138 GB): their
+    scalars also walk the sign threshold, carries rippling through all-ones windows and the top window's magnitude that stands
+    for the scalar 2^256 itself."""
     monkeypatch.setenv("VGEN_GTAB_BITS", str(bits))
     import random
     rng = random.Random(bits)
     keys = [1, 2, N - 1, N - 2, 2**255, 0xFFFF, 0x10000, (1 << 200) + 5, (2**22 - 1) << 220, 2**256 - 1, 0, N] + [rng.randrange(1, N) for _ in range(500)]
-    h = bits // 2
-    for w in range((256 + bits - 1) // bits):
-        for digit in (1, 7, 8, 9, 2**h - 1, 2**h, 2**h + 1, (2**h - 1) << h, 3 << h, 2**bits - 8, 2**bits - 1, rng.randrange(1, 2**bits)):
-            k = digit << (w * bits)
-            if 0 < k < N:
-                keys.append(k)
-                keys.append((k + rng.randrange(1, N)) % N or 1)      # the same digit among random ones: carries do not matter, digits are independent
+    if bits % 2:
+        st, half, nw = bits, 1 << (bits - 1), -(-257 // bits)
+        h = (st - 1) // 2
+        for w in range(nw):
+            for digit in (1, 7, 8, 9, 2**h - 1, 2**h, 2**h + 1, (2**h - 1) << h, 3 << h, half - 8, half - 1, half, half + 1, half + 2**h, 2**st - 9,
+                          2**st - 1, rng.randrange(1, 2**st)):
+                k = digit << (w * st)
+                if 0 < k < N:
+                    keys.append(k)
+                    keys.append((k + rng.randrange(1, N)) % N or 1)
+        for w in range(1, nw):
+            keys.append((1 << (st * w)) - 1)                                   # all ones below window w: the carry ripples up to it
+        top = st * (nw - 1)
+        keys.append((1 << 256) - (1 << top) + (half + 1) * (1 << (top - st)) + 5)     # top magnitude 2^(256 - top): the scalar 2^256, mod n
+        keys.append((1 << 256) - (1 << top) + ((1 << st) - 1) * (1 << (top - st)))
+    else:
+        h = bits // 2
+        for w in range((256 + bits - 1) // bits):
+            for digit in (1, 7, 8, 9, 2**h - 1, 2**h, 2**h + 1, (2**h - 1) << h, 3 << h, 2**bits - 8, 2**bits - 1, rng.randrange(1, 2**bits)):
+                k = digit << (w * bits)
+                if 0 < k < N:
+                    keys.append(k)
+                    keys.append((k + rng.randrange(1, N)) % N or 1)      # the same digit among random ones: carries do not matter, digits are independent
+    keys = [k for k in keys if k < 2**256]
     r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh)
     r.set_filter(None)
     r.dispatch_keys(keys, 0)
@@ -902,6 +926,7 @@ def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypat
     for i, k in enumerate(keys):
         want = vo.payload(0, k) if 0 < k < N else bytes(20)
         assert blob[20 * i:20 * i + 20] == want, (bits, hex(k))
+    assert r.resources()["table_bits"] == bits and r.resources()["note"] == ""      # the width asked for is the width in use
     r.close()
     r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2tr)
     start = vo.seed_key(bits, 3)
@@ -1426,6 +1451,42 @@ def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vgh, vo, monk
     cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgen_amd", "vgen-hip")
     s = subprocess.run([cli, "generate", "-f", "p2tr", "-p", "^bc1pq", "-o", "minimal", "--seed", "5"], capture_output=True, text=True, timeout=120)
     assert s.returncode == 0 and "Warning: device" not in s.stderr and s.stdout == p.stdout
+
+
+def test_scan_picks_the_generator_table_its_expected_length_pays_for(vg, vo):
+    """vgen_scan on the paths that multiply a scalar per key chooses the table by the keys it can expect to test: the default
+    24-bit table for short scans, the 27-bit signed one (9 additions, 60 ms to make) from ~5 s, the 29-bit signed one (8 additions,
+    138 GB, 2.3 s) from a minute — and a context never steps back down by itself.  Results stay the oracle's either way."""
+    import ctypes
+    import threading
+    fmt = vg.AddressFormat.P2tr
+    batch = 8192
+
+    def run(r, start, span, seconds=0.25):
+        stop = ctypes.c_int32(0)
+        t = threading.Timer(seconds, lambda: setattr(stop, "value", 1))
+        t.start()
+        res = vg.scan_gpu_with_runner("^bc1pq[qp]", vg.ScanConfig(format=fmt, count=None, start=start, end=start + span - 1), r, stop=stop)
+        t.cancel()
+        return res
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, frames=2)
+    start = vo.seed_key(31, 3)
+    res = run(r, start, 4 * batch, seconds=5)                 # 32 768 keys: microseconds of work -> the default table
+    assert res.complete and r.resources()["table_bits"] == 24 and r.resources()["table_bits_wanted"] == 24
+    want = [x["address"] for x in vo.scan_range(3, "^bc1pq[qp]", start, start + 4 * batch - 1, count=10**9)["matches"]]
+    assert [m.address for m in res.matches] == want and len(want) > 10
+    res = run(r, start, 2**33)                                # 8.6 G keys = ~6 s at 1.35 Gkeys/s -> 27 bits, signed
+    assert r.resources()["table_bits"] == 27 and res.operations >= batch
+    for m in res.matches[:40]:
+        assert vo.generate(3, int(m.hex, 16))["address"] == m.address
+    res = run(r, start, 2**40)                                # ~13 minutes of keys -> 29 bits, signed (138 GB)
+    rs = r.resources()
+    assert rs["table_bits"] == 29 and rs["table_bits_wanted"] == 29 and rs["note"] == "" and res.operations >= batch
+    for m in res.matches[:40]:
+        assert vo.generate(3, int(m.hex, 16))["address"] == m.address
+    res = run(r, start, 4 * batch, seconds=5)                 # a short scan afterwards keeps the wide table: no stepping down
+    assert r.resources()["table_bits"] == 29 and [m.address for m in res.matches] == want
+    r.close()
 
 
 def test_contexts_on_one_device_share_the_wide_generator_table(vg, vo):

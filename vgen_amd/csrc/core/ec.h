@@ -323,6 +323,67 @@ VG_HD void ec_mul_gen_wide(gej &acc, const u32 k[8], const u32 *tab) {
     }
 }
 
+// ---- signed windows: every entry serves a digit AND its negation -----------------------------------------------------------
+// With 288 GB of HBM per device the table can be wider still.  Windows of ST bits (ST odd: 25 | 27 | 29); the raw ST-bit
+// digit v (plus the carry of the window below) is recoded to d = v or d = v - 2^ST (carrying 1 up) so that |d| <= 2^(ST-1);
+// the table holds m * 2^(ST w) * G for the MAGNITUDES m = 1 .. 2^(ST-1) and a negative digit takes (x, p - y).  One more
+// bit (the last carry) makes it NW = ceil(257 / ST) windows:
+//     29 bits:  9 windows =  8 additions, 138 GB        27 bits: 10 windows = 9 additions (the unsigned 26-bit table's count)
+//     25 bits: 11 windows = 10 additions,  5.9 GB       in 21.5 GB instead of 43
+// The partial sum of the windows below w is smaller in magnitude than any non-zero addend of window w, so the branch-free
+// mixed addition still never meets P = +/-Q.  The top window is short (its raw digit has 256 - ST (NW - 1) bits) and its
+// part of the table is sized for that; its largest magnitude, 2^(256 - ST (NW - 1)), stands for the scalar 2^256 itself,
+// which the table builder takes mod n (kernels.hip: gen_small_signed_kernel).
+VG_HD constexpr bool ec_table_signed(u32 bits) { return (bits & 1u) != 0u; }
+VG_HD constexpr u32 ec_signed_windows(u32 st) { return (257u + st - 1u) / st; }
+VG_HD constexpr u64 ec_signed_per(u32 st) { return 1ull << (st - 1u); }                                  // magnitudes 1 .. 2^(st-1) per window
+VG_HD constexpr u32 ec_signed_top_bits(u32 st) { return 256u - st * (ec_signed_windows(st) - 1u); }      // raw bits of the top window
+VG_HD constexpr u64 ec_signed_top_per(u32 st) { return 1ull << ec_signed_top_bits(st); }                 // its magnitudes: 1 .. 2^top_bits
+VG_HD constexpr u64 ec_signed_entries(u32 st) { return (u64)(ec_signed_windows(st) - 1u) * ec_signed_per(st) + ec_signed_top_per(st); }
+VG_HD constexpr u32 ec_signed_half(u32 st) { return (st - 1u) / 2u; }                                    // the builder's half-width
+VG_HD constexpr u64 ec_signed_small_entries(u32 st) { return (u64)ec_signed_windows(st) * 2ull * (1ull << ec_signed_half(st)); }
+// table sizes for either kind of width (words)
+VG_HD constexpr u64 ec_table_words(u32 bits) { return ec_table_signed(bits) ? ec_signed_entries(bits) * 16ull : ec_wide_words(bits); }
+VG_HD constexpr u64 ec_table_small_words(u32 bits) {
+    return ec_table_signed(bits) ? ec_signed_small_entries(bits) * 16ull : ec_wide_words(bits / 2u);
+}
+
+template <int ST>
+VG_HD void ec_mul_gen_signed(gej &acc, const u32 k[8], const u32 *tab) {
+    static_assert(ST == 25 || ST == 27 || ST == 29, "signed window stride");
+    constexpr u32 NW = ec_signed_windows(ST);
+    constexpr u64 PER = ec_signed_per(ST);
+    gej_set_infinity(acc);
+    u32 carry = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (u32 w = 0; w < NW; w++) {
+        const u32 v = ec_wide_digit(k, w, ST) + carry;           // <= 2^ST
+        const bool neg = v > (1u << (ST - 1));
+        const u32 m = neg ? (1u << ST) - v : v;                  // magnitude 0 .. 2^(ST-1)
+        carry = neg ? 1u : 0u;
+        const u32 e = (m ? m : 1u) - 1u;
+        const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(tab + ((u64)w * PER + e) * 16ull);
+        u32 raw[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const ec_u4 t4 = e4[q];
+#pragma unroll
+            for (int i = 0; i < 4; i++) raw[4 * q + i] = t4.v[i];
+        }
+        ge t;
+        fe ny;
+        fe_from_words(t.x, raw);
+        fe_from_words(t.y, raw + 8);
+        fe_neg(ny, t.y, 1);
+        fe_normalize_weak(ny);                                   // p - y, magnitude 1
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.y.n[i] = neg ? ny.n[i] : t.y.n[i];
+        ec_fixed_accumulate(acc, t, m);
+    }
+}
+
 constexpr u32 EC_TABLE16_ENTRIES = 16u * 65535u;
 constexpr u32 EC_TABLE16_WORDS = EC_TABLE16_ENTRIES * 16u;
 VG_HD void ec_mul_gen_w16(gej &acc, const u32 k[8], const u32 *tab16) { ec_mul_gen_wide<16>(acc, k, tab16); }
@@ -339,6 +400,9 @@ VG_HD void ec_mul_gen_tables(gej &acc, const u32 k[8], const GenTables &g) {
     else if (g.wide && g.wide_bits == 22) ec_mul_gen_wide<22>(acc, k, g.wide);
     else if (g.wide && g.wide_bits == 24) ec_mul_gen_wide<24>(acc, k, g.wide);
     else if (g.wide && g.wide_bits == 26) ec_mul_gen_wide<26>(acc, k, g.wide);
+    else if (g.wide && g.wide_bits == 25) ec_mul_gen_signed<25>(acc, k, g.wide);
+    else if (g.wide && g.wide_bits == 27) ec_mul_gen_signed<27>(acc, k, g.wide);
+    else if (g.wide && g.wide_bits == 29) ec_mul_gen_signed<29>(acc, k, g.wide);
     else ec_mul_gen_w8(acc, k, g.w8);
 }
 

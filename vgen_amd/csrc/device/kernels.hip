@@ -1250,8 +1250,191 @@ __global__ void __launch_bounds__(256) gen_table_combine_kernel(const u32 *small
     }
 }
 
-// tab: the wide table (ec_wide_words(bits) words); small: scratch for the half-width table (ec_wide_words(bits / 2) words).
+// ---- the signed-window tables (core/ec.h: ec_mul_gen_signed) --------------------------------------------------------------
+// Same two levels.  Half-width table: for window w two half-windows of 2^h entries (h = (ST - 1) / 2):
+//     small[2w][m]     = m * 2^(ST w)     * G         small[2w + 1][m] = m * 2^(ST w + h) * G        m = 1 .. 2^h
+// (one lane per entry: 8-bit multiplication + own inversion); wide entry (w, m), m = 1 .. 2^(ST-1), = small[2w][m_lo] +
+// small[2w+1][m_hi] with m = m_lo + 2^h m_hi — m_hi reaches 2^h for the one magnitude 2^(ST-1), which is why the half-windows
+// have 2^h entries and not 2^h - 1.  Entries whose scalar would pass 2^256 are never addressed and stay unwritten — except
+// the scalar 2^256 ITSELF (the top window's largest magnitude: a raw top digit of all ones plus a carry from below, e.g.
+// k = 2^256 - 2^232 + 2^231 + 2^203 + 5 < n at 29 bits), which is taken mod n: 2^256 - n.
+__device__ __forceinline__ bool signed_entry_scalar(u32 m, u32 bit, u32 k[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) k[i] = 0;
+    const u32 len = 32u - (u32)__clz(m);
+    if (bit + len <= 256u) {
+        const u32 i0 = bit >> 5, sh = bit & 31u;
+        const unsigned long long lo = (unsigned long long)m << sh;     // m < 2^29 (the top entry 2^28 << 31 fits 64 bits)
+        k[i0] = (u32)lo;
+        if (i0 + 1 < 8) k[i0 + 1] = (u32)(lo >> 32);
+        return true;
+    }
+    if (bit + len == 257u && (m & (m - 1u)) == 0u) {   // m * 2^bit == 2^256  ->  2^256 mod n
+        k[0] = 0x2FC9BEBFu; k[1] = 0x402DA173u; k[2] = 0x50B75FC4u; k[3] = 0x45512319u; k[4] = 1u;
+        return true;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256) gen_small_signed_kernel(const u32 *tab8, u32 *small, u32 st, unsigned long long entries) {
+    const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= entries) return;
+    const u32 h = (st - 1u) / 2u;
+    const u32 hw = (u32)(idx >> h), m = (u32)(idx & ((1ull << h) - 1ull)) + 1u;      // half-window, magnitude 1 .. 2^h
+    const u32 bit = st * (hw >> 1) + h * (hw & 1u);
+    u32 k[9];
+    if (!signed_entry_scalar(m, bit, k)) return;
+    gej p;
+    ec_mul_gen_w8(p, k, tab8);
+    fe zi, zi2, zi3, x, y;
+    fe_inv(zi, p.z);
+    fe_sqr(zi2, zi);
+    fe_mul(zi3, zi2, zi);
+    fe_mul(x, p.x, zi2);
+    fe_mul(y, p.y, zi3);
+    fe_canonicalize_product(x);
+    fe_canonicalize_product(y);
+    u32 xw[8], yw[8];
+    fe_to_words(x, xw);
+    fe_to_words(y, yw);
+    ec_u4 *o = reinterpret_cast<ec_u4 *>(small + idx * 16ull);
+    o[0] = ec_u4{{xw[0], xw[1], xw[2], xw[3]}};
+    o[1] = ec_u4{{xw[4], xw[5], xw[6], xw[7]}};
+    o[2] = ec_u4{{yw[0], yw[1], yw[2], yw[3]}};
+    o[3] = ec_u4{{yw[4], yw[5], yw[6], yw[7]}};
+}
+
+// groups of GT_K consecutive magnitudes m0 + 1 .. m0 + GT_K of one window (same m_hi for all but the group's last magnitude
+// when that is a multiple of 2^h — handled by looking m_hi up per magnitude), one shared inversion per lane.
+__global__ void __launch_bounds__(256) gen_combine_signed_kernel(const u32 *small, u32 *tab, u32 st, unsigned long long groups) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const u32 h = (st - 1u) / 2u, nw = ec_signed_windows(st);
+    const unsigned long long per = ec_signed_per(st), per_h = 1ull << h, top_per = ec_signed_top_per(st);
+    const unsigned long long full_groups = per / GT_K;                 // per window 0 .. nw-2
+    u32 w;
+    unsigned long long gi;
+    if (g < (unsigned long long)(nw - 1u) * full_groups) {
+        w = (u32)(g / full_groups);
+        gi = g % full_groups;
+    } else {
+        w = nw - 1u;
+        gi = g - (unsigned long long)(nw - 1u) * full_groups;
+    }
+    const unsigned long long limit = w == nw - 1u ? top_per : per;     // magnitudes 1 .. limit
+    const u32 m0 = (u32)(gi * GT_K);                                   // this lane: magnitudes m0 + 1 .. m0 + GT_K
+    const u32 bit = st * w;
+    const u32 *win_lo = small + (unsigned long long)(2u * w) * per_h * 16ull;
+    const u32 *win_hi = small + (unsigned long long)(2u * w + 1u) * per_h * 16ull;
+    auto load_words = [](const u32 *ent, u32 xw[8], u32 yw[8]) {
+        const ec_u4 *e4 = reinterpret_cast<const ec_u4 *>(ent);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const ec_u4 a = e4[q], b = e4[2 + q];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xw[4 * q + i] = a.v[i];
+                yw[4 * q + i] = b.v[i];
+            }
+        }
+    };
+    // is magnitude m an entry of this window (its scalar m * 2^bit at most 2^256)?
+    auto valid = [&](u32 m) {
+        if (m == 0 || m > limit) return false;
+        const u32 len = 32u - (u32)__clz(m);
+        return bit + len <= 256u || (bit + len == 257u && (m & (m - 1u)) == 0u);
+    };
+    fe pre[GT_K];
+    fe acc;
+    // forward: prefix products of the denominators (1 where no addition is needed: m_lo == 0 or m_hi == 0 or not an entry)
+#pragma unroll
+    for (int j = 0; j < GT_K; j++) {
+        const u32 m = m0 + 1u + (u32)j, m_lo = m & (u32)(per_h - 1ull), m_hi = m >> h;
+        const bool add = valid(m) && m_lo != 0 && m_hi != 0;
+        fe dx;
+        fe_set_one(dx);
+        if (add) {
+            u32 xw[8], yw[8], hx[8], hy[8];
+            load_words(win_lo + (unsigned long long)(m_lo - 1u) * 16ull, xw, yw);
+            load_words(win_hi + (unsigned long long)(m_hi - 1u) * 16ull, hx, hy);
+            fe lx, hxf;
+            fe_from_words(lx, xw);
+            fe_from_words(hxf, hx);
+            fe_sub_n(dx, lx, hxf);
+        }
+        if (j == 0) acc = dx;
+        else fe_mul(acc, acc, dx);
+        pre[j] = acc;
+    }
+    fe inv;
+    fe_inv(inv, acc);
+#pragma unroll
+    for (int j = GT_K - 1; j >= 0; j--) {
+        const u32 m = m0 + 1u + (u32)j, m_lo = m & (u32)(per_h - 1ull), m_hi = m >> h;
+        const bool ok = valid(m);
+        const bool add = ok && m_lo != 0 && m_hi != 0;
+        u32 xw[8], yw[8], hxw[8], hyw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) xw[i] = yw[i] = hxw[i] = hyw[i] = 0;
+        if (ok && m_lo != 0) load_words(win_lo + (unsigned long long)(m_lo - 1u) * 16ull, xw, yw);
+        if (ok && m_hi != 0) load_words(win_hi + (unsigned long long)(m_hi - 1u) * 16ull, hxw, hyw);
+        fe lx, ly, hx, hy, dx;
+        fe_from_words(lx, xw);
+        fe_from_words(ly, yw);
+        fe_from_words(hx, hxw);
+        fe_from_words(hy, hyw);
+        fe_set_one(dx);
+        if (add) fe_sub_n(dx, lx, hx);
+        fe idx;
+        if (j > 0) {
+            fe_mul(idx, inv, pre[j - 1]);
+            fe_mul(inv, inv, dx);
+        } else {
+            idx = inv;
+        }
+        if (!ok) continue;
+        u32 oxw[8], oyw[8];
+        if (add) {
+            fe dy, lam, x3, t, y3;
+            fe_sub_n(dy, ly, hy);
+            fe_mul(lam, dy, idx);
+            fe_sqr(x3, lam);
+            fe_sub_n(x3, x3, lx);
+            fe_sub_n(x3, x3, hx);
+            fe_sub_n(t, lx, x3);
+            fe_mul(y3, lam, t);
+            fe_sub_n(y3, y3, ly);
+            fe_canonicalize(x3);
+            fe_canonicalize(y3);
+            fe_to_words(x3, oxw);
+            fe_to_words(y3, oyw);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                oxw[i] = m_lo != 0 ? xw[i] : hxw[i];     // m_hi == 0: the low entry itself; m_lo == 0: the high one
+                oyw[i] = m_lo != 0 ? yw[i] : hyw[i];
+            }
+        }
+        const unsigned long long base = (unsigned long long)w * per;    // (every window below the top one is full)
+        ec_u4 *o = reinterpret_cast<ec_u4 *>(tab + (base + (m - 1u)) * 16ull);
+        o[0] = ec_u4{{oxw[0], oxw[1], oxw[2], oxw[3]}};
+        o[1] = ec_u4{{oxw[4], oxw[5], oxw[6], oxw[7]}};
+        o[2] = ec_u4{{oyw[0], oyw[1], oyw[2], oyw[3]}};
+        o[3] = ec_u4{{oyw[4], oyw[5], oyw[6], oyw[7]}};
+    }
+}
+
+// tab: the wide table (ec_table_words(bits) words); small: scratch for the half-width table (ec_table_small_words(bits) words).
 hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 *small, u32 bits, hipStream_t stream) {
+    if (bits == 25 || bits == 27 || bits == 29) {
+        const unsigned long long small_entries = ec_signed_small_entries(bits);
+        hipLaunchKernelGGL(gen_small_signed_kernel, dim3((unsigned)((small_entries + 255) / 256)), dim3(256), 0, stream, tab8, small, bits, small_entries);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const unsigned long long groups = (unsigned long long)(ec_signed_windows(bits) - 1u) * (ec_signed_per(bits) / GT_K) + ec_signed_top_per(bits) / GT_K;
+        hipLaunchKernelGGL(gen_combine_signed_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, small, tab, bits, groups);
+        return hipGetLastError();
+    }
     if (bits != 16 && bits != 20 && bits != 22 && bits != 24 && bits != 26) return hipErrorInvalidValue;
     const u32 h = bits / 2;
     const unsigned long long small_entries = ec_wide_entries(h);

@@ -27,8 +27,9 @@ hipError_t launch_p2tr_tweak(const KeysArgs &a, hipStream_t stream);
 // Fills a key buffer (n x 32 bytes, big-endian) with candidates first_index .. first_index + n - 1 of stream `stream` under
 // `seed` of the counter-based scalar stream (core/rnd.h): the random-key mode's scalars, drawn on the device.
 hipError_t launch_rnd_fill(uint8_t *keys_be, uint32_t n, const RndSeed &seed, uint32_t stream, unsigned long long first_index, hipStream_t st);
-// Builds the wide fixed-window generator table (bits = 16 | 20 | 22 | 24; ec_wide_words(bits) words, core/ec.h) from the
-// 8-bit one, through a table of half the width (`small`: ec_wide_words(bits / 2) words of scratch).
+// Builds the wide fixed-window generator table (bits = 16 | 20 | 22 | 24 | 26 unsigned windows, 25 | 27 | 29 signed ones;
+// ec_table_words(bits) words, core/ec.h) from the 8-bit one, through a table of half the width (`small`:
+// ec_table_small_words(bits) words of scratch).
 hipError_t launch_gen_table_wide(const uint32_t *tab8, uint32_t *tab, uint32_t *small, uint32_t bits, hipStream_t stream);
 // Builds the sequential path's offset table on the device: rtab[(i) * lanes + u] / rtab[(9 + i) * lanes + u] = limb i of
 // x / y of base + u * step (a.pw[b] = 2^b * step).  No pair (partial sum, summand) is exceptional as long as base is not a

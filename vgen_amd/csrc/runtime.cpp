@@ -659,10 +659,25 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
     // 6 ms; 24 bits 1362, 19 ms; 26 bits (43 GB, 9 additions) 1451, but its first hipMalloc takes ~1 s and the gathers begin
     // to show (VALU-busy 0.97).  The paths are issue-bound (profiles/pmc_keys.json), so the rate follows the additions saved.
     // VGEN_GTAB_BITS = 8 | 16 | 20 | 22 | 24 | 26 selects.
+    const uint32_t want_now = env_u32("VGEN_GTAB_BITS", c->gtab_bits_pref ? c->gtab_bits_pref : 24);
+    // additions per multiplication of a width: what "wider" means across signed and unsigned tables
+    auto additions = [](uint32_t b) { return ec_table_signed(b) ? ec_signed_windows(b) - 1u : ec_wide_windows(b) - 1u; };
+    if (wide && c->d_gtab16 && c->gtab_bits != want_now && c->gtab_bits_wanted != want_now &&
+        (getenv("VGEN_GTAB_BITS") != nullptr || additions(want_now) < additions(c->gtab_bits))) {
+        // a WIDER table is wanted than the one in use (the scan loop's preference for a longer scan; a context never steps back down
+        // by itself): switch while no frame holds the old table's address in a launched kernel
+        bool busy = false;
+        for (auto &f : c->fr) busy = busy || f.in_flight;
+        if (!busy) {
+            release_gtab(c);
+            c->gtab_wide_failed = false;
+            c->gtab_note.clear();
+        }
+    }
     if (wide && !c->d_gtab16 && !c->gtab_wide_failed) {
-        const uint32_t want = env_u32("VGEN_GTAB_BITS", 24);
-        if (want != 8 && want != 16 && want != 20 && want != 22 && want != 24 && want != 26)
-            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22, 24 or 26");
+        const uint32_t want = want_now;
+        if (want != 8 && want != 16 && want != 20 && want != 22 && want != 24 && want != 26 && want != 25 && want != 27 && want != 29)
+            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22, 24 or 26 (unsigned windows) or 25, 27 or 29 (signed windows)");
         c->gtab_bits_wanted = want;
         if (want == 8) {
             c->gtab_wide_failed = true;   // (asked for: nothing to build)
@@ -674,12 +689,14 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
 #else
         const uint32_t hook_fail_from = 0;
 #endif
-        static const uint32_t widths[] = {26, 24, 22, 20, 16};
+        // by additions per multiplication: 29 signed (8; 138 GB) | 27 signed, 26 (9; 21.5 / 43 GB) | 25 signed, 24 (10; 5.9 / 11.8 GB) | 22 | 20 | 16.
+        // A signed width is only ever tried when it was asked for; stepping down goes through the unsigned ones below it.
+        static const uint32_t widths[] = {29, 27, 26, 25, 24, 22, 20, 16};
         GtabCache &g = gtab_cache();
         std::lock_guard<std::mutex> lk(g.mu);
         std::string why;
         for (uint32_t bits : widths) {
-            if (bits > want) continue;
+            if (bits > want || (ec_table_signed(bits) && bits != want)) continue;
             // somebody on this device has it already
             bool shared = false;
             for (GtabShared &t : g.tabs)
@@ -693,8 +710,8 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
             if (shared) break;
             uint32_t *wide_tab = nullptr, *small = nullptr;   // small: the half-width table the wide one is combined from
             hipError_t e = hook_fail_from && bits >= hook_fail_from ? hipErrorOutOfMemory
-                                                                    : hipMalloc((void **)&wide_tab, (size_t)ec_wide_words(bits) * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_wide_words(bits / 2) * sizeof(uint32_t));
+                                                                    : hipMalloc((void **)&wide_tab, (size_t)ec_table_words(bits) * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_table_small_words(bits) * sizeof(uint32_t));
             lap("hipMalloc wide + scratch");
             hipStream_t st0 = nullptr;
             if (e == hipSuccess && frame_stream(c, 0, &st0) != VGEN_OK) e = hipErrorUnknown;
@@ -1045,12 +1062,16 @@ int rt_read_dump(vgen_ctx *c, uint32_t frame, uint8_t *out, size_t out_len) {
     return VGEN_OK;
 }
 
+void rt_prefer_table_bits(vgen_ctx *c, uint32_t bits) {
+    if (bits == 0 || bits == 16 || bits == 20 || bits == 22 || bits == 24 || bits == 26 || bits == 25 || bits == 27 || bits == 29) c->gtab_bits_pref = bits;
+}
+
 // What dump mode and the scalar-multiplication paths have (or will get) of what they ask for: vgen_get_resources.
 int rt_get_resources(const vgen_ctx *c, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note) {
     if (dump_frames) *dump_frames = dump_frames_for(c);
     // 0 = no generator table yet (no P2TR / arbitrary-scalar dispatch so far); 8 = the 8-bit table only
     if (table_bits) *table_bits = c->d_gtab16 ? c->gtab_bits : c->d_gtab ? 8u : 0u;
-    if (table_bits_wanted) *table_bits_wanted = c->gtab_bits_wanted ? c->gtab_bits_wanted : env_u32("VGEN_GTAB_BITS", 24);
+    if (table_bits_wanted) *table_bits_wanted = c->gtab_bits_wanted ? c->gtab_bits_wanted : env_u32("VGEN_GTAB_BITS", c->gtab_bits_pref ? c->gtab_bits_pref : 24);
     if (note) *note = c->gtab_note;
     return VGEN_OK;
 }

@@ -34,7 +34,8 @@ struct vgen_ctx {
     uint32_t *d_gtab16 = nullptr;        // wide fixed-window generator table (gtab_bits bits): built on the device from d_gtab at first use and
                                          // SHARED by the process's contexts on this device (runtime.cpp: GtabCache; a reference, not owned)
     uint32_t gtab_bits = 0;              // width of d_gtab16
-    uint32_t gtab_bits_wanted = 0;       // width asked for (VGEN_GTAB_BITS, default 24) once a dispatch wanted a wide table
+    uint32_t gtab_bits_wanted = 0;       // width asked for (VGEN_GTAB_BITS, else gtab_bits_pref, else 24) once a dispatch wanted a wide table
+    uint32_t gtab_bits_pref = 0;         // the scan loop's choice for this scan (rt_prefer_table_bits): wider tables pay off on long scans
     bool gtab_wide_failed = false;       // no wide table could be had (or VGEN_GTAB_BITS=8): stay on the 8-bit one
     std::string gtab_note;               // why the table in use is narrower than the one asked for (vgen_get_resources)
     vg::DevFilter *d_filter = nullptr;   // current device filter program
@@ -148,6 +149,11 @@ int rt_frame_times(vgen_ctx *ctx, uint32_t frame, float *kernel_ms, float *total
 int rt_frame_clock(vgen_ctx *ctx, uint32_t frame, uint32_t *cycles, uint32_t *ticks);
 int rt_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
 int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);
+// The generator-table width the next scalar-multiplication dispatches should use when VGEN_GTAB_BITS does not say (0 = the default, 24).
+// A wider table costs more to make (24 bits: 11.8 GB, ~30 ms; 27 signed: 21.5 GB, ~60 ms; 29 signed: 138 GB, ~2.3 s) and saves additions on
+// every key after (10 / 9 / 8 per multiplication: +5 % / +12.5 %): the scan loop asks for what the expected length of the scan pays for.
+// Takes effect at the next dispatch that finds no frame of the context in flight.
+void rt_prefer_table_bits(vgen_ctx *ctx, uint32_t bits);
 int rt_get_resources(const vgen_ctx *ctx, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note);
 
 }  // namespace vg

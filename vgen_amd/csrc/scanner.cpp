@@ -515,6 +515,31 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     int rc = vgen_set_filter(ctx, host_all ? nullptr : &flt);
     if (rc != VGEN_OK) return rc;
 
+    // Scans that multiply a scalar per key (random keys, taproot): how wide a generator table is this scan worth?  The default
+    // 24-bit table (10 additions per multiplication) is there in 30 ms; the 27-bit signed one (9 additions, +5 %) in 60 ms and
+    // 21.5 GB; the 29-bit signed one (8 additions, +12.5 %) takes 2.3 s and 138 of the device's 288 GB (profiles/r04_gtab_signed.txt).
+    // From the keys the scan can expect to test — the range, max_batches, or count / the filter's selectivity — at the path's rate.
+    if (random_keys || ctx->format == VGF_P2TR) {
+        // (a count-limited scan whose pattern has no selectivity estimate — the whole DFA on the device — is taken for short)
+        double keys = cfg->count == UINT64_MAX ? 1e30 : 0.0;
+        if (!host_all && flt.selectivity > 0 && cfg->count != UINT64_MAX) keys = (double)cfg->count / flt.selectivity;
+        if (host_all && cfg->count != UINT64_MAX) keys = (double)cfg->count * 64.0;   // (nearly every key matches)
+        if (cfg->max_batches) keys = std::min(keys, (double)cfg->max_batches * keys_per_dispatch);
+        if (cfg->has_end && cfg->has_start) {
+            Scalar a, b;
+            scalar_from_be(a, cfg->start);
+            scalar_from_be(b, cfg->end);
+            bool small = true;     // the range fits 64 bits of distance?
+            for (int i = 2; i < 8; i++) small = small && a.w[i] == b.w[i];
+            if (small) {
+                const uint64_t lo = (uint64_t)a.w[1] << 32 | a.w[0], hi = (uint64_t)b.w[1] << 32 | b.w[0];
+                if (hi >= lo) keys = std::min(keys, (double)(hi - lo) + 1.0);
+            }
+        }
+        const double seconds = keys / (random_keys && ctx->endo ? 5.5e9 : 1.35e9) / (double)shards;
+        rt_prefer_table_bits(ctx, seconds >= 60.0 ? 29u : seconds >= 5.0 ? 27u : 0u);
+    }
+
     // independent random keys: candidate index = batch number x N within stream `shard` of the seed
     // (the seed of the whole scan when the caller resolved one — all shards of a multi-device scan and a resumed checkpoint
     //  share it —, else this call's own)
