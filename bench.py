@@ -361,8 +361,8 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, en
 
 def wide_table_configs(vg, batch, frames, device, seconds):
     """The scalar-multiplication paths over the 29-bit SIGNED-window generator table (8 additions per multiplication instead of the
-    24-bit table's 10; 138 of the device's 288 GB; 2.3 s to allocate and build): what vgen_scan selects by itself for scans it
-    expects to run a minute or more (scanner.cpp), forced here through VGEN_GTAB_BITS for the length of the leg."""
+    24-bit table's 10; 138 of the device's 288 GB; 0.7 - 2.3 s to allocate and build): what vgen_scan selects by itself for scans it
+    expects to run half a minute or more (scanner.cpp), forced here through VGEN_GTAB_BITS for the length of the leg."""
     old = os.environ.get("VGEN_GTAB_BITS")
     os.environ["VGEN_GTAB_BITS"] = "29"
     out = []

@@ -139,7 +139,7 @@ int vgen_get_topology(const vgen_ctx *ctx, uint32_t *streams, uint32_t *hw_queue
  *                       16 / 20 / 22 / 24 / 26 = the wide table in use (shared by all contexts of the process on this device);
  *                       odd values are SIGNED windows: 25 / 27 / 29 bits = 10 / 9 / 8 additions in 5.9 / 21.5 / 138 GB.
  *   *table_bits_wanted  the width asked for: VGEN_GTAB_BITS when set; else what vgen_scan chose for the scan's expected length
- *                       (>= 5 s of keys: 27, >= 60 s: 29; a context never steps back down by itself); else the default, 24.  *table_bits < *table_bits_wanted after a dispatch
+ *                       (>= 3 s of keys: 27, >= 30 s: 29; a context never steps back down by itself); else the default, 24.  *table_bits < *table_bits_wanted after a dispatch
  *                       means the allocation or build of the wider tables failed and the context stepped down (24 -> 22 ->
  *                       20 -> 16 -> 8): same keys, fewer per second (10 / 11 / 12 / 15 / 31 additions per multiplication).
  *   note                why it stepped down ("" when it did not), NUL-terminated, truncated to note_cap.

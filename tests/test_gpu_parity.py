@@ -1455,8 +1455,8 @@ def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vgh, vo, monk
 
 def test_scan_picks_the_generator_table_its_expected_length_pays_for(vg, vo):
     """vgen_scan on the paths that multiply a scalar per key chooses the table by the keys it can expect to test: the default
-    24-bit table for short scans, the 27-bit signed one (9 additions, 60 ms to make) from ~5 s, the 29-bit signed one (8 additions,
-    138 GB, 2.3 s) from a minute — and a context never steps back down by itself.  Results stay the oracle's either way."""
+    24-bit table for short scans, the 27-bit signed one (9 additions, 60 ms to make) from ~3 s, the 29-bit signed one (8 additions,
+    138 GB, 0.7 - 2.3 s) from 30 s — and a context never steps back down by itself.  Results stay the oracle's either way."""
     import ctypes
     import threading
     fmt = vg.AddressFormat.P2tr

@@ -150,7 +150,7 @@ int rt_frame_clock(vgen_ctx *ctx, uint32_t frame, uint32_t *cycles, uint32_t *ti
 int rt_clock_probe_start(vgen_ctx *ctx, uint32_t duration_ms);
 int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);
 // The generator-table width the next scalar-multiplication dispatches should use when VGEN_GTAB_BITS does not say (0 = the default, 24).
-// A wider table costs more to make (24 bits: 11.8 GB, ~30 ms; 27 signed: 21.5 GB, ~60 ms; 29 signed: 138 GB, ~2.3 s) and saves additions on
+// A wider table costs more to make (24 bits: 11.8 GB, ~30 ms; 27 signed: 21.5 GB, ~60 ms; 29 signed: 138 GB, 0.7 - 2.3 s) and saves additions on
 // every key after (10 / 9 / 8 per multiplication: +5 % / +12.5 %): the scan loop asks for what the expected length of the scan pays for.
 // Takes effect at the next dispatch that finds no frame of the context in flight.
 void rt_prefer_table_bits(vgen_ctx *ctx, uint32_t bits);

@@ -517,7 +517,8 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
 
     // Scans that multiply a scalar per key (random keys, taproot): how wide a generator table is this scan worth?  The default
     // 24-bit table (10 additions per multiplication) is there in 30 ms; the 27-bit signed one (9 additions, +5 %) in 60 ms and
-    // 21.5 GB; the 29-bit signed one (8 additions, +12.5 %) takes 2.3 s and 138 of the device's 288 GB (profiles/r04_gtab_signed.txt).
+    // 21.5 GB; the 29-bit signed one (8 additions, +12.5 %) takes 0.7 - 2.3 s and 138 of the device's 288 GB (profiles/r04_gtab_signed.txt):
+    // from 3 s of expected scanning the first pays for itself several times over, from 30 s the second.
     // From the keys the scan can expect to test — the range, max_batches, or count / the filter's selectivity — at the path's rate.
     if (random_keys || ctx->format == VGF_P2TR) {
         // (a count-limited scan whose pattern has no selectivity estimate — the whole DFA on the device — is taken for short)
@@ -537,7 +538,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             }
         }
         const double seconds = keys / (random_keys && ctx->endo ? 5.5e9 : 1.35e9) / (double)shards;
-        rt_prefer_table_bits(ctx, seconds >= 60.0 ? 29u : seconds >= 5.0 ? 27u : 0u);
+        rt_prefer_table_bits(ctx, seconds >= 30.0 ? 29u : seconds >= 3.0 ? 27u : 0u);
     }
 
     // independent random keys: candidate index = batch number x N within stream `shard` of the seed
