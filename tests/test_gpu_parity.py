@@ -1489,6 +1489,48 @@ def test_scan_picks_the_generator_table_its_expected_length_pays_for(vg, vo):
     r.close()
 
 
+def test_a_scan_that_turns_out_long_moves_to_the_wide_table_on_the_way(vg, vo):
+    """A taproot scan whose pattern gives the loop no estimate (the whole DFA on the device, a count it will not reach) starts on the
+    default table; after five seconds it drains its frames once, builds the 29-bit signed table and goes on — the matches from both
+    sides of the switch are the oracle's, in key order, none lost or doubled at the seam."""
+    import ctypes
+    import threading
+    fmt = vg.AddressFormat.P2tr
+    r = vg.GpuRunner(batch_size=1 << 18, fmt=fmt, frames=4)
+    pat = vg.Pattern("qqqqq", False, fmt)
+    assert pat.device_kind == 4
+    start = vo.seed_key(77, 7)
+    stop = ctypes.c_int32(0)
+    seen = []
+
+    def progress(ops):
+        seen.append((time.perf_counter(), ops, r.resources()["table_bits"]))
+    import time
+    t = threading.Timer(7.0, lambda: setattr(stop, "value", 1))
+    t.start()
+    res = vg.scan_gpu_with_runner("qqqqq", vg.ScanConfig(format=fmt, count=10**9, start=start), r, progress_cb=progress, stop=stop)
+    t.cancel()
+    widths = [w for _, _, w in seen]
+    assert widths[0] == 24 and widths[-1] == 29 and sorted(set(widths)) == [24, 29], sorted(set(widths))
+    switch = next(i for i, w in enumerate(widths) if w == 29)
+    assert seen[switch][1] - seen[switch - 1][1] == 1 << 18          # operations advance batch by batch across the seam
+    keys = [int(m.hex, 16) for m in res.matches]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys) and all(start <= k < start + res.operations for k in keys)
+    ops_at_switch = seen[switch - 1][1]
+    before = [k for k in keys if k < start + ops_at_switch]
+    after = [k for k in keys if k >= start + ops_at_switch]
+    assert len(before) > 50 and len(after) > 20, (len(before), len(after))
+    ore = vo.Regex("qqqqq", False)
+    for m in res.matches[::max(1, len(res.matches) // 150)] + res.matches[-20:]:
+        g = vo.generate(3, int(m.hex, 16))
+        assert g["address"] == m.address and ore.matches(m.address)
+    # nothing lost around the seam: the oracle's own scan of the two batches either side of it
+    lo = start + ops_at_switch - (1 << 18)
+    want = [x["key"] for x in vo.scan_range(3, "qqqqq", lo, lo + (2 << 18) - 1, count=10**9)["matches"]]
+    assert [k for k in keys if lo <= k < lo + (2 << 18)] == want
+    r.close()
+
+
 def test_contexts_on_one_device_share_the_wide_generator_table(vg, vo):
     """The wide table (11.8 GB at the default width) is built once per device and shared by the process's contexts there,
     reference-counted: a second context's first dispatch builds nothing, both compute the oracle's keys, and the table goes
