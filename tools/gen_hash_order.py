@@ -13,7 +13,7 @@ two chains' instruction lists.
   x2           two chains merged instruction by instruction (natural order each)
   x2_grouped   two chains, per round: both chains' rotates, both chains' booleans, both chains' adds
 
-usage: python tools/gen_hash_order.py   (writes tools/hash_order_gen.inc; committed, so the tool builds with hipcc alone)
+usage: python tools/gen_hash_order.py   (writes tools/hash_order_gen.inc — ~750 KB of generated code, not kept in the repository)
 Reference for the algorithms: src/shaders/sha256.wgsl:43-170, src/shaders/ripemd160.wgsl:10-100 (via core/hash.h)."""
 import os
 

@@ -5,6 +5,7 @@ import collections
 import os
 import re
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HALF = ("v_alignbit_b32", "v_add3_u32", "v_perm_b32", "v_lshl_or_b32", "v_lshl_add_u32", "v_and_or_b32", "v_or3_b32", "v_xad_u32", "v_bfe_u32")
@@ -12,6 +13,7 @@ HALF = ("v_alignbit_b32", "v_add3_u32", "v_perm_b32", "v_lshl_or_b32", "v_lshl_a
 
 def main():
     os.makedirs("/tmp/isa", exist_ok=True)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_hash_order.py")], stdout=subprocess.DEVNULL)   # (the .inc is generated)
     out = "/tmp/isa/ubench_hash_order.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "--cuda-device-only", "-S",
                            os.path.join(ROOT, "tools", "ubench_hash_order.hip"), "-o", out], stderr=subprocess.DEVNULL)

@@ -15,7 +15,8 @@
 //
 // Reported per variant and occupancy: G hash pairs/s, shader MHz, SIMD cycles per wave-hash-pair and, with the VALU
 // instruction count per pair read from the kernel's own ISA (tools/hash_order_census.py), cycles per instruction.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_hash_order.hip -o tools/ubench_hash_order
+// Build: python tools/gen_hash_order.py   (writes tools/hash_order_gen.inc: generated, not kept in the repository)
+//        hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_hash_order.hip -o tools/ubench_hash_order
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
