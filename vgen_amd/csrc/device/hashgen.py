@@ -1,0 +1,472 @@
+"""Generator of device/hash_blocks.inc: the address hashes of the scan kernels as scheduled gfx950 instruction blocks.
+
+Each hash160 of the path (SHA-256 of the serialized key followed by RIPEMD-160) is executed SYMBOLICALLY here: a value is a
+Python int when the padded message, the IVs or the round constants determine it, the name of a virtual register otherwise.
+Known values fold (the constant tail of the message schedule, the first rounds on the IV, K[r] + W[r] for constant W), so the
+emitted list is the floor of the computation: 6 rotates + 4 three-input booleans + 5 additions per SHA-256 round, 1 boolean
++ 2 rotates + 2 additions per RIPEMD-160 step.  The list is register-allocated by a linear scan (a pair lives in 28 VGPRs
+and one SGPR for literals) and written out as ONE `asm` statement per hash, so the order below IS the order the SIMD sees.
+
+Two things are decided here rather than by hipcc, both measured in the real kernels on the MI355X (DESIGN.md §4,
+profiles/r04_hash_blocks_ab.txt):
+  * the ORDER: the dependency order of the round functions.  hipcc interleaves rounds for instruction-level parallelism,
+    which a SIMD holding four waves does not need; spreading dependent neighbours apart (`spread`) changes nothing either.
+  * the YIELDS: an `s_nop 0` after every third VALU instruction.  The wave gives up one issue slot; with launches of
+    several frames resident on a SIMD (the scan's steady state) the slot goes to another wave's instruction and the chip
+    retires 5-6 % more keys per second (12.4 -> 13.1 Gkeys/s); one yield per 2..4 instructions is the plateau, a yield
+    after every instruction loses again.  A launch that has the chip to itself at ONE wave per SIMD (2^20 keys, frames = 1)
+    pays 4 cycles per yield instead (+17 % on seq_bwd_kernel's 110 us) - the price of tuning for the steady state.
+
+The same instruction lists run in Python (`evaluate`, `evaluate_allocated`) for the CPU test-suite: tests/test_hashgen.py
+checks them, before and after register allocation, against hashlib and the oracle.
+
+usage: python3 hashgen.py [--order natural|grouped] [--yield every:N|dep|none] [--window W --distance D] > hash_blocks.inc
+Algorithms restated from core/hash.h (reference: src/shaders/sha256.wgsl:43-170, src/shaders/ripemd160.wgsl:10-100)."""
+import sys
+
+M = 0xFFFFFFFF
+K = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+     0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+     0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+     0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+     0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+SHA_IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+RMD_IV = [0x67452301, 0xEFCDAB89, 0x98BADCFE, 0x10325476, 0xC3D2E1F0]
+RL = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 7, 4, 13, 1, 10, 6, 15, 3, 12, 0, 9, 5, 2, 14, 11, 8, 3, 10, 14, 4, 9, 15, 8, 1, 2, 7,
+      0, 6, 13, 11, 5, 12, 1, 9, 11, 10, 0, 8, 12, 4, 13, 3, 7, 15, 14, 5, 6, 2, 4, 0, 5, 9, 7, 12, 2, 10, 14, 1, 3, 8, 11, 6, 15, 13]
+RR = [5, 14, 7, 0, 9, 2, 11, 4, 13, 6, 15, 8, 1, 10, 3, 12, 6, 11, 3, 7, 0, 13, 5, 10, 14, 15, 8, 12, 4, 9, 1, 2, 15, 5, 1, 3, 7, 14, 6, 9, 11,
+      8, 12, 2, 10, 0, 4, 13, 8, 6, 4, 1, 3, 11, 15, 0, 5, 12, 2, 13, 9, 7, 10, 14, 12, 15, 10, 4, 1, 5, 8, 7, 6, 2, 13, 14, 0, 3, 9, 11]
+SL = [11, 14, 15, 12, 5, 8, 7, 9, 11, 13, 14, 15, 6, 7, 9, 8, 7, 6, 8, 13, 11, 9, 7, 15, 7, 12, 15, 9, 11, 7, 13, 12, 11, 13, 6, 7, 14, 9, 13,
+      15, 14, 8, 13, 6, 5, 12, 7, 5, 11, 12, 14, 15, 14, 15, 9, 8, 9, 14, 5, 6, 8, 6, 5, 12, 9, 15, 5, 11, 6, 8, 13, 12, 5, 12, 13, 14, 11, 8,
+      5, 6]
+SR = [8, 9, 9, 11, 13, 15, 15, 5, 7, 7, 8, 11, 14, 14, 12, 6, 9, 13, 15, 7, 12, 8, 9, 11, 7, 7, 12, 7, 6, 15, 13, 11, 9, 7, 15, 11, 8, 6, 6, 14,
+      12, 13, 5, 14, 13, 13, 7, 5, 15, 5, 8, 11, 14, 14, 6, 14, 6, 9, 12, 9, 12, 5, 15, 8, 8, 5, 12, 9, 12, 5, 14, 6, 8, 13, 6, 5, 15, 13, 11,
+      11]
+KL = [0x00000000, 0x5A827999, 0x6ED9EBA1, 0x8F1BBCDC, 0xA953FD4E]
+KR = [0x50A28BE6, 0x5C4DD124, 0x6D703EF3, 0x7A6D76E9, 0x00000000]
+TT_L = [0x96, 0xCA, 0x59, 0xE4, 0x2D]   # f1..f5 as v_bitop3 truth tables (core/hash.h VG_RMD_F1..F5)
+TT_R = [0x2D, 0xE4, 0x59, 0xCA, 0x96]
+
+
+def rotr(x, n):
+    return ((x >> n) | (x << (32 - n))) & M
+
+
+def bswap(x):
+    return int.from_bytes(x.to_bytes(4, "big"), "little")
+
+
+def tt_eval(tt, a, b, c):
+    """v_bitop3_b32: bit i of the result is bit (4a_i + 2b_i + c_i) of the truth table."""
+    r = 0
+    for i in range(8):
+        if (tt >> i) & 1:
+            r |= (a if i & 4 else ~a) & (b if i & 2 else ~b) & (c if i & 1 else ~c)
+    return r & M
+
+
+def known(v):
+    return isinstance(v, int)
+
+
+class Program:
+    """A straight-line list of instructions over virtual registers.
+
+    ins: (op, dst, srcs, imm) with op in alignbit(src; n) lshr(src; n) bitop3(a, b, c; tt) mov(k) add3(a, b, c) add(a, b) bswap(src);
+    a source is a virtual register name or an int (at most one int per instruction, never in alignbit/lshr/bswap)."""
+
+    def __init__(self, grouped=False):
+        self.ins, self.inputs, self.outputs, self.n, self.grouped = [], [], [], 0, grouped
+
+    def input(self, name):
+        self.inputs.append(name)
+        return name
+
+    def emit(self, op, srcs, imm=None):
+        self.n += 1
+        d = f"t{self.n}"
+        self.ins.append((op, d, tuple(srcs), imm))
+        return d
+
+    # ---- folding constructors ----------------------------------------------------------------------------------------
+    def rotr(self, x, n):
+        return rotr(x, n) if known(x) else self.emit("alignbit", (x,), n)
+
+    def rotl(self, x, n):
+        return self.rotr(x, (32 - n) & 31) if n & 31 else x
+
+    def shr(self, x, n):
+        return x >> n if known(x) else self.emit("lshr", (x,), n)
+
+    def bswap(self, x):
+        return bswap(x) if known(x) else self.emit("bswap", (x,))
+
+    def bitop3(self, tt, a, b, c):
+        ops = [a, b, c]
+        kn = [known(o) for o in ops]
+        if all(kn):
+            return tt_eval(tt, a, b, c)
+        while sum(kn) > 1:           # a second constant needs a register of its own (first rounds on the IV only)
+            i = kn.index(True)
+            ops[i] = self.emit("mov", (ops[i],))
+            kn[i] = False
+        return self.emit("bitop3", ops, tt)
+
+    def add(self, *terms):
+        kc = sum(t for t in terms if known(t)) & M
+        vs = [t for t in terms if not known(t)]
+        if not vs:
+            return kc
+        acc, rest = vs[0], vs[1:]
+        while len(rest) >= 2:
+            acc = self.emit("add3", (acc, rest[0], rest[1]))
+            rest = rest[2:]
+        if rest and kc:
+            return self.emit("add3", (acc, rest[0], kc))
+        if rest:
+            return self.emit("add", (acc, rest[0]))
+        if kc:
+            return self.emit("add", (acc, kc))
+        return acc
+
+    # ---- SHA-256: one compression of the 16 words w (ints or registers) into the chaining value st -------------------------
+    def sha256_compress(self, st_in, w):
+        w = list(w)
+        st = list(st_in)
+        for r in range(64):
+            if r >= 16:
+                i15, i2, i7, i0 = (r - 15) & 15, (r - 2) & 15, (r - 7) & 15, r & 15
+                if self.grouped:
+                    a7, a18 = self.rotr(w[i15], 7), self.rotr(w[i15], 18)
+                    b17, b19 = self.rotr(w[i2], 17), self.rotr(w[i2], 19)
+                    a3, b10 = self.shr(w[i15], 3), self.shr(w[i2], 10)
+                    s0, s1 = self.bitop3(0x96, a7, a18, a3), self.bitop3(0x96, b17, b19, b10)
+                else:
+                    b17, b19, b10 = self.rotr(w[i2], 17), self.rotr(w[i2], 19), self.shr(w[i2], 10)
+                    s1 = self.bitop3(0x96, b17, b19, b10)
+                    a7, a18, a3 = self.rotr(w[i15], 7), self.rotr(w[i15], 18), self.shr(w[i15], 3)
+                    s0 = self.bitop3(0x96, a7, a18, a3)
+                w[i0] = self.add(w[i0], s1, w[i7], s0)
+            a, b, c, d, e, f, g, h = (st[(j - r) & 7] for j in range(8))
+            if self.grouped:
+                r6, r11, r25 = self.rotr(e, 6), self.rotr(e, 11), self.rotr(e, 25)
+                r2, r13, r22 = self.rotr(a, 2), self.rotr(a, 13), self.rotr(a, 22)
+                s1, ch = self.bitop3(0x96, r6, r11, r25), self.bitop3(0xCA, e, f, g)
+                s0, mj = self.bitop3(0x96, r2, r13, r22), self.bitop3(0xE8, a, b, c)
+                t1 = self.add(h, s1, ch, K[r], w[r & 15])
+                nh = self.add(t1, s0, mj)
+                nd = self.add(d, t1)
+            else:
+                r6, r11, r25 = self.rotr(e, 6), self.rotr(e, 11), self.rotr(e, 25)
+                s1, ch = self.bitop3(0x96, r6, r11, r25), self.bitop3(0xCA, e, f, g)
+                t1 = self.add(h, s1, ch, K[r], w[r & 15])
+                r2, r13, r22 = self.rotr(a, 2), self.rotr(a, 13), self.rotr(a, 22)
+                s0, mj = self.bitop3(0x96, r2, r13, r22), self.bitop3(0xE8, a, b, c)
+                nd = self.add(d, t1)
+                nh = self.add(t1, s0, mj)
+            st[(3 - r) & 7], st[(7 - r) & 7] = nd, nh
+        return [self.add(st[i], st_in[i]) for i in range(8)]
+
+    # ---- RIPEMD-160: one compression of the 16 little-endian words x into the IV -----------------------------------------
+    def ripemd160_compress_iv(self, x):
+        left, right = list(RMD_IV), list(RMD_IV)
+        for j in range(80):
+            g, o = j // 16, (5 - j % 5) % 5
+            for v, tt, msg, kk, sh in ((left, TT_L[g], x[RL[j]], KL[g], SL[j]), (right, TT_R[g], x[RR[j]], KR[g], SR[j])):
+                a, b, c, d, e = (v[(o + i) % 5] for i in range(5))
+                f = self.bitop3(tt, b, c, d)
+                s = self.add(a, f, msg, kk)
+                if self.grouped:
+                    nc = self.rotl(c, 10)
+                    s = self.rotl(s, sh)
+                    na = self.add(s, e)
+                else:
+                    s = self.rotl(s, sh)
+                    na = self.add(s, e)
+                    nc = self.rotl(c, 10)
+                v[o], v[(o + 2) % 5] = na, nc
+        return [self.add(RMD_IV[1], left[2], right[3]), self.add(RMD_IV[2], left[3], right[4]), self.add(RMD_IV[3], left[4], right[0]),
+                self.add(RMD_IV[4], left[0], right[1]), self.add(RMD_IV[0], left[1], right[2])]
+
+    def ripemd160_of_sha(self, sha):
+        """RIPEMD-160 of a 32-byte SHA-256 digest given as eight big-endian words -> five little-endian words (memory order)."""
+        x = [self.bswap(s) for s in sha] + [0x80, 0, 0, 0, 0, 0, 256, 0]
+        return self.ripemd160_compress_iv(x)
+
+    # ---- statistics ------------------------------------------------------------------------------------------------------
+    def census(self):
+        c = {}
+        for op, _, _, _ in self.ins:
+            c[op] = c.get(op, 0) + 1
+        return c
+
+
+# ---- the hashes of the path: (C prologue computing the inputs, program) -------------------------------------------------------
+
+def prog_pub33_h160(grouped=False):
+    """hash160 of the compressed key: inputs m0..m8 = the nine message words that depend on the key
+    (core/hash.h sha256_pub33 + ripemd160_of_sha; payload of P2PKH / P2WPKH and first half of P2SH-P2WPKH)."""
+    p = Program(grouped)
+    w = [p.input(f"m{i}") for i in range(9)] + [0] * 6 + [33 * 8]
+    p.outputs = p.ripemd160_of_sha(p.sha256_compress(SHA_IV, w))
+    prologue = ["u32 m0 = (prefix << 24) | (xw[7] >> 8);"]
+    prologue += [f"u32 m{i} = (xw[{8 - i}] << 24) | (xw[{7 - i}] >> 8);" for i in range(1, 8)]
+    prologue += ["u32 m8 = (xw[0] << 24) | 0x00800000u;"]
+    return p, "u32 prefix, const u32 xw[8]", prologue
+
+
+def prog_script22_h160(grouped=False):
+    """hash160 of the P2WPKH redeem script 0x00 0x14 || h160: inputs m0..m5 (core/hash.h sha256_script22 + ripemd160_of_sha)."""
+    p = Program(grouped)
+    w = [p.input(f"m{i}") for i in range(6)] + [0] * 9 + [22 * 8]
+    p.outputs = p.ripemd160_of_sha(p.sha256_compress(SHA_IV, w))
+    prologue = ["u32 b0 = bswap32(h[0]), b1 = bswap32(h[1]), b2 = bswap32(h[2]), b3 = bswap32(h[3]), b4 = bswap32(h[4]);",
+                "u32 m0 = 0x00140000u | (b0 >> 16);"]
+    prologue += [f"u32 m{i} = (b{i - 1} << 16) | (b{i} >> 16);" for i in range(1, 5)]
+    prologue += ["u32 m5 = (b4 << 16) | 0x00008000u;"]
+    return p, "const u32 h[5]", prologue
+
+
+def prog_pub65_h160(grouped=False):
+    """hash160 of the uncompressed key 0x04 || X || Y: two SHA-256 blocks (core/hash.h sha256_pub65 + ripemd160_of_sha)."""
+    p = Program(grouped)
+    w = [p.input(f"m{i}") for i in range(17)]
+    mid = p.sha256_compress(SHA_IV, w[:16])
+    sha = p.sha256_compress(mid, [w[16]] + [0] * 14 + [65 * 8])
+    p.outputs = p.ripemd160_of_sha(sha)
+    prologue = ["u32 m0 = (0x04u << 24) | (xw[7] >> 8);"]
+    prologue += [f"u32 m{i} = (xw[{8 - i}] << 24) | (xw[{7 - i}] >> 8);" for i in range(1, 8)]
+    prologue += ["u32 m8 = (xw[0] << 24) | (yw[7] >> 8);"]
+    prologue += [f"u32 m{8 + i} = (yw[{8 - i}] << 24) | (yw[{7 - i}] >> 8);" for i in range(1, 8)]
+    prologue += ["u32 m16 = (yw[0] << 24) | 0x00800000u;"]
+    return p, "const u32 xw[8], const u32 yw[8]", prologue
+
+
+PROGRAMS = {"hash160_pub33_block": prog_pub33_h160, "hash160_script22_block": prog_script22_h160,
+            "hash160_pub65_block": prog_pub65_h160}
+
+
+# ---- the Python model of the instruction list (CPU tests) ---------------------------------------------------------------------
+
+def evaluate(p, inputs):
+    """Run program p on concrete input words (dict name -> int); -> list of output words."""
+    v = dict(inputs)
+
+    def val(s):
+        return s if known(s) else v[s]
+
+    for op, d, srcs, imm in p.ins:
+        s = [val(x) for x in srcs]
+        if op == "alignbit":
+            r = rotr(s[0], imm)
+        elif op == "lshr":
+            r = s[0] >> imm
+        elif op == "bitop3":
+            r = tt_eval(imm, *s)
+        elif op == "mov":
+            r = s[0]
+        elif op in ("add3", "add"):
+            r = sum(s) & M
+        elif op == "bswap":
+            r = bswap(s[0])
+        else:
+            raise ValueError(op)
+        v[d] = r
+    return [val(o) for o in p.outputs]
+
+
+def evaluate_allocated(p, reg, nreg, inputs):
+    """The same on the PHYSICAL registers `allocate` chose (what the asm statement does): -> list of output words."""
+    rf = [None] * nreg
+    for name in p.inputs:
+        rf[reg[name]] = inputs[name]
+    q = Program()
+    q.ins = [(op, ("r", reg[d]), tuple(s if known(s) else ("r", reg[s]) for s in srcs), imm) for op, d, srcs, imm in p.ins]
+    for op, (_, d), srcs, imm in q.ins:
+        one = Program()
+        one.ins = [(op, "d", tuple(s if known(s) else f"s{i}" for i, s in enumerate(srcs)), imm)]
+        one.outputs = ["d"]
+        rf[d] = evaluate(one, {f"s{i}": rf[s[1]] for i, s in enumerate(srcs) if not known(s)})[0]
+    return [o if known(o) else rf[reg[o]] for o in p.outputs]
+
+
+# ---- instruction order ----------------------------------------------------------------------------------------------------------
+
+def spread(p, window=24, distance=1):
+    """Reorder p.ins so that no instruction reads a result written by one of the `distance` instructions before it, wherever the
+    dependency graph allows.  Greedy list scheduling over a window of the original order (which bounds the extra register
+    pressure): the earliest complete instruction among those farthest from their operands goes next.  An option of the A/B,
+    not the default: on the MI355X it changes nothing (12.62 against 12.62 Gkeys/s without yields, 13.10 against 13.14 with).
+    -> number of dependent neighbours that remain."""
+    ins = p.ins
+    n = len(ins)
+    producer = {d: i for i, (_, d, _, _) in enumerate(ins)}
+    preds = [[producer[s] for s in srcs if not known(s) and s in producer] for _, _, srcs, _ in ins]
+    done = [False] * n
+    pos = {}                    # original index -> position in the new order
+    order = []
+    head = 0
+    remaining = 0
+    while len(order) < n:
+        while head < n and done[head]:
+            head += 1
+        best, pick = -1, None          # the earliest complete instruction among those farthest (up to `distance`) from their operands
+        for i in range(head, min(n, head + window)):
+            if done[i] or not all(done[q] for q in preds[i]):
+                continue
+            gap = min([len(order) - pos[q] - 1 for q in preds[i]] + [distance])
+            if gap > best:
+                best, pick = gap, i
+                if gap == distance:
+                    break
+        if best == 0:
+            remaining += 1
+        done[pick] = True
+        pos[pick] = len(order)
+        order.append(pick)
+    p.ins = [ins[i] for i in order]
+    return remaining
+
+
+# ---- register allocation and the asm text -------------------------------------------------------------------------------------
+
+def inline_const(k):
+    """gfx9 inline integer constants: 0..64 and -16..-1."""
+    return k <= 64 or k >= (M + 1 - 16)
+
+
+def allocate(p):
+    """Linear scan over the straight-line list.  -> (reg of every virtual name, number of registers).
+    Inputs occupy r0..r(n-1) on entry; a register is free again after the last read of its value, and the instruction that
+    reads it last may write its own result there (in-order issue: the read precedes the write)."""
+    last = {}
+    for i, (_, _, srcs, _) in enumerate(p.ins):
+        for s in srcs:
+            if not known(s):
+                last[s] = i
+    for o in p.outputs:
+        if not known(o):
+            last[o] = len(p.ins)
+    reg, free, nreg = {}, [], 0
+    for name in p.inputs:
+        reg[name] = nreg
+        nreg += 1
+    for name in p.inputs:
+        if name not in last:
+            free.append(reg[name])
+    for i, (_, d, srcs, _) in enumerate(p.ins):
+        for s in dict.fromkeys(srcs):
+            if not known(s) and last[s] == i:
+                free.append(reg[s])
+        if d not in last:
+            raise ValueError(f"dead instruction {i}: {p.ins[i]}")
+        if free:
+            reg[d] = free.pop(0)       # oldest free register first: spreads the writes over the pool
+        else:
+            reg[d] = nreg
+            nreg += 1
+    return reg, nreg
+
+
+def asm_lines(p, reg, yields="every:3"):
+    """-> (list of asm lines with %[rN] / %[k] operands, VALU count, s_mov count, yield count).
+    yields: "every:N" puts an `s_nop 0` after every N-th VALU instruction, "dep" between an instruction and a successor that
+    reads its result (what hipcc does around single-instruction asm statements), "none" nowhere."""
+    out, valu, salu, nyield = [], 0, 0, 0
+    prev_dst = None
+
+    def r(s):
+        return f"%[r{reg[s]}]"
+
+    def const_operand(k):
+        nonlocal salu
+        if inline_const(k):
+            return str(k if k <= 64 else k - (M + 1))
+        out.append(f"s_mov_b32 %[k], 0x{k:08x}")
+        salu += 1
+        return "%[k]"
+
+    for op, d, srcs, imm in p.ins:
+        D = r(d)
+        if prev_dst is not None and (yields == "dep" and prev_dst in srcs or yields.startswith("every:") and valu % int(yields[6:]) == 0):
+            out.append("s_nop 0")
+            nyield += 1
+        prev_dst = d
+        if op == "alignbit":
+            line = f"v_alignbit_b32 {D}, {r(srcs[0])}, {r(srcs[0])}, {imm}"
+        elif op == "lshr":
+            line = f"v_lshrrev_b32 {D}, {imm}, {r(srcs[0])}"
+        elif op == "mov":
+            line = f"v_mov_b32 {D}, 0x{srcs[0]:08x}"
+        elif op == "bswap":
+            line = f"v_perm_b32 {D}, 0, {r(srcs[0])}, {const_operand(0x00010203)}"
+        elif op == "bitop3":
+            o = [const_operand(s) if known(s) else r(s) for s in srcs]
+            line = f"v_bitop3_b32 {D}, {o[0]}, {o[1]}, {o[2]} bitop3:0x{imm:02x}"
+        elif op == "add3":
+            o = [const_operand(s) if known(s) else r(s) for s in srcs]
+            line = f"v_add3_u32 {D}, {o[0]}, {o[1]}, {o[2]}"
+        elif op == "add":
+            a, b = srcs
+            if known(b):
+                a, b = b, a
+            if known(a):     # VOP2: a 32-bit literal is allowed in src0
+                line = f"v_add_u32 {D}, {a if a <= 64 else ('0x%08x' % a)}, {r(b)}"
+            else:
+                line = f"v_add_u32 {D}, {r(a)}, {r(b)}"
+        else:
+            raise ValueError(op)
+        out.append(line)
+        valu += 1
+    return out, valu, salu, nyield
+
+
+def function_source(name, grouped=False, yields="every:3", window=0, distance=1):
+    p, params, prologue = PROGRAMS[name](grouped)
+    left = spread(p, window, distance) if window else None
+    reg, nreg = allocate(p)
+    lines, valu, salu, nyield = asm_lines(p, reg, yields)
+    nin = len(p.inputs)
+    nout = len(p.outputs)
+    c = p.census()
+    src = f"// {name}: {valu} VALU ({', '.join(f'{c[k]} {k}' for k in sorted(c))}) + {salu} s_mov + {nyield} yields,\n"
+    src += f"// {nreg} VGPRs + 1 SGPR, {'grouped' if grouped else 'dependency'} order"
+    src += f", spread over a window of {window}: {left} dependent neighbours left.\n" if window else ".\n"
+    src += f"__device__ __forceinline__ void {name}({params}, u32 out[{nout}]) {{\n"
+    for l in prologue:
+        src += f"    {l}\n"
+    for i, nm in enumerate(p.inputs):
+        src += f"    u32 r{i} = {nm};\n"
+    if nreg > nin:
+        src += "    u32 " + ", ".join(f"r{i}" for i in range(nin, nreg)) + ";\n"
+    src += "    u32 k;\n"
+    src += "    asm(\n"
+    for l in lines:
+        src += f'        "{l}\\n\\t"\n'
+    ops = [f'[r{i}] "+v"(r{i})' for i in range(nin)] + [f'[r{i}] "=&v"(r{i})' for i in range(nin, nreg)] + ['[k] "=&s"(k)']
+    src += "        : " + ", ".join(ops) + ");\n"
+    for j, o in enumerate(p.outputs):
+        src += f"    out[{j}] = {('0x%08xu' % o) if known(o) else 'r%d' % reg[o]};\n"
+    src += "}\n\n"
+    return src
+
+
+def generate(grouped=False, yields="every:3", window=0, distance=1):
+    src = "// GENERATED by device/hashgen.py (`make -C vgen_amd/csrc hashblocks`) - do not edit.\n"
+    src += "// The address hashes of the scan kernels as single asm statements of gfx950 instructions; see hashgen.py.\n\n"
+    for name in PROGRAMS:
+        src += function_source(name, grouped, yields, window, distance)
+    return src
+
+
+def main(argv):
+    def opt(name, default):
+        return argv[argv.index(name) + 1] if name in argv else default
+
+    sys.stdout.write(generate(opt("--order", "natural") == "grouped", opt("--yield", "every:3"),
+                              int(opt("--window", "0")), int(opt("--distance", "1"))))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

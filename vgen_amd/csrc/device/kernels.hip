@@ -117,6 +117,12 @@ __device__ __forceinline__ u32 match_slot(DevMatchHeader *hdr, bool hit, u32 mat
     return first + rank - match_base;
 }
 
+// ---- the address hashes as scheduled instruction blocks ----------------------------------------------------
+// hash160_pub33_block / hash160_script22_block / hash160_pub65_block: one asm statement each, generated by
+// device/hashgen.py from the same round functions as core/hash.h (the Makefile writes hash_blocks.inc).  The order of the
+// instructions and the issue-slot yields between them are part of the kernel's design, not hipcc's.
+#include "hash_blocks.inc"
+
 // ---- payload per format -----------------------------------------------------------------------------
 
 template <int FMT>
@@ -133,20 +139,15 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
     u32 xw[8];
     fe_to_words(x, xw);
     if (FMT == VGF_P2PKH || FMT == VGF_P2WPKH) {
-        u32 sha[8];
-        sha256_pub33(2u | (y_canon.n[0] & 1u), xw, sha);
-        ripemd160_of_sha(sha, out);
+        hash160_pub33_block(2u | (y_canon.n[0] & 1u), xw, out);
     } else if (FMT == VGF_P2SH_P2WPKH) {
-        u32 sha[8], h[5];
-        sha256_pub33(2u | (y_canon.n[0] & 1u), xw, sha);
-        ripemd160_of_sha(sha, h);
-        sha256_script22(h, sha);
-        ripemd160_of_sha(sha, out);
+        u32 h[5];
+        hash160_pub33_block(2u | (y_canon.n[0] & 1u), xw, h);
+        hash160_script22_block(h, out);
     } else if (FMT == VGF_P2PKH_UNCOMPRESSED) {
-        u32 yw[8], sha[8];
+        u32 yw[8];
         fe_to_words(y_canon, yw);
-        sha256_pub65(xw, yw, sha);
-        ripemd160_of_sha(sha, out);
+        hash160_pub65_block(xw, yw, out);
     } else {  // VGF_ETHEREUM
         u32 yw[8];
         fe_to_words(y_canon, yw);
