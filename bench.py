@@ -879,9 +879,12 @@ def main():
         roofline["issue"] = {k: pmc[k] for k in ("valu_busy", "valu_instr_per_key", "valu_instr_per_key_all_kernels", "waves_per_simd",
                                                  "source", "how") if k in pmc}
         # The same bound from wall time: VALU instructions retired per second (instructions per key from the counters x the
-        # keys per second of this run) against one wave64 VALU instruction per SIMD every 4 cycles at the measured shader
+        # keys per second of this run) against (a) one wave64 VALU instruction per SIMD every 4 cycles at the measured shader
         # clock — the issue rate of the instruction classes that make up ~60 % of the mix (v_alignbit, v_add3, v_mad_u64_u32,
-        # v_bfe ...: 35-38 T lane-instructions/s in profiles/r01_ubench_valu.jsonl); v_add / v_xor / v_bitop3 can issue in 2.
+        # v_bfe ...: 35-38 T lane-instructions/s in profiles/r01_ubench_valu.jsonl) — and (b) the price the mix would have if
+        # every instruction issued at its own class's rate (0.6 x 4.15 + 0.4 x 2.3 = 3.4 cycles; v_add / v_xor / v_bitop3
+        # issue in 2.2-2.4 in streams of their own kind).  Until round 4 (a) was what the kernel reached (0.98); with the hash
+        # pair as scheduled blocks with issue-slot yields (device/hashgen.py) the steady state runs ABOVE it, so (b) is the ceiling.
         ipk = pmc.get("valu_instr_per_key_all_kernels")
         rate_keys = (sustained["value"] if sustained else value) * 1e6 / world
         if ipk and not args.endo:
@@ -889,7 +892,9 @@ def main():
             peak_t = N_SIMD * mhz * 1e6 / 4.0 * 64 / 1e12
             roofline["issue"].update({"valu_lane_instr_per_s_T": round(rate_keys * ipk / 1e12, 2),
                                       "issue_peak_T_at_4_cycles_per_wave_instr": round(peak_t, 2),
-                                      "frac_of_issue_peak": round(rate_keys * ipk / 1e12 / peak_t, 4)})
+                                      "frac_of_issue_peak": round(rate_keys * ipk / 1e12 / peak_t, 4),
+                                      "simd_cycles_per_valu_instr_steady_state": round(4.0 * peak_t / (rate_keys * ipk / 1e12), 3),
+                                      "frac_of_ideal_mix_3p4_cycles": round(rate_keys * ipk / 1e12 / (peak_t * 4.0 / 3.4), 4)})
 
     out = {
         "metric": "Mkeys/sec (keys tried per second)", "value": round(value, 2), "unit": "Mkeys/sec", "n_gpus": world,

@@ -10,6 +10,8 @@ one of them fails the CPU suite instead of silently costing throughput:
   * match compaction is per WAVE: one global atomic per kernel, fed by the popcount of the wave's ballot, the leader's
     result broadcast by v_readlane, ranks by v_mbcnt (kernels.hip: match_slot) — never a per-lane atomic, never system scope;
   * the short first-half kernels of a dispatch raise their issue priority (s_setprio);
+  * the hash pair of the headline kernel is the scheduled block device/hashgen.py writes — its instructions in the
+    generator's order, one `s_nop 0` yield after every third — not a schedule of hipcc's;
   * no instantiation uses more registers or scratch than the committed table profiles/r04_kernel_resources.txt.
 
 Reference counterpart of the code under test: src/shaders/search.wgsl:2-31 (one storage write per key, no compaction).
@@ -134,6 +136,28 @@ def test_the_checker_rejects_a_per_lane_or_system_scope_atomic():
     assert check_match_path("k", {"body": llvm})
     assert check_match_path("k", {"body": good + ["\tglobal_atomic_add v8, v13, v8, s[28:29] sc0"]})     # two atomics
     assert check_match_path("k", {"body": ["\ts_cbranch_execnz .LBB0_1"] + good})                         # waterfall loop
+
+
+def test_the_hash_pair_is_the_generated_block_in_the_generators_order(isa):
+    """The order of the hash instructions and the yields between them are design decisions measured on the MI355X
+    (profiles/r04_hash_blocks_ab.txt): the assembly must contain the generator's list verbatim, modulo register names."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "vgen_amd", "csrc", "device"))
+    import hashgen as g
+    p, _, _ = g.prog_pub33_h160()
+    reg, _ = g.allocate(p)
+    want = [re.sub(r"%\[\w+\]", "R", l) for l in g.asm_lines(p, reg)[0]]
+    norm = []
+    for l in isa[HEADLINE]["body"]:
+        l = l.split(";")[0].strip()
+        if re.match(r"(v_|s_nop|s_mov_b32)", l):
+            norm.append(re.sub(r"\b[vs]\d+\b", "R", l))
+    first = next(i for i, l in enumerate(norm) if l == want[0] and norm[i:i + 8] == want[:8])
+    got = norm[first:first + len(want)]
+    assert got == want
+    assert sum(l == "s_nop 0" for l in want) == 731 and sum(l.startswith("v_") for l in want) == 2196
+    # and the block appears once: the loop over a lane's keys is not unrolled around it
+    assert count(isa[HEADLINE]["body"], r"v_alignbit_b32") < 2 * 868
 
 
 def test_chain_kernels_raise_their_priority(isa):

@@ -5,7 +5,7 @@ cp vgen_amd/libvgen_hip.so /tmp/libA.so
 echo "== A (in-tree)"; python tools/gpu_perf.py $ARGS 2>&1 | grep Mkeys | cut -c1-120
 for T in "$@"; do
   cp vgen_amd/libvgen_hip.so.$T vgen_amd/libvgen_hip.so
-  echo "== $T"; python tests/manual/gpu_smoke.py 0 32768 2>&1 | tail -1 | cut -c1-80; python tools/gpu_perf.py $ARGS 2>&1 | grep Mkeys | cut -c1-120
+  echo "== $T"; python tests/manual/gpu_smoke.py ${ARGS%% *} 32768 2>&1 | tail -1 | cut -c1-80; python tools/gpu_perf.py $ARGS 2>&1 | grep Mkeys | cut -c1-120
 done
 cp /tmp/libA.so vgen_amd/libvgen_hip.so
 echo "== A again"; python tools/gpu_perf.py $ARGS 2>&1 | grep Mkeys | cut -c1-120

@@ -39,4 +39,4 @@ if __name__ == "__main__":
         b = int(os.environ.get("VGEN_PERF_BATCH", str(1 << 20)))
         sweep = [(b, int(f), max(32, int(os.environ.get("VGEN_PERF_STEPS", "256")) * (1 << 20) // b)) for f in sys.argv[2].split(",")]
     for batch, frames, steps in sweep:
-        run(batch, frames, steps, fmt)
+        run(batch, frames, steps, fmt, os.environ.get("VGEN_PERF_PATTERN", "^0xdead" if fmt == 5 else "^1Cat"))
