@@ -194,6 +194,32 @@ def test_both_frames_and_repeat_are_consistent(vg, vo):
     r.close()
 
 
+@pytest.mark.parametrize("fmt,pattern", [(0, "^1Cat"), (1, "^bc1qaa")])
+def test_one_frame_contexts_run_the_variant_without_yields_and_find_the_same_keys(vg, vo, fmt, pattern):
+    """A context with ONE frame in flight launches seq_bwd_kernel<.., LONE> (hipcc's schedule of core/hash.h instead of the
+    scheduled hash block, kernels.hip: payload_from_point): dump and filter mode of both variants against the oracle."""
+    batch = 1 << 16
+    start = vo.seed_key(11, fmt)
+    ref = vo.payload_seq(fmt, start, batch)
+    p = vg.Pattern(pattern, False, vg.AddressFormat(fmt))
+    assert p.device_kind != 0
+    found = []
+    for frames in (1, 3):
+        r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=frames, match_cap=65536)
+        r.set_filter(None)
+        r.dispatch(start, 0)
+        assert r.await_result(0)[0] == ref
+        r.set_filter(p)
+        r.dispatch(start, 0)
+        recs, _, _ = r.await_result(0)
+        for i, payload in recs:
+            assert payload == ref[20 * i:20 * i + 20]
+        found.append([i for i, payload in recs if p.matches(vg.address_from_payload(fmt, payload))])
+        r.close()
+    assert found[0] == found[1]
+    assert found[0] == [i for i in range(batch) if p.matches(vg.address_from_payload(fmt, ref[20 * i:20 * i + 20]))]
+
+
 CASES = [
     (0, "^1Cat", False), (0, "^1[Oo]ri", False), (0, "^1cat", True), (0, "^1(Ab|Zz)", False), (0, "^11", False),
     (1, "dead$", False), (1, "^bc1qaa", False), (1, "^bc1q.*dd$", False), (1, "^bc1qq[qp]", False),

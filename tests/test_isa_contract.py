@@ -25,7 +25,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ISA = os.path.join(ROOT, "build", "lib", "device", "kernels.s")
 SRC = os.path.join(ROOT, "vgen_amd", "csrc", "device", "kernels.hip")
-HEADLINE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0EEEvNS_7SeqArgsE"
+HEADLINE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0ELb0EEEvNS_7SeqArgsE"
+LONE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0ELb1EEEvNS_7SeqArgsE"   # its twin for contexts with one frame in flight
 
 
 def parse_isa(txt):
@@ -100,7 +101,7 @@ def test_headline_kernel_budget(isa):
 
 def test_match_compaction_is_one_atomic_per_wave(isa):
     with_match = [s for s in isa if re.search(r"(seq_bwd_kernelILi[0245]|keys_bwd_kernelILi[0245]|p2tr_finish_kernel|p2tr_out_kernel)", s)]
-    assert len(with_match) == 16 + 16 + 2 + 2, sorted(with_match)
+    assert len(with_match) == 16 + 1 + 16 + 2 + 2, sorted(with_match)   # + 1: the one-frame twin of the headline kernel
     bad = []
     for sym in with_match:
         bad += check_match_path(sym, isa[sym])
@@ -158,6 +159,15 @@ def test_the_hash_pair_is_the_generated_block_in_the_generators_order(isa):
     assert sum(l == "s_nop 0" for l in want) == 731 and sum(l.startswith("v_") for l in want) == 2196
     # and the block appears once: the loop over a lane's keys is not unrolled around it
     assert count(isa[HEADLINE]["body"], r"v_alignbit_b32") < 2 * 868
+
+
+def test_the_one_frame_twin_carries_no_yields(isa):
+    """Contexts with one frame in flight launch seq_bwd_kernel<P2PKH, false, false, LONE>: hipcc's schedule of core/hash.h, because a
+    wave that has its SIMD to itself pays four cycles per yield.  Same budget as the headline kernel."""
+    k = isa[LONE]
+    assert k["vgpr"] <= 128 and k["scratch"] == 0
+    assert count(k["body"], r"s_nop") < 100 < 700 < count(isa[HEADLINE]["body"], r"s_nop")
+    assert count(k["body"], r"v_alignbit_b32") >= 868
 
 
 def test_chain_kernels_raise_their_priority(isa):

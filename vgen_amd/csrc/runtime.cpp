@@ -875,6 +875,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     a.groups = c->groups;
     a.n = c->batch;
     a.s = S;
+    a.lone = c->frames == 1;
     const bool dump = dump_mode(c);
     if (dump) {
         if (int rc = ensure_dump_frame(c, (uint32_t)(&f - c->fr.data()))) return rc;
