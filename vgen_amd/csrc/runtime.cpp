@@ -250,6 +250,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     c->timing = (p->flags & VGEN_FLAG_TIMING) != 0;
     c->endo = (p->flags & VGEN_FLAG_ENDO) != 0 && p->format != VGF_P2TR;
     c->S = env_u32("VGEN_SEQ_S", 8);
+    c->lone_variant = env_u32("VGEN_LONE_VARIANT", 1) != 0;   // 0: one-frame contexts launch the steady-state kernel too (counter passes: tools/pmc_valu.sh)
     auto bail = [&](int st, const std::string &m) {
         err = m;
         rt_destroy(c);
@@ -875,7 +876,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     a.groups = c->groups;
     a.n = c->batch;
     a.s = S;
-    a.lone = c->frames == 1;
+    a.lone = c->frames == 1 && c->lone_variant;
     const bool dump = dump_mode(c);
     if (dump) {
         if (int rc = ensure_dump_frame(c, (uint32_t)(&f - c->fr.data()))) return rc;

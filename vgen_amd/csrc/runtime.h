@@ -24,6 +24,7 @@ struct vgen_ctx {
     int device = 0;
     uint32_t batch = 0, frames = 0, match_cap = 0, format = 0;
     uint32_t S = 0, lanes = 0, groups = 0;
+    bool lone_variant = true;   // frames == 1: launch seq_bwd_kernel<.., LONE> (VGEN_LONE_VARIANT=0 turns that off)
     vg::SeqBaseCache base_cache;         // host-side incremental base points (host_ec.h)
     uint32_t payload_words = 5;
     bool timing = false;                 // VGEN_FLAG_TIMING: events around every dispatch
