@@ -43,7 +43,7 @@ def test_fault_injection_is_not_part_of_the_shipped_library():
     assert "vgen_debug" not in open(os.path.join(ROOT, "INTEGRATION.md")).read()
     # the environment variables the shipped library does read are the documented ones
     env = set(re.findall(rb"VGEN_[A-Z0-9_]+", blob))
-    read = {b"VGEN_SEQ_S", b"VGEN_GTAB_BITS", b"VGEN_TRACE_CREATE"}                         # getenv'ed (INTEGRATION.md lists them)
+    read = {b"VGEN_SEQ_S", b"VGEN_GTAB_BITS", b"VGEN_TRACE_CREATE", b"VGEN_LONE_VARIANT"}                       # getenv'ed (INTEGRATION.md lists them)
     named_in_messages = {b"VGEN_FLAG_ENDO", b"VGEN_FLAG_TIMING", b"VGEN_SCAN_RANDOM_KEYS"}    # ABI constants quoted in error texts
     assert read <= env <= read | named_in_messages, env
     # ... and the test build has both hooks
