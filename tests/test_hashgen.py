@@ -50,7 +50,15 @@ def case_pub65(rng):
     return m, po.hash160(b"\x04" + x.to_bytes(32, "big") + y.to_bytes(32, "big"))
 
 
-CASES = {"hash160_pub33_block": case_pub33, "hash160_script22_block": case_script22, "hash160_pub65_block": case_pub65}
+def case_base58_check(rng):
+    version, h = rng.choice([0, 5]), rng.randbytes(20)
+    H = struct.unpack(">5I", h)
+    m = [(version << 24) | (H[0] >> 8)] + [((H[i - 1] << 24) & M) | (H[i] >> 8) for i in range(1, 5)] + [((H[4] << 24) & M) | 0x00800000]
+    import hashlib
+    return m, hashlib.sha256(hashlib.sha256(bytes([version]) + h).digest()).digest()[:4][::-1]   # out[0] is a big-endian word
+
+
+CASES = {"base58_check_block": case_base58_check, "hash160_pub33_block": case_pub33, "hash160_script22_block": case_script22, "hash160_pub65_block": case_pub65}
 
 
 def test_every_emitted_function_has_a_case():

@@ -51,7 +51,16 @@ VG_HD bool dfa_accept(const DfaView &v, u32 s) { return (v.flags[s] & 3u) != 0; 
 // ---- Base58Check ----------------------------------------------------------------------------------------
 
 // checksum = first 4 bytes of SHA-256(SHA-256(version || h160)); H = h160 as five big-endian words
+#if defined(__HIP_DEVICE_COMPILE__) && defined(VG_HASH_BLOCKS)
+// in the kernels: the two compressions as one scheduled instruction block (device/hashgen.py -> device/hash_blocks.inc)
+__device__ __forceinline__ void base58_check_block(u32 version, const u32 H[5], u32 out[1]);
+#endif
 VG_HD u32 base58_checksum(u32 version, const u32 H[5]) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(VG_HASH_BLOCKS)
+    u32 chk[1];
+    base58_check_block(version, H, chk);
+    return chk[0];
+#else
     u32 w[16], st[8];
     w[0] = (version << 24) | (H[0] >> 8);
     w[1] = (H[0] << 24) | (H[1] >> 8);
@@ -75,6 +84,7 @@ VG_HD u32 base58_checksum(u32 version, const u32 H[5]) {
     for (int i = 0; i < 8; i++) st[i] = SHA256_IV[i];
     sha256_compress(st, w);
     return st[0];
+#endif
 }
 
 // (hi:lo) / 58^5 for hi < 58^5: quotient (< 2^32) and remainder.  One double-precision reciprocal
@@ -187,14 +197,21 @@ VG_HD bool dfa_match_hex40(const u32 *blob, const u32 H[5]) {
     return dfa_accept(v, s);
 }
 
-// payload: NW words in memory order (5, or 8 for P2TR).  fmt: VGF_*.
-template <int NW>
+// payload: NW words in memory order (5, or 8 for P2TR).  fmt: VGF_* (run time).  KFMT: what the caller knows about fmt at
+// compile time — -1 nothing; a kernel instantiated for one payload kind passes its own format, so that it carries only the
+// encoders it can need (VGF_P2PKH: hash160 of the compressed key, i.e. P2PKH or P2WPKH, told apart by fmt; every other value: exactly that format).
+template <int NW, int KFMT = -1>
 VG_HD bool dfa_match_payload_n(const u32 *blob, int fmt, const u32 *payload) {
     u32 H[NW];
 #pragma unroll
     for (int i = 0; i < NW; i++) H[i] = bswap32(payload[i]);
     if (NW == 8) return dfa_match_bech32<NW>(blob, H, 1);
+    if (KFMT == VGF_ETHEREUM) return dfa_match_hex40(blob, H);
+    if (KFMT == VGF_P2WPKH) return dfa_match_bech32<NW>(blob, H, 0);
+    if (KFMT == VGF_P2SH_P2WPKH) return dfa_match_base58(blob, 5u, H);
+    if (KFMT == VGF_P2PKH_UNCOMPRESSED) return dfa_match_base58(blob, 0u, H);
     if (fmt == VGF_P2WPKH) return dfa_match_bech32<NW>(blob, H, 0);
+    if (KFMT == VGF_P2PKH) return dfa_match_base58(blob, 0u, H);
     if (fmt == VGF_ETHEREUM) return dfa_match_hex40(blob, H);
     return dfa_match_base58(blob, fmt == VGF_P2SH_P2WPKH ? 5u : 0u, H);
 }

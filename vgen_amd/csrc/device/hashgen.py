@@ -194,6 +194,17 @@ class Program:
         x = [self.bswap(s) for s in sha] + [0x80, 0, 0, 0, 0, 0, 256, 0]
         return self.ripemd160_compress_iv(x)
 
+    def prune(self):
+        """Drop the instructions no output depends on (a digest of which only the first word is wanted)."""
+        live = {o for o in self.outputs if not known(o)}
+        keep = []
+        for ins in reversed(self.ins):
+            if ins[1] in live:
+                keep.append(ins)
+                live.update(x for x in ins[2] if not known(x))
+        self.ins = keep[::-1]
+        return self
+
     # ---- statistics ------------------------------------------------------------------------------------------------------
     def census(self):
         c = {}
@@ -243,8 +254,22 @@ def prog_pub65_h160(grouped=False):
     return p, "const u32 xw[8], const u32 yw[8]", prologue
 
 
+def prog_base58_check(grouped=False):
+    """Base58Check checksum: the first word of SHA-256(SHA-256(version || hash160)); inputs m0..m5, the six message words of the
+    21 bytes (core/dfa_eval.h base58_checksum; the on-device match of unanchored patterns needs the whole address string)."""
+    p = Program(grouped)
+    w = [p.input(f"m{i}") for i in range(6)] + [0] * 9 + [21 * 8]
+    first = p.sha256_compress(SHA_IV, w)
+    p.outputs = p.sha256_compress(SHA_IV, first + [0x80000000] + [0] * 6 + [32 * 8])[:1]
+    p.prune()
+    prologue = ["u32 m0 = (version << 24) | (H[0] >> 8);"]
+    prologue += [f"u32 m{i} = (H[{i - 1}] << 24) | (H[{i}] >> 8);" for i in range(1, 5)]
+    prologue += ["u32 m5 = (H[4] << 24) | 0x00800000u;"]
+    return p, "u32 version, const u32 H[5]", prologue
+
+
 PROGRAMS = {"hash160_pub33_block": prog_pub33_h160, "hash160_script22_block": prog_script22_h160,
-            "hash160_pub65_block": prog_pub65_h160}
+            "hash160_pub65_block": prog_pub65_h160, "base58_check_block": prog_base58_check}
 
 
 # ---- the Python model of the instruction list (CPU tests) ---------------------------------------------------------------------

@@ -37,6 +37,7 @@
 //     (profiles/r02_queue_sweep.txt: 11.4 instead of 9.5 Gkeys/s at four frames).
 #include <hip/hip_runtime.h>
 
+#define VG_HASH_BLOCKS 1   // core/dfa_eval.h: base58_checksum runs as a scheduled block too (hash_blocks.inc below)
 #include "../core/dfa_eval.h"
 #include "../core/ec.h"
 #include "../core/filter_eval.h"
@@ -118,12 +119,21 @@ __device__ __forceinline__ u32 match_slot(DevMatchHeader *hdr, bool hit, u32 mat
 }
 
 // ---- the address hashes as scheduled instruction blocks ----------------------------------------------------
-// hash160_pub33_block / hash160_script22_block / hash160_pub65_block: one asm statement each, generated by
+// hash160_pub33_block / hash160_script22_block / hash160_pub65_block / base58_check_block: one asm statement each, generated by
 // device/hashgen.py from the same round functions as core/hash.h (the Makefile writes hash_blocks.inc).  The order of the
 // instructions and the issue-slot yields between them are part of the kernel's design, not hipcc's.
 #include "hash_blocks.inc"
 
 // ---- payload per format -----------------------------------------------------------------------------
+
+// What a FULL kernel tells the on-device matcher about the address format at compile time (core/dfa_eval.h: the encoders that
+// cannot be needed are not compiled in: Base58Check +3 % with its checksum as a scheduled block, A/B profiles/r04_hash_blocks_ab.txt).
+// Not for Ethereum: the kernel that carries only the hex walk measured 1.8 % SLOWER than the one that still carries all three
+// (7.61 against 7.75 Gkeys/s, twice; another register allocation of the Keccak rounds), so that format keeps the run-time choice.
+template <int FMT>
+struct MatchFmt {
+    static constexpr int value = (FMT == VGF_P2TR || FMT == VGF_ETHEREUM) ? -1 : FMT;
+};
 
 template <int FMT>
 struct PayloadWords {
@@ -456,7 +466,7 @@ seq_bwd_kernel(const SeqArgs args) {
 #pragma unroll
                         for (int i = 0; i < NW; i++) o[i] = ple[i];
                     } else {
-                        const bool hit = FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple);
+                        const bool hit = FULL ? dfa_match_payload_n<NW, MatchFmt<FMT>::value>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple);
                         const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
                         if (hit && slot < args.match_cap) {
                             DevMatch *m = args.mrec + slot;
@@ -479,7 +489,7 @@ seq_bwd_kernel(const SeqArgs args) {
                 for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
             } else {
                 // monotonic counter: no per-dispatch reset; this dispatch's slots start at match_base
-                const bool hit = ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl));
+                const bool hit = ok && (FULL ? dfa_match_payload_n<NW, MatchFmt<FMT>::value>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl));
                 const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
                 if (hit && slot < args.match_cap) {
                     DevMatch *m = args.mrec + slot;
@@ -1042,7 +1052,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
 #pragma unroll
                 for (int i = 0; i < NW; i++) o[i] = live ? ple[i] : 0u;
             } else {
-                const bool hit = live && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple));
+                const bool hit = live && (FULL ? dfa_match_payload_n<NW, MatchFmt<FMT>::value>(dfa_lds, (int)args.fmt, ple) : filter_eval_n<NW>(args.filter, ple));
                 const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
                 if (hit && slot < args.match_cap) {
                     DevMatch *m = args.mrec + slot;
@@ -1064,7 +1074,7 @@ __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) 
 #pragma unroll
         for (int i = 0; i < NW; i++) o[i] = ok ? pl[i] : 0u;
     } else {
-        const bool hit = ok && (FULL ? dfa_match_payload_n<NW>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl));
+        const bool hit = ok && (FULL ? dfa_match_payload_n<NW, MatchFmt<FMT>::value>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<NW>(args.filter, pl));
         const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
         if (hit && slot < args.match_cap) {
             DevMatch *m = args.mrec + slot;
