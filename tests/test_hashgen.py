@@ -58,22 +58,32 @@ def case_base58_check(rng):
     return m, hashlib.sha256(hashlib.sha256(bytes([version]) + h).digest()).digest()[:4][::-1]   # out[0] is a big-endian word
 
 
-CASES = {"base58_check_block": case_base58_check, "hash160_pub33_block": case_pub33, "hash160_script22_block": case_script22, "hash160_pub65_block": case_pub65}
+def case_keccak_addr(rng):
+    x, y = rng.getrandbits(256), rng.getrandbits(256)
+    xw, yw = words_le(x), words_le(y)
+    m = []
+    for w in (xw, yw):
+        for i in range(4):
+            m += [g.bswap(w[7 - 2 * i]), g.bswap(w[6 - 2 * i])]
+    return m, po.keccak256(x.to_bytes(32, "big") + y.to_bytes(32, "big"))[12:]
+
+
+CASES = {"keccak_addr_block": case_keccak_addr, "base58_check_block": case_base58_check, "hash160_pub33_block": case_pub33, "hash160_script22_block": case_script22, "hash160_pub65_block": case_pub65}
 
 
 def test_every_emitted_function_has_a_case():
-    assert set(CASES) == set(g.PROGRAMS)
+    assert set(CASES) == set(g.PROGRAMS) | set(g.OPTIONAL)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 @pytest.mark.parametrize("grouped,window,distance", [(False, 0, 1), (True, 0, 1), (False, 8, 1), (False, 16, 2)])
 def test_blocks_compute_the_hashes(name, grouped, window, distance):
     rng = random.Random(hash((name, grouped, window)) & 0xFFFF)
-    p, _, _ = g.PROGRAMS[name](grouped)
+    p, _, _ = {**g.PROGRAMS, **g.OPTIONAL}[name](grouped)
     if window:
         g.spread(p, window, distance)
     reg, nreg = g.allocate(p)
-    assert nreg <= 40                                   # the pair fits beside the point arithmetic's registers
+    assert nreg <= (80 if "keccak" in name else 40)     # the pair fits beside the point arithmetic's registers
     assert sorted(reg[i] for i in p.inputs) == list(range(len(p.inputs)))
     for _ in range(12):
         m, want = CASES[name](rng)

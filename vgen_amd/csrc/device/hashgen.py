@@ -20,7 +20,7 @@ profiles/r04_hash_blocks_ab.txt):
 The same instruction lists run in Python (`evaluate`, `evaluate_allocated`) for the CPU test-suite: tests/test_hashgen.py
 checks them, before and after register allocation, against hashlib and the oracle.
 
-usage: python3 hashgen.py [--order natural|grouped] [--yield every:N|dep|none] [--window W --distance D] > hash_blocks.inc
+usage: python3 hashgen.py [--order natural|grouped] [--yield every:N|dep|none] [--yield-for FUNCTION=MODE] [--with FUNCTION] [--window W --distance D] > hash_blocks.inc
 Algorithms restated from core/hash.h (reference: src/shaders/sha256.wgsl:43-170, src/shaders/ripemd160.wgsl:10-100)."""
 import sys
 
@@ -45,6 +45,11 @@ SR = [8, 9, 9, 11, 13, 15, 15, 5, 7, 7, 8, 11, 14, 14, 12, 6, 9, 13, 15, 7, 12, 
       11]
 KL = [0x00000000, 0x5A827999, 0x6ED9EBA1, 0x8F1BBCDC, 0xA953FD4E]
 KR = [0x50A28BE6, 0x5C4DD124, 0x6D703EF3, 0x7A6D76E9, 0x00000000]
+KECCAK_RHO = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]   # [x][y]
+KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808a, 0x8000000080008000, 0x000000000000808b, 0x0000000080000001,
+             0x8000000080008081, 0x8000000000008009, 0x000000000000008a, 0x0000000000000088, 0x0000000080008009, 0x000000008000000a,
+             0x000000008000808b, 0x800000000000008b, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+             0x000000000000800a, 0x800000008000000a, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
 TT_L = [0x96, 0xCA, 0x59, 0xE4, 0x2D]   # f1..f5 as v_bitop3 truth tables (core/hash.h VG_RMD_F1..F5)
 TT_R = [0x2D, 0xE4, 0x59, 0xCA, 0x96]
 
@@ -73,8 +78,8 @@ def known(v):
 class Program:
     """A straight-line list of instructions over virtual registers.
 
-    ins: (op, dst, srcs, imm) with op in alignbit(src; n) lshr(src; n) bitop3(a, b, c; tt) mov(k) add3(a, b, c) add(a, b) bswap(src);
-    a source is a virtual register name or an int (at most one int per instruction, never in alignbit/lshr/bswap)."""
+    ins: (op, dst, srcs, imm) with op in alignbit(hi, lo; n) lshr(src; n) bitop3(a, b, c; tt) mov(k) add3(a, b, c) add(a, b) xor(a, b)
+    bswap(src); a source is a virtual register name or an int (at most one int per instruction, never in lshr/bswap)."""
 
     def __init__(self, grouped=False):
         self.ins, self.inputs, self.outputs, self.n, self.grouped = [], [], [], 0, grouped
@@ -91,7 +96,22 @@ class Program:
 
     # ---- folding constructors ----------------------------------------------------------------------------------------
     def rotr(self, x, n):
-        return rotr(x, n) if known(x) else self.emit("alignbit", (x,), n)
+        return rotr(x, n) if known(x) else self.emit("alignbit", (x, x), n)
+
+    def funnel(self, hi, lo, n):
+        """Low word of the 64-bit value hi:lo shifted right by n (0 < n < 32): v_alignbit_b32."""
+        if known(hi) and known(lo):
+            return ((hi << 32 | lo) >> n) & M
+        return self.emit("alignbit", (hi, lo), n)
+
+    def xor(self, a, b):
+        if known(a) and known(b):
+            return a ^ b
+        if known(a):
+            a, b = b, a
+        if known(b) and b == 0:
+            return a
+        return self.emit("xor", (a, b))
 
     def rotl(self, x, n):
         return self.rotr(x, (32 - n) & 31) if n & 31 else x
@@ -205,6 +225,43 @@ class Program:
         self.ins = keep[::-1]
         return self
 
+    # ---- Keccak-f[1600] on 25 lanes of (lo, hi) word pairs ------------------------------------------------------------------
+    def rotl64(self, lane, n):
+        lo, hi = lane
+        if n == 0:
+            return lane
+        if n == 32:
+            return (hi, lo)
+        m = n & 31
+        a = self.funnel(hi, lo, 32 - m)     # (hi << m) | (lo >> (32 - m))
+        b = self.funnel(lo, hi, 32 - m)     # (lo << m) | (hi >> (32 - m))
+        return (b, a) if n < 32 else (a, b)
+
+    def bitop3_64(self, tt, a, b, c):
+        return (self.bitop3(tt, a[0], b[0], c[0]), self.bitop3(tt, a[1], b[1], c[1]))
+
+    def keccak_f1600(self, a):
+        """a: 25 lanes, index x + 5y.  Per round: the column parities as two xor3 each; `a ^ d` of every lane as one more xor3
+        (d = c[x-1] ^ rotl(c[x+1], 1) is never materialised); rho and pi; chi as the truth table 0xD2; one output row at a time,
+        so that a row's five source lanes die as they are read (core/hash.h keccak_round, restated)."""
+        a = list(a)
+        for rnd in range(24):
+            c = [self.bitop3_64(0x96, self.bitop3_64(0x96, a[x], a[x + 5], a[x + 10]), a[x + 15], a[x + 20]) for x in range(5)]
+            rc = [self.rotl64(c[x], 1) for x in range(5)]
+            n = [None] * 25
+            for Y in range(5):
+                b = []
+                for X in range(5):
+                    y = X
+                    x = ((Y - 3 * X) * 3) % 5            # pi: B[y][2x + 3y] = rot(A[x][y])
+                    t = self.bitop3_64(0x96, a[x + 5 * y], c[(x + 4) % 5], rc[(x + 1) % 5])
+                    b.append(self.rotl64(t, KECCAK_RHO[x][y]))
+                for X in range(5):
+                    n[X + 5 * Y] = self.bitop3_64(0xD2, b[X], b[(X + 1) % 5], b[(X + 2) % 5])
+            n[0] = (self.xor(n[0][0], KECCAK_RC[rnd] & M), self.xor(n[0][1], KECCAK_RC[rnd] >> 32))
+            a = n
+        return a
+
     # ---- statistics ------------------------------------------------------------------------------------------------------
     def census(self):
         c = {}
@@ -268,8 +325,30 @@ def prog_base58_check(grouped=False):
     return p, "u32 version, const u32 H[5]", prologue
 
 
+def prog_keccak_addr(grouped=False):
+    """Ethereum address: the low 20 bytes of Keccak-256(X || Y); inputs m0..m15 = the 16 message words, lane i = (m[2i], m[2i+1])
+    (core/hash.h keccak256_pub64_addr: one rate block, pre-SHA-3 padding); out = five words in memory order."""
+    p = Program(grouped)
+    lanes = [(p.input(f"m{2 * i}"), p.input(f"m{2 * i + 1}")) for i in range(8)] + [(0, 0)] * 17
+    lanes[8] = (1, 0)
+    lanes[16] = (0, 0x80000000)
+    a = p.keccak_f1600(lanes)
+    p.outputs = [a[1][1], a[2][0], a[2][1], a[3][0], a[3][1]]
+    p.prune()
+    prologue = []
+    for i in range(4):
+        prologue.append(f"u32 m{2 * i} = bswap32(xw[{7 - 2 * i}]), m{2 * i + 1} = bswap32(xw[{6 - 2 * i}]);")
+    for i in range(4):
+        prologue.append(f"u32 m{8 + 2 * i} = bswap32(yw[{7 - 2 * i}]), m{9 + 2 * i} = bswap32(yw[{6 - 2 * i}]);")
+    return p, "const u32 xw[8], const u32 yw[8]", prologue
+
+
 PROGRAMS = {"hash160_pub33_block": prog_pub33_h160, "hash160_script22_block": prog_script22_h160,
             "hash160_pub65_block": prog_pub65_h160, "base58_check_block": prog_base58_check}
+# Not emitted unless asked for (--with NAME): measured and not shipped (profiles/r04_hash_blocks_ab.txt; kernels.hip VG_KECCAK_BLOCK)
+OPTIONAL = {"keccak_addr_block": prog_keccak_addr}
+# yields per function where they differ from the default
+YIELDS = {"keccak_addr_block": "none"}
 
 
 # ---- the Python model of the instruction list (CPU tests) ---------------------------------------------------------------------
@@ -284,7 +363,9 @@ def evaluate(p, inputs):
     for op, d, srcs, imm in p.ins:
         s = [val(x) for x in srcs]
         if op == "alignbit":
-            r = rotr(s[0], imm)
+            r = ((s[0] << 32 | s[1]) >> imm) & M
+        elif op == "xor":
+            r = s[0] ^ s[1]
         elif op == "lshr":
             r = s[0] >> imm
         elif op == "bitop3":
@@ -419,7 +500,11 @@ def asm_lines(p, reg, yields="every:3"):
             nyield += 1
         prev_dst = d
         if op == "alignbit":
-            line = f"v_alignbit_b32 {D}, {r(srcs[0])}, {r(srcs[0])}, {imm}"
+            o = [const_operand(x) if known(x) else r(x) for x in srcs]
+            line = f"v_alignbit_b32 {D}, {o[0]}, {o[1]}, {imm}"
+        elif op == "xor":        # VOP2: a 32-bit literal is allowed in src0
+            a, b = srcs
+            line = f"v_xor_b32 {D}, {('0x%08x' % b) if known(b) else r(b)}, {r(a)}"
         elif op == "lshr":
             line = f"v_lshrrev_b32 {D}, {imm}, {r(srcs[0])}"
         elif op == "mov":
@@ -448,7 +533,7 @@ def asm_lines(p, reg, yields="every:3"):
 
 
 def function_source(name, grouped=False, yields="every:3", window=0, distance=1):
-    p, params, prologue = PROGRAMS[name](grouped)
+    p, params, prologue = {**PROGRAMS, **OPTIONAL}[name](grouped)
     left = spread(p, window, distance) if window else None
     reg, nreg = allocate(p)
     lines, valu, salu, nyield = asm_lines(p, reg, yields)
@@ -477,11 +562,11 @@ def function_source(name, grouped=False, yields="every:3", window=0, distance=1)
     return src
 
 
-def generate(grouped=False, yields="every:3", window=0, distance=1):
+def generate(grouped=False, yields="every:3", window=0, distance=1, overrides=None, extra=()):
     src = "// GENERATED by device/hashgen.py (`make -C vgen_amd/csrc hashblocks`) - do not edit.\n"
     src += "// The address hashes of the scan kernels as single asm statements of gfx950 instructions; see hashgen.py.\n\n"
-    for name in PROGRAMS:
-        src += function_source(name, grouped, yields, window, distance)
+    for name in list(PROGRAMS) + list(extra):
+        src += function_source(name, grouped, (overrides or {}).get(name, YIELDS.get(name, yields)), window, distance)
     return src
 
 
@@ -489,8 +574,10 @@ def main(argv):
     def opt(name, default):
         return argv[argv.index(name) + 1] if name in argv else default
 
+    overrides = dict(a.split("=", 1) for i, a in enumerate(argv) if i and argv[i - 1] == "--yield-for")   # --yield-for name=mode
     sys.stdout.write(generate(opt("--order", "natural") == "grouped", opt("--yield", "every:3"),
-                              int(opt("--window", "0")), int(opt("--distance", "1"))))
+                              int(opt("--window", "0")), int(opt("--distance", "1")), overrides,
+                              [a for i, a in enumerate(argv) if i and argv[i - 1] == "--with"]))
 
 
 if __name__ == "__main__":

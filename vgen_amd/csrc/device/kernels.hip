@@ -168,7 +168,13 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
     } else {  // VGF_ETHEREUM
         u32 yw[8];
         fe_to_words(y_canon, yw);
+#ifdef VG_KECCAK_BLOCK   // A/B only (hashgen.py --with keccak_addr_block): Keccak-f as one block of 4 195 instructions in 74 registers measured
+        // +0.7 % with a prefilter, -14 % on six images per point and -8 % under the on-device DFA (33 KB of straight-line code per
+        // copy against hipcc's rolled rounds; same instruction count: 5 003 per key either way) - profiles/r04_hash_blocks_ab.txt
+        keccak_addr_block(xw, yw, out);
+#else
         keccak256_pub64_addr(xw, yw, out);
+#endif
     }
     return true;
 }
