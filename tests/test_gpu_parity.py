@@ -195,7 +195,7 @@ def test_both_frames_and_repeat_are_consistent(vg, vo):
 
 
 @pytest.mark.parametrize("fmt,pattern", [(0, "^1Cat"), (1, "^bc1qaa")])
-def test_one_frame_contexts_run_the_variant_without_yields_and_find_the_same_keys(vg, vo, fmt, pattern):
+def test_one_frame_contexts_run_the_variant_without_yields_and_find_the_same_keys(vg, vo, fmt, pattern, monkeypatch):
     """A context with ONE frame in flight launches seq_bwd_kernel<.., LONE> (hipcc's schedule of core/hash.h instead of the
     scheduled hash block, kernels.hip: payload_from_point): dump and filter mode of both variants against the oracle."""
     batch = 1 << 16
@@ -204,7 +204,8 @@ def test_one_frame_contexts_run_the_variant_without_yields_and_find_the_same_key
     p = vg.Pattern(pattern, False, vg.AddressFormat(fmt))
     assert p.device_kind != 0
     found = []
-    for frames in (1, 3):
+    for frames, twin in ((1, "1"), (3, "1"), (1, "0")):      # the last: one frame, but the steady-state kernel (the counter passes' switch)
+        monkeypatch.setenv("VGEN_LONE_VARIANT", twin)
         r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=frames, match_cap=65536)
         r.set_filter(None)
         r.dispatch(start, 0)
@@ -216,7 +217,7 @@ def test_one_frame_contexts_run_the_variant_without_yields_and_find_the_same_key
             assert payload == ref[20 * i:20 * i + 20]
         found.append([i for i, payload in recs if p.matches(vg.address_from_payload(fmt, payload))])
         r.close()
-    assert found[0] == found[1]
+    assert found[0] == found[1] == found[2]
     assert found[0] == [i for i in range(batch) if p.matches(vg.address_from_payload(fmt, ref[20 * i:20 * i + 20]))]
 
 

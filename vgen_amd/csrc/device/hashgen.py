@@ -11,11 +11,12 @@ Two things are decided here rather than by hipcc, both measured in the real kern
 profiles/r04_hash_blocks_ab.txt):
   * the ORDER: the dependency order of the round functions.  hipcc interleaves rounds for instruction-level parallelism,
     which a SIMD holding four waves does not need; spreading dependent neighbours apart (`spread`) changes nothing either.
-  * the YIELDS: an `s_nop 0` after every third VALU instruction.  The wave gives up one issue slot; with launches of
-    several frames resident on a SIMD (the scan's steady state) the slot goes to another wave's instruction and the chip
-    retires 5-6 % more keys per second (12.4 -> 13.1 Gkeys/s); one yield per 2..4 instructions is the plateau, a yield
-    after every instruction loses again.  A launch that has the chip to itself at ONE wave per SIMD (2^20 keys, frames = 1)
-    pays 4 cycles per yield instead (+17 % on seq_bwd_kernel's 110 us) - the price of tuning for the steady state.
+  * the YIELDS: an `s_nop 0` after every third VALU instruction.  The wave gives up one issue slot; with four or more
+    waves on a SIMD (the scan's steady state) the chip retires 5-6 % more keys per second (12.4 -> 13.1 Gkeys/s; the hash
+    pair alone: +5.7 % at four waves per SIMD, +9.3 % at eight, tools/ubench_hash_yield.hip); one yield per 2..4
+    instructions is the plateau, a yield after every instruction loses again.  A launch that has the chip to itself at ONE
+    wave per SIMD (2^20 keys, frames = 1) would pay 4 cycles per yield (+17 % on seq_bwd_kernel's 110 us): such contexts
+    launch a twin of the kernel that keeps hipcc's schedule of core/hash.h (kernels.hip: LONE).
 
 The same instruction lists run in Python (`evaluate`, `evaluate_allocated`) for the CPU test-suite: tests/test_hashgen.py
 checks them, before and after register allocation, against hashlib and the oracle.

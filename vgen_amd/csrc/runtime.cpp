@@ -250,7 +250,10 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     c->timing = (p->flags & VGEN_FLAG_TIMING) != 0;
     c->endo = (p->flags & VGEN_FLAG_ENDO) != 0 && p->format != VGF_P2TR;
     c->S = env_u32("VGEN_SEQ_S", 8);
-    c->lone_variant = env_u32("VGEN_LONE_VARIANT", 1) != 0;   // 0: one-frame contexts launch the steady-state kernel too (counter passes: tools/pmc_valu.sh)
+    {   // "0": one-frame contexts launch the steady-state kernel too (counter passes: tools/pmc_valu.sh)
+        const char *v = getenv("VGEN_LONE_VARIANT");
+        c->lone_variant = !(v && v[0] == '0');
+    }
     auto bail = [&](int st, const std::string &m) {
         err = m;
         rt_destroy(c);
