@@ -1596,7 +1596,7 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
     if (full && a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), true, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     else if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     else if (a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
-    else if (a.lone && FMT == VGF_P2PKH) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2PKH ? FMT : VGF_P2PKH), false, false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
+    else if (a.lone && FMT == VGF_P2PKH) hipLaunchKernelGGL((seq_bwd_kernel<VGF_P2PKH, false, false, true>), dim3(a.groups), dim3(WG), 0, stream, a);   // one frame in flight: the twin without yields
     else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
     return hipGetLastError();
 }
