@@ -7,11 +7,10 @@
 //   lockstep   all waves start together (what one launch of the scan does),
 //   staggered  every workgroup first sleeps 0..3 quarters of a hash pair's duration (by a hash of its index), so that the four
 //              waves of a SIMD are at different places of the instruction list (what waves of different launches are) —
-// for  compiler  hipcc's schedule of core/hash.h,  block  the generated block without yields,  block_y3  with a yield per three.
+// for  compiler  hipcc's schedule of core/hash.h  and six generated blocks (default: no yields, a yield per 3 / 2 / 4 instructions, ...).
 //
-// Build: python3 vgen_amd/csrc/device/hashgen.py --yield none > tools/hb_none.inc
-//        python3 vgen_amd/csrc/device/hashgen.py --yield every:3 > tools/hb_y3.inc        (generated, not kept in the repository)
-//        hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_hash_yield.hip -o tools/ubench_hash_yield
+// Build: bash tools/ubench_hash_yield_gen.sh [six hashgen.py --yield modes]     (writes tools/hb_*.inc, tools/hb_labels.h: generated, not
+//        kept in the repository; then compiles tools/ubench_hash_yield)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -23,12 +22,26 @@
 
 using namespace vg;
 
-namespace hb_none {
-#include "hb_none.inc"
+// tools/ubench_hash_yield_gen.sh writes hb_0.inc .. hb_5.inc (one hashgen.py --yield mode each) and hb_labels.h (their names)
+namespace hb0 {
+#include "hb_0.inc"
 }
-namespace hb_y3 {
-#include "hb_y3.inc"
+namespace hb1 {
+#include "hb_1.inc"
 }
+namespace hb2 {
+#include "hb_2.inc"
+}
+namespace hb3 {
+#include "hb_3.inc"
+}
+namespace hb4 {
+#include "hb_4.inc"
+}
+namespace hb5 {
+#include "hb_5.inc"
+}
+#include "hb_labels.h"
 
 #define CHECK(x)                                                                                   \
     do {                                                                                           \
@@ -46,9 +59,17 @@ __device__ __forceinline__ void hashpair(u32 prefix, const u32 xw[8], u32 h[5]) 
         sha256_pub33(prefix, xw, sha);
         ripemd160_of_sha(sha, h);
     } else if (V == 1) {
-        hb_none::hash160_pub33_block(prefix, xw, h);
+        hb0::hash160_pub33_block(prefix, xw, h);
+    } else if (V == 2) {
+        hb1::hash160_pub33_block(prefix, xw, h);
+    } else if (V == 3) {
+        hb2::hash160_pub33_block(prefix, xw, h);
+    } else if (V == 4) {
+        hb3::hash160_pub33_block(prefix, xw, h);
+    } else if (V == 5) {
+        hb4::hash160_pub33_block(prefix, xw, h);
     } else {
-        hb_y3::hash160_pub33_block(prefix, xw, h);
+        hb5::hash160_pub33_block(prefix, xw, h);
     }
 }
 
@@ -82,7 +103,8 @@ typedef void (*kern_t)(u32 *, int, int, unsigned long long *);
 
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 512;
-    const struct { const char *name; kern_t k; } vars[] = {{"compiler", k_hash<0>}, {"block", k_hash<1>}, {"block_y3", k_hash<2>}};
+    const struct { const char *name; kern_t k; } vars[] = {{"compiler", k_hash<0>}, {HB_LABEL_0, k_hash<1>}, {HB_LABEL_1, k_hash<2>}, {HB_LABEL_2, k_hash<3>},
+                                                           {HB_LABEL_3, k_hash<4>}, {HB_LABEL_4, k_hash<5>}, {HB_LABEL_5, k_hash<6>}};
     u32 *dout;
     unsigned long long *dclk;
     hipDeviceProp_t prop;
@@ -105,7 +127,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "all variants agree with core/hash.h on %d keys\n", blocks * 256);
     }
     for (int w : {4, 2, 8}) {
-        for (int quarters : {0, 1, 2}) {
+        for (int quarters : {0, 2}) {
             for (const auto &v : vars) {
                 const int blocks = prop.multiProcessorCount * w;
                 hipEvent_t e0, e1;

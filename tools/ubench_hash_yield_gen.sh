@@ -1,0 +1,14 @@
+#!/bin/bash
+# Generates the six block variants of tools/ubench_hash_yield.hip and compiles it.
+# usage: bash tools/ubench_hash_yield_gen.sh [mode0 .. mode5]      (hashgen.py --yield modes; default below)
+cd "$(dirname "$0")"
+MODES=("${@:-none every:3 every:2 every:4 every:3:salu every:4:salu}")
+[ $# -eq 0 ] && MODES=(none every:3 every:2 every:4 every:3:salu every:4:salu)
+: > hb_labels.h
+for i in 0 1 2 3 4 5; do
+  M="${MODES[$i]}"; INSN="s_nop 0"
+  case "$M" in *"|"*) INSN="${M#*|}"; M="${M%%|*}";; esac      # "mode|instruction": another yield instruction
+  python3 ../vgen_amd/csrc/device/hashgen.py --yield "$M" --yield-insn "$INSN" > hb_$i.inc
+  echo "#define HB_LABEL_$i \"block ${MODES[$i]}\"" >> hb_labels.h
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed ubench_hash_yield.hip -o ubench_hash_yield

@@ -438,6 +438,9 @@ def spread(p, window=24, distance=1):
 
 # ---- register allocation and the asm text -------------------------------------------------------------------------------------
 
+YIELD_INSN = "s_nop 0"     # (--yield-insn: A/B of other ways to give the slot away)
+
+
 def inline_const(k):
     """gfx9 inline integer constants: 0..64 and -16..-1."""
     return k <= 64 or k >= (M + 1 - 16)
@@ -482,6 +485,7 @@ def asm_lines(p, reg, yields="every:3"):
     reads its result (what hipcc does around single-instruction asm statements), "none" nowhere."""
     out, valu, salu, nyield = [], 0, 0, 0
     prev_dst = None
+    last_yield_at = last_salu_at = 0
 
     def r(s):
         return f"%[r{reg[s]}]"
@@ -496,10 +500,25 @@ def asm_lines(p, reg, yields="every:3"):
 
     for op, d, srcs, imm in p.ins:
         D = r(d)
-        if prev_dst is not None and (yields == "dep" and prev_dst in srcs or yields.startswith("every:") and valu % int(yields[6:]) == 0):
-            out.append("s_nop 0")
+        if yields.startswith("every:"):
+            # "every:N": after every N-th VALU instruction; "every:N:salu": N VALU instructions after the last yield OR s_mov
+            # (a scalar instruction of the wave's own gives the slot away just as well)
+            parts = yields.split(":")
+            if len(parts) == 4:          # "every:N:from:to": only between VALU instructions `from` and `to` (A/B of the two hashes of a pair)
+                want = prev_dst is not None and int(parts[2]) <= valu < int(parts[3]) and valu % int(parts[1]) == 0
+            elif len(parts) == 3:
+                since = valu - max(last_yield_at, last_salu_at)
+                want = prev_dst is not None and since >= int(parts[1])
+            else:
+                want = prev_dst is not None and valu % int(parts[1]) == 0
+        else:
+            want = yields == "dep" and prev_dst is not None and prev_dst in srcs
+        if want:
+            out.append(YIELD_INSN)
             nyield += 1
+            last_yield_at = valu
         prev_dst = d
+        salu_before = salu
         if op == "alignbit":
             o = [const_operand(x) if known(x) else r(x) for x in srcs]
             line = f"v_alignbit_b32 {D}, {o[0]}, {o[1]}, {imm}"
@@ -530,6 +549,8 @@ def asm_lines(p, reg, yields="every:3"):
             raise ValueError(op)
         out.append(line)
         valu += 1
+        if salu != salu_before:
+            last_salu_at = valu - 1      # the s_mov sits in front of the instruction just emitted
     return out, valu, salu, nyield
 
 
@@ -575,6 +596,8 @@ def main(argv):
     def opt(name, default):
         return argv[argv.index(name) + 1] if name in argv else default
 
+    global YIELD_INSN
+    YIELD_INSN = opt("--yield-insn", YIELD_INSN)
     overrides = dict(a.split("=", 1) for i, a in enumerate(argv) if i and argv[i - 1] == "--yield-for")   # --yield-for name=mode
     sys.stdout.write(generate(opt("--order", "natural") == "grouped", opt("--yield", "every:3"),
                               int(opt("--window", "0")), int(opt("--distance", "1")), overrides,
