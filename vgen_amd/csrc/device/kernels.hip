@@ -265,6 +265,9 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 // Register budget: 4 waves per SIMD (128 VGPRs) for the 20-byte formats — four launches of different frames
 // then share a SIMD; Keccak (50 state registers) runs better at 3 waves without spills (6.16 vs 5.85 Gkeys/s),
 // the taproot path (a full scalar multiplication per key) keeps its ~240 registers (217 vs 197 Mkeys/s).
+#ifndef VG_SEQ_WAVES_P2PKH
+#define VG_SEQ_WAVES_P2PKH 4
+#endif
 #ifndef VG_SEQ_WAVES_P2SH
 #define VG_SEQ_WAVES_P2SH 4
 #endif
@@ -278,7 +281,7 @@ template <int FMT, bool FULL>
 struct SeqWaves {
     static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH
                                  : FULL ? VG_SEQ_WAVES_FULL20 : FMT == VGF_P2SH_P2WPKH ? VG_SEQ_WAVES_P2SH
-                                 : FMT == VGF_P2PKH_UNCOMPRESSED ? VG_SEQ_WAVES_UNCOMP : 4;
+                                 : FMT == VGF_P2PKH_UNCOMPRESSED ? VG_SEQ_WAVES_UNCOMP : VG_SEQ_WAVES_P2PKH;
 };
 
 // (The blocks that write a payload to the dump or the match ring, and the six-image loops of seq_bwd_kernel and keys_bwd_kernel,
