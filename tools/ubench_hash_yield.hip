@@ -52,24 +52,25 @@ namespace hb5 {
         }                                                                                          \
     } while (0)
 
+// HB_CALL_i(prefix, xw, h, fill): hb_labels.h - the variant's block, with the filler's sink where the variant carries multiply-adds
 template <int V>
-__device__ __forceinline__ void hashpair(u32 prefix, const u32 xw[8], u32 h[5]) {
+__device__ __forceinline__ void hashpair(u32 prefix, const u32 xw[8], u32 h[5], u32 *fill) {
     if (V == 0) {
         u32 sha[8];
         sha256_pub33(prefix, xw, sha);
         ripemd160_of_sha(sha, h);
     } else if (V == 1) {
-        hb0::hash160_pub33_block(prefix, xw, h);
+        HB_CALL_0(prefix, xw, h, fill);
     } else if (V == 2) {
-        hb1::hash160_pub33_block(prefix, xw, h);
+        HB_CALL_1(prefix, xw, h, fill);
     } else if (V == 3) {
-        hb2::hash160_pub33_block(prefix, xw, h);
+        HB_CALL_2(prefix, xw, h, fill);
     } else if (V == 4) {
-        hb3::hash160_pub33_block(prefix, xw, h);
+        HB_CALL_3(prefix, xw, h, fill);
     } else if (V == 5) {
-        hb4::hash160_pub33_block(prefix, xw, h);
+        HB_CALL_4(prefix, xw, h, fill);
     } else {
-        hb5::hash160_pub33_block(prefix, xw, h);
+        HB_CALL_5(prefix, xw, h, fill);
     }
 }
 
@@ -79,17 +80,17 @@ __global__ void __launch_bounds__(256) k_hash(u32 *out, int iters, int quarters,
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
     const u32 phase = ((blockIdx.x * 2654435761u) >> 13) & 3u;
     for (u32 i = 0; i < phase * (u32)quarters; i++) __builtin_amdgcn_s_sleep(127);
-    u32 xw[8], h[5] = {0, 0, 0, 0, 0};
+    u32 xw[8], h[5] = {0, 0, 0, 0, 0}, fill[1] = {0};
 #pragma unroll
     for (int i = 0; i < 8; i++) xw[i] = threadIdx.x * 0x9E3779B9u + blockIdx.x * 0x85EBCA6Bu + i;
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
-        hashpair<V>(2u | (h[0] & 1u), xw, h);
+        hashpair<V>(2u | (h[0] & 1u), xw, h, fill);
 #pragma unroll
         for (int i = 0; i < 5; i++) xw[i] ^= h[i];
         xw[5] += h[0]; xw[6] += h[1]; xw[7] += h[2];
     }
-    u32 r = 0;
+    u32 r = fill[0];
 #pragma unroll
     for (int i = 0; i < 5; i++) r ^= h[i];
     if (r == 0x12345678u || iters < 0) out[blockIdx.x * blockDim.x + threadIdx.x] = r;

@@ -554,11 +554,32 @@ def asm_lines(p, reg, yields="every:3"):
     return out, valu, salu, nyield
 
 
+FILLER = None   # (--filler seq:N | mix:N, micro-benchmark only: N multiply-adds of four independent chains after / spread through hash160_pub33_block)
+
+
+def add_filler(lines, mode, n):
+    """tools/ubench_hash_yield.hip: what the point arithmetic's multiply-adds cost beside the hash - in a phase of their own or mixed in."""
+    mads = [f"v_mad_u64_u32 %[p{i % 4}], vcc, %[q{i % 2}], %[q{(i // 2) % 2}], %[p{i % 4}]" for i in range(n)]
+    if mode == "seq":
+        return lines + mads
+    out, step, k = [], max(1, len(lines) // max(1, n)), 0
+    for i, l in enumerate(lines):
+        out.append(l)
+        if (i + 1) % step == 0 and k < n and l.startswith("v_"):     # never between an s_mov and the instruction that reads it
+            out.append(mads[k])
+            k += 1
+    return out + mads[k:]
+
+
 def function_source(name, grouped=False, yields="every:3", window=0, distance=1):
     p, params, prologue = {**PROGRAMS, **OPTIONAL}[name](grouped)
     left = spread(p, window, distance) if window else None
     reg, nreg = allocate(p)
     lines, valu, salu, nyield = asm_lines(p, reg, yields)
+    filler = FILLER if name == "hash160_pub33_block" else None
+    if filler:
+        lines = add_filler(lines, filler[0], filler[1])
+        params += ", u32 *fill"
     nin = len(p.inputs)
     nout = len(p.outputs)
     c = p.census()
@@ -573,11 +594,18 @@ def function_source(name, grouped=False, yields="every:3", window=0, distance=1)
     if nreg > nin:
         src += "    u32 " + ", ".join(f"r{i}" for i in range(nin, nreg)) + ";\n"
     src += "    u32 k;\n"
+    if filler:
+        src += "    u32 q0 = prefix | 1u, q1 = xw[0] | 1u;\n    unsigned long long p0 = q0, p1 = q1, p2 = q0 + 2u, p3 = q1 + 2u;\n"
     src += "    asm(\n"
     for l in lines:
         src += f'        "{l}\\n\\t"\n'
     ops = [f'[r{i}] "+v"(r{i})' for i in range(nin)] + [f'[r{i}] "=&v"(r{i})' for i in range(nin, nreg)] + ['[k] "=&s"(k)']
-    src += "        : " + ", ".join(ops) + ");\n"
+    if filler:
+        ops += [f'[p{i}] "+v"(p{i})' for i in range(4)]
+        src += "        : " + ", ".join(ops) + ' : [q0] "v"(q0), [q1] "v"(q1) : "vcc");\n'
+        src += "    fill[0] ^= (u32)(p0 ^ p1 ^ p2 ^ p3) ^ (u32)((p0 ^ p1 ^ p2 ^ p3) >> 32);\n"
+    else:
+        src += "        : " + ", ".join(ops) + ");\n"
     for j, o in enumerate(p.outputs):
         src += f"    out[{j}] = {('0x%08xu' % o) if known(o) else 'r%d' % reg[o]};\n"
     src += "}\n\n"
@@ -596,8 +624,11 @@ def main(argv):
     def opt(name, default):
         return argv[argv.index(name) + 1] if name in argv else default
 
-    global YIELD_INSN
+    global YIELD_INSN, FILLER
     YIELD_INSN = opt("--yield-insn", YIELD_INSN)
+    if "--filler" in argv:
+        mode, n = opt("--filler", "").split(":")
+        FILLER = (mode, int(n))
     overrides = dict(a.split("=", 1) for i, a in enumerate(argv) if i and argv[i - 1] == "--yield-for")   # --yield-for name=mode
     sys.stdout.write(generate(opt("--order", "natural") == "grouped", opt("--yield", "every:3"),
                               int(opt("--window", "0")), int(opt("--distance", "1")), overrides,
