@@ -24,10 +24,14 @@
 extern "C" {
 #endif
 
-#define VGEN_ABI_VERSION 3   /* 2: frames = 0 selects 12; vgen_get_topology reports streams / priority levels; vgen_dispatch_random;
+#define VGEN_ABI_VERSION 4   /* 2: frames = 0 selects 12; vgen_get_topology reports streams / priority levels; vgen_dispatch_random;
                                   vgen_scan_multi returns partial results beside an error
                                   3: vgen_get_resources; the fault-injection entry point left the library (test build only);
-                                  random-key streams take a 24-byte seed (vgen_dispatch_random_seed / vgen_random_key_seed) */
+                                  random-key streams take a 24-byte seed (vgen_dispatch_random_seed / vgen_random_key_seed)
+                                  4: the device-memory policy is the caller's: vgen_params.table_bits / device_mem_budget_bytes,
+                                  vgen_scan_config.table_bits_max, vgen_get_memory; generator tables are replaced in the
+                                  background, never by pausing a scan.  The ABI-3 layouts of vgen_params (28 bytes) and
+                                  vgen_scan_config (136 bytes) are still accepted (struct_size tells): the new fields read as 0 */
 
 typedef enum vgen_status {
     VGEN_OK = 0,
@@ -81,6 +85,22 @@ typedef struct vgen_params {
                               GPU_MAX_HW_QUEUES is; multiples of 4 balance the queue pools */
     uint32_t match_cap;    /* match records kept per dispatch in filter mode; 0 -> 4096 */
     uint32_t flags;        /* VGEN_FLAG_* */
+    /* ---- ABI 4: the device memory a context may take is the caller's decision, as in the reference, where a runner's device
+     * memory is a pure function of batch_size (64 B x N table + 200 B x N per frame, limits requested up front: src/gpu.rs:216-231,391-402).
+     * Here the frames are that function too (vgen_get_memory reports it); what is POLICY is the fixed-base generator table
+     * of the paths that multiply a scalar per key (P2TR, vgen_dispatch_keys, vgen_dispatch_random): wider tables are faster
+     * (24 bits: 11.8 GB, 10 additions per key; 27 signed: 21.5 GB, 9; 29 signed: 138 GB, 8: +12.5 %). */
+    uint32_t table_bits;   /* generator-table width for this context: 0 = automatic (24 bits; vgen_scan moves to 27 / 29 bits
+                              for scans long enough to pay for them, see vgen_scan_config.table_bits_max); else 8 | 16 | 20 |
+                              22 | 24 | 26 (unsigned windows) or 25 | 27 | 29 (signed windows): exactly this width, stepping
+                              down only when it cannot be allocated or passes the budget below */
+    uint64_t device_mem_budget_bytes;   /* upper bound on the device memory this context holds (its frames, dump / key buffers and
+                              the generator tables it references); 0 = automatic: the frames as sized by batch_size x frames, and
+                              no generator table larger than HALF of the device memory free when the table is chosen
+                              (hipMemGetInfo) — a device another tenant is using never loses 138 GB to a scan that "expects"
+                              to be long.  With a budget, vgen_create fails with VGEN_E_NOMEM when the frames alone pass it,
+                              later buffers (dump mode, arbitrary-scalar mode) fail the call that needs them, and the
+                              generator table steps down to the widest width that fits (vgen_get_resources says so). */
 } vgen_params;
 
 /* One candidate reported by the device filter.  key = start_key + index.  payload is the 20-byte
@@ -138,14 +158,36 @@ int vgen_get_topology(const vgen_ctx *ctx, uint32_t *streams, uint32_t *hw_queue
  *                       vgen_dispatch_random) use: 0 = none built yet (first use builds it), 8 = the 8-bit table only,
  *                       16 / 20 / 22 / 24 / 26 = the wide table in use (shared by all contexts of the process on this device);
  *                       odd values are SIGNED windows: 25 / 27 / 29 bits = 10 / 9 / 8 additions in 5.9 / 21.5 / 138 GB.
- *   *table_bits_wanted  the width asked for: VGEN_GTAB_BITS when set; else what vgen_scan chose for the scan's expected length
- *                       (>= 3 s of keys: 27, >= 30 s: 29; a context never steps back down by itself); else the default, 24.  *table_bits < *table_bits_wanted after a dispatch
- *                       means the allocation or build of the wider tables failed and the context stepped down (24 -> 22 ->
- *                       20 -> 16 -> 8): same keys, fewer per second (10 / 11 / 12 / 15 / 31 additions per multiplication).
+ *   *table_bits_wanted  the width asked for: vgen_params.table_bits when set; else what vgen_scan chose for the scan's expected length
+ *                       (>= 3 s of keys: 27, >= 30 s: 29, capped by vgen_scan_config.table_bits_max; a context never steps back
+ *                       down by itself); else the default, 24.  (The VGEN_GTAB_BITS environment variable overrides all three: a
+ *                       test switch, read once at vgen_create.)  A wider table than the one in use is built IN THE BACKGROUND — on a
+ *                       low-priority stream, by a thread of its own, while dispatches go on with the old table — and taken into
+ *                       use by the first dispatch after it is ready: *table_bits < *table_bits_wanted with an empty note means
+ *                       "on its way".  With a note it means the wider tables could not be had — allocation or build failed, the
+ *                       budget or the half-of-free-memory rule forbids them — and the context stepped down in order of
+ *                       (additions per multiplication, bytes): 29s -> 27s -> 26 -> 25s -> 24 -> 22 -> 20 -> 16 -> 8 (8 / 9 / 9 / 10 /
+ *                       10 / 11 / 12 / 15 / 31 additions): same keys, fewer per second.
  *   note                why it stepped down ("" when it did not), NUL-terminated, truncated to note_cap.
  * A step-down is not an error: the dispatch that caused it returned VGEN_OK and vgen_last_error is untouched. */
 int vgen_get_resources(const vgen_ctx *ctx, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted,
                        char *note, size_t note_cap);
+
+/* Device and pinned host memory of a context (the reference requests its buffer limits up front, src/gpu.rs:216-231, and sizes every
+ * buffer from batch_size, src/gpu.rs:391-402).  Fill struct_size before the call. */
+typedef struct vgen_memory_info {
+    uint32_t struct_size;        /* = sizeof(vgen_memory_info) */
+    uint32_t table_bits;         /* generator table in use (as vgen_get_resources) */
+    uint64_t frames_bytes;       /* device memory of the frames and per-context tables: scratch, match rings, offset table, filter (fixed at vgen_create) */
+    uint64_t mode_bytes;         /* device memory of buffers made at first use: dump mode's payload buffers, the arbitrary-scalar path's keys + scratch */
+    uint64_t table_bytes;        /* generator tables this context references (shared by the process's contexts on the device: counted in full
+                                    by each), including a retired one a dispatch in flight still reads and one being built */
+    uint64_t pinned_host_bytes;  /* page-locked host memory: match-ring mirrors, dump mirrors */
+    uint64_t budget_bytes;       /* vgen_params.device_mem_budget_bytes (0 = automatic) */
+    uint64_t device_free_bytes;  /* hipMemGetInfo now */
+    uint64_t device_total_bytes;
+} vgen_memory_info;
+int vgen_get_memory(const vgen_ctx *ctx, vgen_memory_info *out);
 
 /* ---- pattern: Pattern::new / Pattern::matches (src/pattern.rs:21-45) -------------------------------- */
 
@@ -318,6 +360,13 @@ typedef struct vgen_scan_config {
     const char *checkpoint_path;
     uint32_t checkpoint_interval_ms;   /* 0 = 10 s */
     uint32_t flags;                    /* VGEN_SCAN_* */
+    /* ---- ABI 4 ---- */
+    uint32_t table_bits_max;           /* scans that multiply a scalar per key (P2TR, VGEN_SCAN_RANDOM_KEYS): the widest generator table this
+                                          scan may move the context to — compared by additions per multiplication, so 24 also forbids 25 / 27 / 29 —;
+                                          0 = no cap beyond the context's memory policy (vgen_params.device_mem_budget_bytes).  The scan asks
+                                          for 27 bits from ~3 s and 29 bits from ~30 s of expected (or, after 5 s, observed) scanning; the table
+                                          is built in the background and the scan never waits for it. */
+    uint32_t reserved;                 /* 0 */
 } vgen_scan_config;
 
 /* vgen_scan_config.flags */
@@ -363,7 +412,7 @@ typedef void (*vgen_progress_cb)(uint64_t operations, void *user); /* ProgressCa
  * in ascending key order within a batch (gpu.rs:1095-1104), counts batch_size operations per
  * completed batch (gpu.rs:1106) and honours *stop between batches (gpu.rs:980-984,1007-1011). */
 int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
-              void *user, volatile int32_t *stop, vgen_scan_result *out);
+              void *user, const volatile int32_t *stop, vgen_scan_result *out);
 /* The same scan over several contexts (one per GPU of the node; the reference is single-adapter,
  * src/gpu.rs:161-165): one host thread per context, global batch b goes to context b mod n_ctx, a
  * shared match counter / stop flag, matches merged in ascending key order and truncated to count,
@@ -375,7 +424,7 @@ int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, v
  * VGEN_OK with out->failed_shards > 0 when the survivors covered everything (or `count` / the stop flag ended the scan),
  * and the first failure's status — with out still filled, complete = 0 — when no context was left to do so. */
 int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *pattern, const vgen_scan_config *cfg,
-                    vgen_progress_cb cb, void *user, volatile int32_t *stop, vgen_scan_result *out);
+                    vgen_progress_cb cb, void *user, const volatile int32_t *stop, vgen_scan_result *out);
 void vgen_scan_result_free(vgen_scan_result *r);
 
 #ifdef __cplusplus

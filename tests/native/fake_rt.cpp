@@ -239,11 +239,15 @@ int rt_device_name(int device, std::string &name, std::string &err) {
     return VGEN_OK;
 }
 
-int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
-    if (!p || !out || p->struct_size != sizeof(vgen_params)) {
+int rt_create(const vgen_params *p_in, vgen_ctx **out, std::string &err) {
+    if (!p_in || !out || (p_in->struct_size != sizeof(vgen_params) && p_in->struct_size != 28)) {   // ABI 4's block or ABI 3's 28 bytes
         err = "vgen_create: bad parameter block";
         return VGEN_E_INVALID;
     }
+    vgen_params p_full;
+    memset(&p_full, 0, sizeof p_full);
+    memcpy(&p_full, p_in, p_in->struct_size);
+    const vgen_params *p = &p_full;
     if (p->device != 0) {
         err = "device index out of range";
         return VGEN_E_NODEVICE;
@@ -473,7 +477,18 @@ int rt_frame_clock(vgen_ctx *, uint32_t, uint32_t *cycles, uint32_t *ticks) {
 }
 int rt_clock_probe_start(vgen_ctx *c, uint32_t) { return c->fail(VGEN_E_UNSUPPORTED, "fake runtime: no clock probe"); }
 int rt_clock_probe_read(vgen_ctx *c, double *) { return c->fail(VGEN_E_UNSUPPORTED, "fake runtime: no clock probe"); }
-void rt_prefer_table_bits(vgen_ctx *c, uint32_t bits) { c->gtab_bits_pref = bits; }   // (the stand-in multiplies on the host: nothing to build)
+void rt_prefer_table_bits(vgen_ctx *c, uint32_t bits, uint32_t cap) {   // (the stand-in multiplies on the host: nothing to build)
+    c->gtab_bits_pref = bits;
+    c->gtab_bits_cap = cap;
+}
+int rt_get_memory(const vgen_ctx *c, vgen_memory_info *out) {
+    if (!out || out->struct_size != sizeof(vgen_memory_info)) return VGEN_E_INVALID;
+    const uint32_t sz = out->struct_size;
+    memset(out, 0, sizeof *out);
+    out->struct_size = sz;
+    out->budget_bytes = c->mem_budget;
+    return VGEN_OK;
+}
 int rt_get_resources(const vgen_ctx *c, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note) {
     if (dump_frames) *dump_frames = c->dump_frames ? c->dump_frames : c->frames;
     if (table_bits) *table_bits = 0;      // (the stand-in multiplies on the host: no generator table)

@@ -917,7 +917,6 @@ def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypat
     (core/ec.h: ec_mul_gen_signed — a table of magnitudes, negative digits take (x, p - y); 29 bits: 8 additions, 138 GB): their
     scalars also walk the sign threshold, carries rippling through all-ones windows and the top window's magnitude that stands
     for the scalar 2^256 itself."""
-    monkeypatch.setenv("VGEN_GTAB_BITS", str(bits))
     import random
     rng = random.Random(bits)
     keys = [1, 2, N - 1, N - 2, 2**255, 0xFFFF, 0x10000, (1 << 200) + 5, (2**22 - 1) << 220, 2**256 - 1, 0, N] + [rng.randrange(1, N) for _ in range(500)]
@@ -945,7 +944,7 @@ def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypat
                     keys.append(k)
                     keys.append((k + rng.randrange(1, N)) % N or 1)      # the same digit among random ones: carries do not matter, digits are independent
     keys = [k for k in keys if k < 2**256]
-    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh)
+    r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2pkh, table_bits=bits)      # the caller's choice: vgen_params.table_bits ...
     r.set_filter(None)
     r.dispatch_keys(keys, 0)
     blob, _, tested = r.await_result(0)
@@ -955,6 +954,7 @@ def test_every_generator_table_width_gives_the_same_keys(vg, vo, bits, monkeypat
         assert blob[20 * i:20 * i + 20] == want, (bits, hex(k))
     assert r.resources()["table_bits"] == bits and r.resources()["note"] == ""      # the width asked for is the width in use
     r.close()
+    monkeypatch.setenv("VGEN_GTAB_BITS", str(bits))                                  # ... and the test override, read at vgen_create
     r = vg.GpuRunner(batch_size=8192, fmt=vg.AddressFormat.P2tr)
     start = vo.seed_key(bits, 3)
     assert dump(r, start) == vo.payload_seq(3, start, 8192)
@@ -1480,48 +1480,125 @@ def test_a_wide_generator_table_that_cannot_be_had_is_not_an_error(vgh, vo, monk
     assert s.returncode == 0 and "Warning: device" not in s.stderr and s.stdout == p.stdout
 
 
+def _scan_until_table(vg, r, pattern, cfg_kwargs, want_bits, timeout_s):
+    """Runs a scan under the host's stop flag until the context reports `want_bits` in use (plus a few batches on it), a note says
+    it will not come, or the timeout passes.  -> (result, [(t, operations, table_bits)])"""
+    import ctypes
+    import time
+    stop = ctypes.c_int32(0)
+    seen = []
+    t0 = time.perf_counter()
+    extra = [0]
+
+    def progress(ops):
+        rs = r.resources()
+        seen.append((time.perf_counter(), ops, rs["table_bits"]))
+        if rs["table_bits"] == want_bits or rs["note"]:
+            extra[0] += 1
+        if extra[0] >= 24 or time.perf_counter() - t0 > timeout_s:
+            stop.value = 1
+    res = vg.scan_gpu_with_runner(pattern, vg.ScanConfig(**cfg_kwargs), r, progress_cb=progress, stop=stop)
+    return res, seen
+
+
 def test_scan_picks_the_generator_table_its_expected_length_pays_for(vg, vo):
     """vgen_scan on the paths that multiply a scalar per key chooses the table by the keys it can expect to test: the default
-    24-bit table for short scans, the 27-bit signed one (9 additions, 60 ms to make) from ~3 s, the 29-bit signed one (8 additions,
-    138 GB, 0.7 - 2.3 s) from 30 s — and a context never steps back down by itself.  Results stay the oracle's either way."""
-    import ctypes
-    import threading
+    24-bit table for short scans, the 27-bit signed one (9 additions) from ~3 s, the 29-bit signed one (8 additions, 138 GB) from
+    30 s — as a PREFERENCE the runtime checks against the device's free memory and builds behind the dispatches: the scan starts on the
+    table it has and moves when the wider one is complete; a context never steps back down by itself; a device that is not empty may
+    refuse the 138 GB (then a note says so and the scan stays where it is).  Results stay the oracle's either way."""
     fmt = vg.AddressFormat.P2tr
     batch = 8192
-
-    def run(r, start, span, seconds=0.25):
-        stop = ctypes.c_int32(0)
-        t = threading.Timer(seconds, lambda: setattr(stop, "value", 1))
-        t.start()
-        res = vg.scan_gpu_with_runner("^bc1pq[qp]", vg.ScanConfig(format=fmt, count=None, start=start, end=start + span - 1), r, stop=stop)
-        t.cancel()
-        return res
     r = vg.GpuRunner(batch_size=batch, fmt=fmt, frames=2)
     start = vo.seed_key(31, 3)
-    res = run(r, start, 4 * batch, seconds=5)                 # 32 768 keys: microseconds of work -> the default table
-    assert res.complete and r.resources()["table_bits"] == 24 and r.resources()["table_bits_wanted"] == 24
+    res = vg.scan_gpu_with_runner("^bc1pq[qp]", vg.ScanConfig(format=fmt, count=None, start=start, end=start + 4 * batch - 1), r)
+    assert res.complete and r.resources()["table_bits"] == 24 and r.resources()["table_bits_wanted"] == 24   # 32 768 keys: the default table
     want = [x["address"] for x in vo.scan_range(3, "^bc1pq[qp]", start, start + 4 * batch - 1, count=10**9)["matches"]]
     assert [m.address for m in res.matches] == want and len(want) > 10
-    res = run(r, start, 2**33)                                # 8.6 G keys = ~6 s at 1.35 Gkeys/s -> 27 bits, signed
-    assert r.resources()["table_bits"] == 27 and res.operations >= batch
-    for m in res.matches[:40]:
-        assert vo.generate(3, int(m.hex, 16))["address"] == m.address
-    res = run(r, start, 2**40)                                # ~13 minutes of keys -> 29 bits, signed (138 GB)
+    # 8.6 G keys = ~6 s at 1.35 Gkeys/s -> 27 bits, signed: arrives in the background within the first second
+    res, seen = _scan_until_table(vg, r, "^bc1pq[qp]", dict(format=fmt, count=None, start=start, end=start + 2**33 - 1), 27, 20.0)
     rs = r.resources()
-    assert rs["table_bits"] == 29 and rs["table_bits_wanted"] == 29 and rs["note"] == "" and res.operations >= batch
+    assert rs["table_bits_wanted"] == 27 and (rs["table_bits"] == 27 or rs["note"]), rs
+    assert [w for _, _, w in seen][0] == 24 and res.operations >= batch      # ... and the scan began on the table it had
     for m in res.matches[:40]:
         assert vo.generate(3, int(m.hex, 16))["address"] == m.address
-    res = run(r, start, 4 * batch, seconds=5)                 # a short scan afterwards keeps the wide table: no stepping down
-    assert r.resources()["table_bits"] == 29 and [m.address for m in res.matches] == want
+    # ~13 minutes of keys -> 29 bits, signed (138 GB: only when half of the device's free memory covers it)
+    bits_before = rs["table_bits"]
+    res, seen = _scan_until_table(vg, r, "^bc1pq[qp]", dict(format=fmt, count=None, start=start, end=start + 2**40 - 1), 29, 60.0)
+    rs = r.resources()
+    mem = r.memory()
+    assert rs["table_bits_wanted"] == 29, rs
+    if rs["table_bits"] == 29:
+        assert rs["note"] == "" and mem["table_bytes"] > 130 * 10**9
+    else:   # a device somebody else is using: refused by the memory policy, said so, and the scan went on where it was
+        assert rs["table_bits"] == bits_before and "half of the" in rs["note"], rs
+    widths = [w for _, _, w in seen]
+    assert widths[0] == bits_before and all(a <= b for a, b in zip(widths, widths[1:]))     # never down, never a gap in the reports
+    assert [o for _, o, _ in seen] == [batch * (i + 1) for i in range(len(seen))]
+    for m in res.matches[:40] + res.matches[-40:]:
+        assert vo.generate(3, int(m.hex, 16))["address"] == m.address
+    final = rs["table_bits"]
+    res = vg.scan_gpu_with_runner("^bc1pq[qp]", vg.ScanConfig(format=fmt, count=None, start=start, end=start + 4 * batch - 1), r)
+    assert r.resources()["table_bits"] == final and [m.address for m in res.matches] == want   # a short scan afterwards: no stepping down
     r.close()
+
+
+def test_a_table_cap_and_a_memory_budget_bound_what_a_long_scan_takes(vg, vo):
+    """The caller's side of the policy (vgen_scan_config.table_bits_max, vgen_params.device_mem_budget_bytes, vgen_params.table_bits):
+    a scan that expects to run for 40 s stays on 24 bits when capped there, stays within a 1 GB budget on a table of at most 20
+    bits (872 MB) — with the oracle's results —, a context created with table_bits = 22 uses exactly that, a budget the frames
+    alone pass fails vgen_create, and vgen_get_memory accounts for all of it."""
+    fmt = vg.AddressFormat.P2tr
+    batch = 8192
+    start = vo.seed_key(32, 4)
+    want = [x["address"] for x in vo.scan_range(3, "^bc1pq[qp]", start, start + 4 * batch - 1, count=10**9)["matches"]]
+    span = 2**36      # ~51 s of keys at 1.35 Gkeys/s: the scan would ask for 29 bits
+
+    def short_run(r, **kw):
+        import ctypes
+        import threading
+        stop = ctypes.c_int32(0)
+        t = threading.Timer(0.6, lambda: setattr(stop, "value", 1))
+        t.start()
+        res = vg.scan_gpu_with_runner("^bc1pq[qp]", vg.ScanConfig(format=fmt, count=None, start=start, end=start + span - 1, **kw), r, stop=stop)
+        t.cancel()
+        return res
+    # capped by the scan
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, frames=2)
+    res = short_run(r, table_bits_max=24)
+    rs = r.resources()
+    assert rs["table_bits"] == 24 and rs["table_bits_wanted"] == 24 and rs["note"] == "", rs
+    assert [m.address for m in res.matches[:len(want)]] == want
+    m = r.memory()
+    assert 11 * 10**9 < m["table_bytes"] < 13 * 10**9 and m["budget_bytes"] == 0 and m["frames_bytes"] > 0 and m["device_total_bytes"] > 200 * 10**9
+    r.close()
+    # bounded by the context's budget: 1 GB holds the frames (a few MB at this batch size) and the 20-bit table, nothing wider
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, frames=2, device_mem_budget_bytes=10**9)
+    res = short_run(r)
+    rs, m = r.resources(), r.memory()
+    assert rs["table_bits"] <= 22 and rs["table_bits"] == 20 and "device_mem_budget_bytes" in rs["note"], rs
+    assert m["frames_bytes"] + m["mode_bytes"] + m["table_bytes"] <= 10**9 and m["budget_bytes"] == 10**9, m
+    assert [x.address for x in res.matches[:len(want)]] == want
+    r.close()
+    # a width by name
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, frames=2, table_bits=22)
+    res = short_run(r)
+    assert r.resources()["table_bits"] == 22 and r.resources()["table_bits_wanted"] == 22
+    assert [x.address for x in res.matches[:len(want)]] == want
+    r.close()
+    # a budget the frames themselves pass
+    with pytest.raises(vg.VgenError, match="does not cover the frames"):
+        vg.GpuRunner(batch_size=1 << 20, fmt=fmt, frames=12, device_mem_budget_bytes=10**8)
 
 
 def test_a_scan_that_turns_out_long_moves_to_the_wide_table_on_the_way(vg, vo):
     """A taproot scan whose pattern gives the loop no estimate (the whole DFA on the device, a count it will not reach) starts on the
-    default table; after five seconds it drains its frames once, builds the 29-bit signed table and goes on — the matches from both
-    sides of the switch are the oracle's, in key order, none lost or doubled at the seam."""
+    default table; after five seconds it asks for the 29-bit signed table, which is allocated by a thread of its own and built in
+    slices that ride in front of the scan's own dispatches — the scan never pauses (no gap between two finished batches beyond a few
+    batch times), the matches from both sides of the switch are the oracle's, in key order, none lost or doubled at the seam.  (Here
+    the scan is capped at 27 bits — 21.5 GB instead of 138 — so that the test also runs on a device that is not empty.)"""
     import ctypes
-    import threading
+    import time
     fmt = vg.AddressFormat.P2tr
     r = vg.GpuRunner(batch_size=1 << 18, fmt=fmt, frames=4)
     pat = vg.Pattern("qqqqq", False, fmt)
@@ -1529,24 +1606,35 @@ def test_a_scan_that_turns_out_long_moves_to_the_wide_table_on_the_way(vg, vo):
     start = vo.seed_key(77, 7)
     stop = ctypes.c_int32(0)
     seen = []
+    after = [0]
 
     def progress(ops):
-        seen.append((time.perf_counter(), ops, r.resources()["table_bits"]))
-    import time
-    t = threading.Timer(7.0, lambda: setattr(stop, "value", 1))
-    t.start()
-    res = vg.scan_gpu_with_runner("qqqqq", vg.ScanConfig(format=fmt, count=10**9, start=start), r, progress_cb=progress, stop=stop)
-    t.cancel()
+        rs = r.resources()
+        seen.append((time.perf_counter(), ops, rs["table_bits"]))
+        if rs["table_bits"] == 27 or rs["note"]:
+            after[0] += 1
+        if after[0] > 1500 or time.perf_counter() - seen[0][0] > 40.0:
+            stop.value = 1
+    res = vg.scan_gpu_with_runner("qqqqq", vg.ScanConfig(format=fmt, count=10**9, start=start, table_bits_max=27), r, progress_cb=progress, stop=stop)
     widths = [w for _, _, w in seen]
-    assert widths[0] == 24 and widths[-1] == 29 and sorted(set(widths)) == [24, 29], sorted(set(widths))
-    switch = next(i for i, w in enumerate(widths) if w == 29)
-    assert seen[switch][1] - seen[switch - 1][1] == 1 << 18          # operations advance batch by batch across the seam
+    assert widths[0] == 24 and widths[-1] == 27 and sorted(set(widths)) == [24, 27], (sorted(set(widths)), r.resources())
+    switch = next(i for i, w in enumerate(widths) if w == 27)
+    assert seen[switch][0] - seen[0][0] > 5.0                           # asked for after five seconds, there some time later
+    assert [o for _, o, _ in seen] == [(i + 1) << 18 for i in range(len(seen))]   # operations advance batch by batch across the seam
+    # no pause: batch completions keep coming while the table is allocated, built and switched to
+    gaps = [b[0] - a[0] for a, b in zip(seen, seen[1:])]
+    steady = sorted(gaps[:switch // 2])[len(gaps[:switch // 2]) // 2]
+    t_ask = seen[0][0] + 5.0
+    during = [g for (a, g) in zip(seen, gaps) if a[0] >= t_ask - 0.5]
+    print(f"table switch: steady batch interval {steady * 1e3:.3f} ms, longest interval from the request to the end {max(during) * 1e3:.3f} ms, "
+          f"switch {seen[switch][0] - t_ask:.2f} s after the request")
+    assert max(during) < max(8 * steady, 0.004), (steady, max(during))
     keys = [int(m.hex, 16) for m in res.matches]
     assert keys == sorted(keys) and len(set(keys)) == len(keys) and all(start <= k < start + res.operations for k in keys)
     ops_at_switch = seen[switch - 1][1]
     before = [k for k in keys if k < start + ops_at_switch]
-    after = [k for k in keys if k >= start + ops_at_switch]
-    assert len(before) > 50 and len(after) > 20, (len(before), len(after))
+    behind = [k for k in keys if k >= start + ops_at_switch]
+    assert len(before) > 50 and len(behind) > 20, (len(before), len(behind))
     ore = vo.Regex("qqqqq", False)
     for m in res.matches[::max(1, len(res.matches) // 150)] + res.matches[-20:]:
         g = vo.generate(3, int(m.hex, 16))

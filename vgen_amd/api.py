@@ -57,7 +57,13 @@ class AddressFormat(enum.IntEnum):
 class _Params(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("batch_size", ctypes.c_uint32),
                 ("format", ctypes.c_uint32), ("frames", ctypes.c_uint32), ("match_cap", ctypes.c_uint32),
-                ("flags", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32), ("table_bits", ctypes.c_uint32), ("device_mem_budget_bytes", ctypes.c_uint64)]
+
+
+class _MemoryInfo(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("table_bits", ctypes.c_uint32), ("frames_bytes", ctypes.c_uint64),
+                ("mode_bytes", ctypes.c_uint64), ("table_bytes", ctypes.c_uint64), ("pinned_host_bytes", ctypes.c_uint64),
+                ("budget_bytes", ctypes.c_uint64), ("device_free_bytes", ctypes.c_uint64), ("device_total_bytes", ctypes.c_uint64)]
 
 
 class _Match(ctypes.Structure):
@@ -70,7 +76,7 @@ class _ScanConfig(ctypes.Structure):
                 ("has_end", ctypes.c_int32), ("end", ctypes.c_uint8 * 32), ("seed", ctypes.c_uint64),
                 ("shard", ctypes.c_uint32), ("n_shards", ctypes.c_uint32), ("max_batches", ctypes.c_uint64),
                 ("checkpoint_path", ctypes.c_char_p), ("checkpoint_interval_ms", ctypes.c_uint32),
-                ("flags", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32), ("table_bits_max", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 SCAN_RANDOM_KEYS = 1   # VGEN_SCAN_RANDOM_KEYS
@@ -120,6 +126,7 @@ if hasattr(_L, "vgen_debug_fail_after"):   # only the test build (tests/native/l
 _L.vgen_dispatch_random_seed.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64]
 _L.vgen_random_key_seed.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
 _L.vgen_get_resources.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint32)] * 3 + [ctypes.c_char_p, ctypes.c_size_t]
+_L.vgen_get_memory.argtypes = [ctypes.c_void_p, ctypes.POINTER(_MemoryInfo)]
 _L.vgen_dispatch_random.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
 _L.vgen_random_key.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p]
 _L.vgen_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_Match), ctypes.c_uint32,
@@ -331,6 +338,7 @@ class ScanConfig:
     checkpoint_path: Optional[str] = None      # resumable scans (vgen_scan_config.checkpoint_path)
     checkpoint_interval_ms: int = 0
     random_keys: bool = False       # VGEN_SCAN_RANDOM_KEYS: an independent random key per candidate (scanner.rs:118-169's shape)
+    table_bits_max: int = 0         # widest generator table the scan may move the context to (0 = the context's memory policy decides)
 
 
 @dataclass
@@ -350,10 +358,13 @@ class GpuRunner:
     """GpuRunner (src/gpu.rs:116-131): one device, `frames` dispatches in flight."""
 
     def __init__(self, batch_size: int = 1 << 20, fmt: AddressFormat = AddressFormat.P2pkh, device: int = 0,
-                 frames: int = 2, match_cap: int = 4096, timing: bool = True, endo: bool = False):
+                 frames: int = 2, match_cap: int = 4096, timing: bool = True, endo: bool = False, table_bits: int = 0,
+                 device_mem_budget_bytes: int = 0):
         # timing: VGEN_FLAG_TIMING — events around every dispatch so that kernel_ms() / dispatch_ms() work
         # endo: VGEN_FLAG_ENDO — six keys per curve point (vanity searches on compressed-key formats)
-        p = _Params(ctypes.sizeof(_Params), device, batch_size, int(fmt), frames, match_cap, (1 if timing else 0) | (2 if endo else 0))
+        # table_bits / device_mem_budget_bytes: the generator-table width and the device-memory bound of this context (0 = automatic)
+        p = _Params(ctypes.sizeof(_Params), device, batch_size, int(fmt), frames, match_cap, (1 if timing else 0) | (2 if endo else 0),
+                    table_bits, device_mem_budget_bytes)
         h = ctypes.c_void_p()
         _check(_L.vgen_create(ctypes.byref(p), ctypes.byref(h)))
         self._h = h
@@ -412,6 +423,13 @@ class GpuRunner:
         note = ctypes.create_string_buffer(256)
         _check(_L.vgen_get_resources(self._h, ctypes.byref(d), ctypes.byref(b), ctypes.byref(w), note, 256), self._h)
         return {"dump_frames": d.value, "table_bits": b.value, "table_bits_wanted": w.value, "note": note.value.decode()}
+
+    def memory(self):
+        """vgen_get_memory -> dict of the context's device / pinned host bytes, its budget and the device's free / total bytes."""
+        m = _MemoryInfo()
+        m.struct_size = ctypes.sizeof(_MemoryInfo)
+        _check(_L.vgen_get_memory(self._h, ctypes.byref(m)), self._h)
+        return {k: getattr(m, k) for k, _ in _MemoryInfo._fields_ if k != "struct_size"}
 
     def dispatch_random(self, seed, stream: int, first_index: int, frame: int):
         """vgen_dispatch_random: batch_size independent random keys drawn on the device from the counter-based stream.
@@ -490,6 +508,7 @@ def scan_gpu_with_runner(pattern: str, config: ScanConfig, runner,
         c.checkpoint_path = os.fsencode(config.checkpoint_path)
         c.checkpoint_interval_ms = config.checkpoint_interval_ms
     c.flags = SCAN_RANDOM_KEYS if config.random_keys else 0
+    c.table_bits_max = config.table_bits_max
     res = _ScanResult()
     cb = _PROGRESS(lambda ops, _u: progress_cb(ops)) if progress_cb else ctypes.cast(None, _PROGRESS)
     stop_p = ctypes.byref(stop) if stop is not None else None

@@ -74,6 +74,11 @@ int vgen_get_resources(const vgen_ctx *ctx, uint32_t *dump_frames, uint32_t *tab
     return rc;
 }
 
+int vgen_get_memory(const vgen_ctx *ctx, vgen_memory_info *out) {
+    if (!ctx || !out) return VGEN_E_INVALID;
+    return vg::rt_get_memory(ctx, out);
+}
+
 int vgen_filter_compile(const char *pattern, int case_insensitive, uint32_t format, vgen_filter **out) {
     if (!pattern || !out) return VGEN_E_INVALID;
     vgen_filter *f = new vgen_filter();

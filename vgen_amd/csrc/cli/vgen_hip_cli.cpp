@@ -37,6 +37,8 @@ struct Opts {
     bool no_endo = false;
     bool random_keys = false;
     uint32_t batch = 1u << 20, frames = 12;   // twelve frames own twelve hardware queues (runtime.cpp)
+    uint32_t table_bits_max = 0;              // vgen_scan_config.table_bits_max (0 = the context's memory policy decides)
+    uint64_t mem_budget = 0;                  // vgen_params.device_mem_budget_bytes (0 = automatic)
     int puzzle = 0;
     long prefix_length = -1;   // -l / --prefix-length (provider patterns)
 };
@@ -185,6 +187,10 @@ void usage() {
             "                    [--seed S]            (a reproducible search: base key / candidate stream derived from the 64-bit S —\n"
             "                                           for tests and benchmarks; keys found this way are only as secret as S)\n"
             "                    [--checkpoint FILE]   (resume an interrupted scan from FILE; written as the scan runs)\n"
+            "                    [--mem-budget-gib G]  (device memory each context may hold; default: its frames, and no generator table\n"
+            "                                           larger than half of the device's free memory)\n"
+            "                    [--table-bits-max B]  (P2TR / --random-keys: the widest generator table a long scan may move to —\n"
+            "                                           24: 11.8 GB, 27: 21.5 GB, 29: 138 GB (+12.5 %%); built behind the scan, never waited for)\n"
             "                    [--no-endo]           (unseeded searches, any format but P2TR, test six keys per curve\n"
             "                                           point — k, lambda k, lambda^2 k and their negations; this walks k0 + i only)\n"
             "                    [--random-keys]       (an independent random key per candidate, drawn on the device — the shape of\n"
@@ -210,7 +216,8 @@ Opts parse(int argc, char **argv) {
     // it starts with (`-p -abc` is the pattern "-abc", not three flags).
     static const char *const long_with_value[] = {"--pattern", "--format", "--count", "--output", "--file", "--gpu-batch-size", "--repeat",
                                                   "--seed", "--devices", "--frames", "--checkpoint", "--range", "--puzzle", "--key", "--address",
-                                                  "--prefix-length", "--provider-table", "--threads", "--backend", "--cpu-batch-size"};
+                                                  "--prefix-length", "--provider-table", "--threads", "--backend", "--cpu-batch-size", "--table-bits-max",
+                                                  "--mem-budget-gib"};
     static const char short_with_value[] = "pfcorkaltT";
     std::vector<std::string> args;
     bool next_is_value = false;
@@ -265,6 +272,8 @@ Opts parse(int argc, char **argv) {
         else if (a == "--devices") o.devices = val();
         else if (a == "--frames") o.frames = (uint32_t)strtoul(val().c_str(), nullptr, 10);
         else if (a == "--checkpoint") o.checkpoint = val();
+        else if (a == "--table-bits-max") o.table_bits_max = (uint32_t)strtoul(val().c_str(), nullptr, 10);
+        else if (a == "--mem-budget-gib") o.mem_budget = (uint64_t)(strtod(val().c_str(), nullptr) * 1073741824.0);
         else if (a == "-r" || a == "--range") o.range = val();
         else if (a == "--puzzle") o.puzzle = atoi(val().c_str());
         else if (a == "-k" || a == "--key") o.key = val();
@@ -445,6 +454,7 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         p.batch_size = o.batch;
         p.format = (uint32_t)fmt;
         p.frames = o.frames;
+        p.device_mem_budget_bytes = o.mem_budget;
         // a vanity search proper — random base, no range, no seed, no checkpoint — may test any keys it likes:
         // six images per curve point (VGEN_FLAG_ENDO, +30 % keys per second); everything else walks k0 + i
         // (--random-keys: six keys per draw; seeds name candidate streams there, so they do not rule it out)
@@ -461,6 +471,7 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
     cfg.count = o.count == 0 ? UINT64_MAX : o.count;   // lib.rs:524
     cfg.case_insensitive = o.ignore_case;
     cfg.seed = o.seed;
+    cfg.table_bits_max = o.table_bits_max;
     // every key a seeded search returns is a function of the 64-bit seed and a small counter: whoever learns the address can
     // replay the search (unseeded searches draw 256 / 192 bits from the OS, as the reference does: src/gpu.rs:936-945, scanner.rs:144)
     if (o.seed && !has_range && !o.quiet)
@@ -497,7 +508,8 @@ int run_search(const Opts &o, const std::string &pattern, bool has_range, const 
         for (size_t i = 0; i < ctxs.size() && rep == 0; i++) {
             uint32_t bits = 0, wanted = 0;
             char note[256] = "";
-            if (vgen_get_resources(ctxs[i], nullptr, &bits, &wanted, note, sizeof note) == VGEN_OK && bits && bits < wanted && note[0])
+            // (a note exists only for a table the context could NOT have: widths are not comparable as numbers — 27 signed bits beat 26)
+            if (vgen_get_resources(ctxs[i], nullptr, &bits, &wanted, note, sizeof note) == VGEN_OK && bits && bits != wanted && note[0])
                 fprintf(stderr, "Warning: device %zu: %s\n", i, note);
         }
         for (uint64_t i = 0; i < res.n_matches; i++) all.push_back(res.matches[i]);

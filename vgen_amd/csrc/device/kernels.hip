@@ -37,6 +37,9 @@
 //     (profiles/r02_queue_sweep.txt: 11.4 instead of 9.5 Gkeys/s at four frames).
 #include <hip/hip_runtime.h>
 
+#ifndef VG_PARK
+#define VG_PARK 0
+#endif
 #define VG_HASH_BLOCKS 1   // core/dfa_eval.h: base58_checksum runs as a scheduled block too (hash_blocks.inc below)
 #include "../core/dfa_eval.h"
 #include "../core/ec.h"
@@ -301,6 +304,10 @@ seq_bwd_kernel(const SeqArgs args) {
     __shared__ u32 ypark[ENDO && (FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM) ? 9 * WG : 1];   // ENDO: the point's y
     extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
     constexpr int NW = PayloadWords<FMT>::value;
+    // PARK: the lane's table point R_u and the running inverse live in LDS between their uses instead of in 27 registers (LDS reads
+    // issue beside the VALU, not through it), so that the prefilter kernels of the compressed-key formats fit VG_SEQ_WAVES_P2PKH > 4
+    constexpr bool PARK = VG_PARK && !FULL && !ENDO && !LONE && (FMT == VGF_P2PKH || FMT == VGF_P2WPKH);
+    __shared__ u32 rpark[PARK ? 17 * WG : 1];   // (R.y's top limb stays in a register: 26 KB of LDS per workgroup lets six share a CU)
     const int tid = threadIdx.x;
     const GenTables gtab{args.gtab, args.gtab16, args.gtab_bits};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache / HBM)
     u32 *dfa_lds = dyn_lds;
@@ -348,13 +355,22 @@ seq_bwd_kernel(const SeqArgs args) {
         for (int i = 0; i < 9; i++) sib.n[i] = args.pre[(size_t)((S - 1) * 9 + i) * lanes + (u ^ 1u)];
         fe_mul(inv, ip, sib);
     }
-    if (ENDO) __syncthreads();   // every lane has read its pair's inverse: the tree's LDS now parks the x of the point in hand
+    if (ENDO || PARK) __syncthreads();   // every lane has read its pair's inverse: the tree's LDS now parks the x of the point in hand (PARK: the running inverse)
 
     fe rx, ry;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         rx.n[i] = args.rtab[(size_t)i * lanes + u];
         ry.n[i] = args.rtab[(size_t)(9 + i) * lanes + u];
+    }
+    if (PARK) {
+        lds_park_fe(rpark, WG, tid, rx);
+        {
+            lds_vu32 *b = (lds_vu32 *)(rpark + 9 * WG);
+#pragma unroll
+            for (int i = 0; i < 8; i++) b[i * WG + tid] = ry.n[i];
+        }
+        lds_park_fe(tree, WG, tid, inv);
     }
 
     const u32 half = args.n >> 1;
@@ -366,6 +382,10 @@ seq_bwd_kernel(const SeqArgs args) {
     for (int j = (int)S - 1; j >= 0; j--) {
         const DevSeqQ &q = args.q[j];
         fe dx, idx;
+        if (PARK) {
+            lds_unpark_fe(rpark, WG, tid, rx);
+            lds_unpark_fe(tree, WG, tid, inv);
+        }
 #pragma unroll
         for (int i = 0; i < 9; i++) dx.n[i] = rx.n[i] + q.nqx[i];
         if (j > 0) {
@@ -374,15 +394,18 @@ seq_bwd_kernel(const SeqArgs args) {
             for (int i = 0; i < 9; i++) pj.n[i] = pre[(size_t)((j - 1) * 9 + i) * lanes];
             fe_mul(idx, inv, pj);
             fe_mul(inv, inv, dx);
+            if (PARK) lds_park_fe(tree, WG, tid, inv);
         } else {
             idx = inv;
         }
         // -R.x and -R.y are recomputed where needed (9 subtractions each) instead of living in 18 registers
         // across the loop; the empty asm keeps the compiler from hoisting them back out as loop invariants.
+        if (!PARK) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            asm volatile("" : "+v"(rx.n[i]));
-            asm volatile("" : "+v"(ry.n[i]));
+            for (int i = 0; i < 9; i++) {
+                asm volatile("" : "+v"(rx.n[i]));
+                asm volatile("" : "+v"(ry.n[i]));
+            }
         }
         fe nsum, nqy;   // -(R.x + Q.x) (magnitude 3) and -Q.y, shared by the +R and -R results
         fe_neg(nsum, rx, 1);
@@ -395,6 +418,11 @@ seq_bwd_kernel(const SeqArgs args) {
         for (int sgn = 0; sgn < 2; sgn++) {
             // +R: dy = R.y - Q.y ; -R: dy = -R.y - Q.y
             fe dy, lam, x3, t, y3;
+            if (PARK) {
+                lds_vu32 *b = (lds_vu32 *)(rpark + 9 * WG);
+#pragma unroll
+                for (int i = 0; i < 8; i++) ry.n[i] = b[i * WG + tid];
+            }
             if (sgn) fe_neg(dy, ry, 1);
             else dy = ry;
 #pragma unroll
@@ -1126,8 +1154,8 @@ static hipError_t launch_keys_fmt(const KeysArgs &a, hipStream_t stream, hipEven
 // normalises with its own inversion (~610 field multiplications per entry: 1 M entries ~3 ms of the chip, once per
 // context).  Entries whose scalar would not fit 256 bits (top window) are never addressed and stay unwritten.
 // Output: eight little-endian words of x, eight of y per entry (core/ec.h: ec_mul_gen_wide).
-__global__ void __launch_bounds__(256) gen_table_wide_kernel(const u32 *tab8, u32 *tab, u32 bits, unsigned long long entries) {
-    const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) gen_table_wide_kernel(const u32 *tab8, u32 *tab, u32 bits, unsigned long long entries, unsigned long long first) {
+    const unsigned long long idx = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= entries) return;
     const unsigned long long per = (1ull << bits) - 1ull;
     const u32 w = (u32)(idx / per);
@@ -1169,8 +1197,8 @@ __global__ void __launch_bounds__(256) gen_table_wide_kernel(const u32 *tab8, u3
 // cold first P2TR match waits for.  No pair is exceptional: d_lo 2^(bits w) = +/- d_hi 2^(bits w + h) has no
 // solution with d_lo < 2^h.  Digits whose scalar would not fit 256 bits are skipped as in the one-level kernel.
 constexpr int GT_K = 8;   // digits per lane
-__global__ void __launch_bounds__(256) gen_table_combine_kernel(const u32 *small, u32 *tab, u32 bits, unsigned long long groups) {
-    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) gen_table_combine_kernel(const u32 *small, u32 *tab, u32 bits, unsigned long long groups, unsigned long long first) {
+    const unsigned long long g = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= groups) return;
     const u32 h = bits >> 1;
     const unsigned long long per = (1ull << bits) - 1ull, per_h = (1ull << h) - 1ull;
@@ -1304,8 +1332,8 @@ __device__ __forceinline__ bool signed_entry_scalar(u32 m, u32 bit, u32 k[9]) {
     return false;
 }
 
-__global__ void __launch_bounds__(256) gen_small_signed_kernel(const u32 *tab8, u32 *small, u32 st, unsigned long long entries) {
-    const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) gen_small_signed_kernel(const u32 *tab8, u32 *small, u32 st, unsigned long long entries, unsigned long long first) {
+    const unsigned long long idx = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= entries) return;
     const u32 h = (st - 1u) / 2u;
     const u32 hw = (u32)(idx >> h), m = (u32)(idx & ((1ull << h) - 1ull)) + 1u;      // half-window, magnitude 1 .. 2^h
@@ -1334,8 +1362,8 @@ __global__ void __launch_bounds__(256) gen_small_signed_kernel(const u32 *tab8, 
 
 // groups of GT_K consecutive magnitudes m0 + 1 .. m0 + GT_K of one window (same m_hi for all but the group's last magnitude
 // when that is a multiple of 2^h — handled by looking m_hi up per magnitude), one shared inversion per lane.
-__global__ void __launch_bounds__(256) gen_combine_signed_kernel(const u32 *small, u32 *tab, u32 st, unsigned long long groups) {
-    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) gen_combine_signed_kernel(const u32 *small, u32 *tab, u32 st, unsigned long long groups, unsigned long long first) {
+    const unsigned long long g = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= groups) return;
     const u32 h = (st - 1u) / 2u, nw = ec_signed_windows(st);
     const unsigned long long per = ec_signed_per(st), per_h = 1ull << h, top_per = ec_signed_top_per(st);
@@ -1453,25 +1481,44 @@ __global__ void __launch_bounds__(256) gen_combine_signed_kernel(const u32 *smal
 }
 
 // tab: the wide table (ec_table_words(bits) words); small: scratch for the half-width table (ec_table_small_words(bits) words).
-hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 *small, u32 bits, hipStream_t stream) {
-    if (bits == 25 || bits == 27 || bits == 29) {
-        const unsigned long long small_entries = ec_signed_small_entries(bits);
-        hipLaunchKernelGGL(gen_small_signed_kernel, dim3((unsigned)((small_entries + 255) / 256)), dim3(256), 0, stream, tab8, small, bits, small_entries);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        const unsigned long long groups = (unsigned long long)(ec_signed_windows(bits) - 1u) * (ec_signed_per(bits) / GT_K) + ec_signed_top_per(bits) / GT_K;
-        hipLaunchKernelGGL(gen_combine_signed_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, small, tab, bits, groups);
-        return hipGetLastError();
+// The build has two phases — 0: the half-width table, one lane per entry; 1: every wide entry as the sum of two of those, GT_K
+// entries per lane — and either can be launched in SLICES of lanes [first, first + count): the runtime replaces a table in use by
+// a wider one without pausing the scan, a slice riding in front of each dispatch on the frame's own stream (runtime.cpp: GtabJob).
+// Phase 1 may start once every slice of phase 0 has completed.
+unsigned long long gen_table_phase_lanes(u32 bits, int phase) {
+    if (bits == 25 || bits == 27 || bits == 29)
+        return phase == 0 ? ec_signed_small_entries(bits)
+                          : (unsigned long long)(ec_signed_windows(bits) - 1u) * (ec_signed_per(bits) / GT_K) + ec_signed_top_per(bits) / GT_K;
+    if (bits != 16 && bits != 20 && bits != 22 && bits != 24 && bits != 26) return 0;
+    return phase == 0 ? ec_wide_entries(bits / 2) : (unsigned long long)ec_wide_windows(bits) * ((1ull << bits) / GT_K);
+}
+
+hipError_t launch_gen_table_slice(const u32 *tab8, u32 *tab, u32 *small, u32 bits, int phase, unsigned long long first,
+                                  unsigned long long count, hipStream_t stream) {
+    const unsigned long long total = gen_table_phase_lanes(bits, phase);
+    if (total == 0 || (phase != 0 && phase != 1)) return hipErrorInvalidValue;
+    if (first >= total || count == 0) return hipSuccess;
+    if (count > total - first) count = total - first;
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    const unsigned long long end = first + count;   // the kernels' bound: lanes beyond the slice do nothing
+    const bool sgn = ec_table_signed(bits);
+    if (phase == 0) {
+        if (sgn) hipLaunchKernelGGL(gen_small_signed_kernel, grid, block, 0, stream, tab8, small, bits, end, first);
+        else hipLaunchKernelGGL(gen_table_wide_kernel, grid, block, 0, stream, tab8, small, bits / 2, end, first);
+    } else {
+        if (sgn) hipLaunchKernelGGL(gen_combine_signed_kernel, grid, block, 0, stream, small, tab, bits, end, first);
+        else hipLaunchKernelGGL(gen_table_combine_kernel, grid, block, 0, stream, small, tab, bits, end, first);
     }
-    if (bits != 16 && bits != 20 && bits != 22 && bits != 24 && bits != 26) return hipErrorInvalidValue;
-    const u32 h = bits / 2;
-    const unsigned long long small_entries = ec_wide_entries(h);
-    hipLaunchKernelGGL(gen_table_wide_kernel, dim3((unsigned)((small_entries + 255) / 256)), dim3(256), 0, stream, tab8, small, h, small_entries);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const unsigned long long groups = (unsigned long long)ec_wide_windows(bits) * ((1ull << bits) / GT_K);
-    hipLaunchKernelGGL(gen_table_combine_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, small, tab, bits, groups);
     return hipGetLastError();
+}
+
+hipError_t launch_gen_table_wide(const u32 *tab8, u32 *tab, u32 *small, u32 bits, hipStream_t stream) {
+    if (gen_table_phase_lanes(bits, 0) == 0) return hipErrorInvalidValue;
+    for (int phase = 0; phase < 2; phase++) {
+        const hipError_t e = launch_gen_table_slice(tab8, tab, small, bits, phase, 0, gen_table_phase_lanes(bits, phase), stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---- offset table of the sequential path, built on the device -------------------------------------------------

@@ -31,6 +31,11 @@ hipError_t launch_rnd_fill(uint8_t *keys_be, uint32_t n, const RndSeed &seed, ui
 // ec_table_words(bits) words, core/ec.h) from the 8-bit one, through a table of half the width (`small`:
 // ec_table_small_words(bits) words of scratch).
 hipError_t launch_gen_table_wide(const uint32_t *tab8, uint32_t *tab, uint32_t *small, uint32_t bits, hipStream_t stream);
+// The same build in slices: phase 0 = the half-width table, phase 1 = the wide table from it (only after every slice of phase 0 has
+// completed); lanes [first, first + count) of the phase's gen_table_phase_lanes(bits, phase).  A slice is one kernel launch.
+unsigned long long gen_table_phase_lanes(uint32_t bits, int phase);
+hipError_t launch_gen_table_slice(const uint32_t *tab8, uint32_t *tab, uint32_t *small, uint32_t bits, int phase, unsigned long long first,
+                                  unsigned long long count, hipStream_t stream);
 // Builds the sequential path's offset table on the device: rtab[(i) * lanes + u] / rtab[(9 + i) * lanes + u] = limb i of
 // x / y of base + u * step (a.pw[b] = 2^b * step).  No pair (partial sum, summand) is exceptional as long as base is not a
 // multiple of step and the scalars stay far below n (runtime.cpp: base = S/2, step = S).

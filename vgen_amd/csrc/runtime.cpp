@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 
 #include "device/launch.h"
@@ -63,6 +64,7 @@ void fe_canon_neg(fe &r, const fe &a) {
 size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 void release_gtab(vgen_ctx *c);   // (defined with the generator-table cache below)
+bool mem_allows(vgen_ctx *c, uint64_t extra, bool table, bool by_name, std::string *why);   // (the memory policy, same place)
 
 // Frame i's stream, created on first use (a stream costs ~5-8 ms: a scan's first dispatches should be running while
 // the later streams are still being set up).
@@ -218,9 +220,20 @@ int rt_device_name(int device, std::string &name, std::string &err) {
     return VGEN_OK;
 }
 
-int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
-    if (!p || !out || p->struct_size != sizeof(vgen_params)) {
+int rt_create(const vgen_params *p_in, vgen_ctx **out, std::string &err) {
+    // ABI 4's parameter block, or ABI 3's 28 bytes (no table_bits, no budget: both automatic)
+    constexpr uint32_t PARAMS_ABI3 = 28;
+    if (!p_in || !out || (p_in->struct_size != sizeof(vgen_params) && p_in->struct_size != PARAMS_ABI3)) {
         err = "vgen_create: bad parameter block";
+        return VGEN_E_INVALID;
+    }
+    vgen_params p_full;
+    memset(&p_full, 0, sizeof p_full);
+    memcpy(&p_full, p_in, p_in->struct_size);
+    const vgen_params *p = &p_full;
+    if (p->table_bits && !(p->table_bits == 8 || p->table_bits == 16 || p->table_bits == 20 || p->table_bits == 22 || p->table_bits == 24 ||
+                           p->table_bits == 26 || p->table_bits == 25 || p->table_bits == 27 || p->table_bits == 29)) {
+        err = "vgen_params.table_bits must be 0 (automatic), 8, 16, 20, 22, 24 or 26 (unsigned windows) or 25, 27 or 29 (signed windows)";
         return VGEN_E_INVALID;
     }
     int ndev = 0;
@@ -241,7 +254,11 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     double tlast = now();
     auto lap = [&](const char *what) { if (trace) { double t = now(); fprintf(stderr, "[vgen_create] %-28s %.2f ms\n", what, t - tlast); tlast = t; } };
     vgen_ctx *c = new vgen_ctx();
+    c->trace_create = trace;
     c->device = p->device;
+    c->mem_budget = p->device_mem_budget_bytes;
+    c->gtab_param = p->table_bits;
+    c->gtab_env = env_u32("VGEN_GTAB_BITS", 0);   // test override, read once: the dispatch path never looks at the environment
     c->batch = p->batch_size ? p->batch_size : (1u << 20);
     c->frames = p->frames ? p->frames : 12;   // the engine's own optimum (the reference's wgpu runner keeps 2, src/gpu.rs:399)
     c->match_cap = p->match_cap ? p->match_cap : 4096;
@@ -299,8 +316,18 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     const size_t scratch_b = up256(scratch_words(c) * sizeof(uint32_t));
     const size_t p2tr_b = up256(p2tr_words(c) * sizeof(uint32_t));
     const size_t frame_b = scratch_b + p2tr_b;
+    {
+        // what the frames take is a function of batch_size x frames (x the format), as in the reference (src/gpu.rs:391-402): known
+        // before anything is allocated, and refused here when the caller's budget does not cover it
+        const uint64_t fixed = (uint64_t)frame_b * c->frames + sizeof(DevFilter) + (uint64_t)18 * c->lanes * sizeof(uint32_t) +
+                               (uint64_t)up256(match_bytes(c->match_cap)) * c->frames;
+        if (c->mem_budget && fixed > c->mem_budget)
+            return bail(VGEN_E_NOMEM, "device_mem_budget_bytes " + std::to_string(c->mem_budget) + " does not cover the frames: " + std::to_string(fixed) +
+                                          " bytes for " + std::to_string(c->frames) + " frames of " + std::to_string(c->batch) + " keys");
+    }
     if ((e = hipMalloc((void **)&c->d_slab, frame_b * c->frames)) != hipSuccess)
         return bail(VGEN_E_NOMEM, std::string("frame allocation: ") + hipGetErrorString(e));
+    c->frames_bytes += (uint64_t)frame_b * c->frames;
     for (uint32_t i = 0; i < c->frames; i++) {
         vgen_ctx::Frame &f = c->fr[i];
         f.d_scratch = reinterpret_cast<uint32_t *>(c->d_slab + frame_b * i);
@@ -308,6 +335,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     }
     e = hipMalloc((void **)&c->d_filter, sizeof(DevFilter));
     if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(filter): ") + hipGetErrorString(e));
+    c->frames_bytes += sizeof(DevFilter);
 
     lap("hipMalloc slab + filter");
     // offset table R_u = (u*S + S/2) * G, limb-major ([18][lanes]) for coalesced reads — built on the device
@@ -337,6 +365,7 @@ int rt_create(const vgen_params *p, vgen_ctx **out, std::string &err) {
     lap("host: base + doublings");
     e = hipMalloc((void **)&c->d_rtab, (size_t)18 * c->lanes * sizeof(uint32_t));
     if (e != hipSuccess) return bail(VGEN_E_NOMEM, std::string("hipMalloc(rtab): ") + hipGetErrorString(e));
+    c->frames_bytes += (uint64_t)18 * c->lanes * sizeof(uint32_t);
     ra.rtab = c->d_rtab;
     // The scratch needs no initialisation (the memset only makes a first read of never-written padding deterministic);
     // cleared and built on frame 0's stream and waited for: the other frames' streams do not synchronise with it, so
@@ -369,6 +398,9 @@ int rt_set_match_cap(vgen_ctx *c, uint32_t cap) {
     if (cap > most) cap = (uint32_t)std::min<uint64_t>(most, 0xFFFFFFFFu);
     if (c->d_match_slab && cap == c->match_cap) return VGEN_OK;
     const size_t match_b = up256(match_bytes(cap));
+    const uint64_t old_b = c->d_match_slab ? (uint64_t)up256(match_bytes(c->match_cap)) * c->frames : 0;
+    if (c->mem_budget && c->frames_bytes - old_b + c->mode_bytes + (uint64_t)match_b * c->frames > c->mem_budget)   // (the tables are not in the way of a ring)
+        return c->fail(VGEN_E_NOMEM, "match rings of " + std::to_string(cap) + " records per frame pass device_mem_budget_bytes");
     uint8_t *d = nullptr, *h = nullptr;
     if (hipMalloc((void **)&d, match_b * c->frames) != hipSuccess) return c->fail(VGEN_E_NOMEM, "match ring allocation failed");
     if (hipHostMalloc((void **)&h, match_b * c->frames, hipHostMallocDefault) != hipSuccess) {
@@ -391,6 +423,8 @@ int rt_set_match_cap(vgen_ctx *c, uint32_t cap) {
     c->d_match_slab = d;
     c->h_slab = h;
     c->match_cap = cap;
+    c->frames_bytes += (uint64_t)match_b * c->frames - old_b;
+    c->pinned_bytes += (uint64_t)match_b * c->frames - old_b;
     for (uint32_t i = 0; i < c->frames; i++) {
         vgen_ctx::Frame &f = c->fr[i];
         f.d_match = d + match_b * i;
@@ -475,11 +509,15 @@ namespace {
 int alloc_dump_piece(vgen_ctx *c, uint32_t first, uint32_t n, uint8_t **d_out, uint8_t **h_out) {
     const size_t per = up256((size_t)c->batch * (c->endo ? 6 : 1) * c->payload_words * sizeof(uint32_t));
     uint8_t *d = nullptr, *h = nullptr;
+    std::string refused;
+    if (!mem_allows(c, (uint64_t)per * n, false, false, &refused)) return c->fail(VGEN_E_NOMEM, "dump buffers: " + refused);
     if (hipMalloc((void **)&d, per * n) != hipSuccess) return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed");
     if (hipHostMalloc((void **)&h, per * n, hipHostMallocDefault) != hipSuccess) {
         (void)hipFree(d);
         return c->fail(VGEN_E_NOMEM, "dump buffer allocation failed (pinned host memory)");
     }
+    c->mode_bytes += (uint64_t)per * n;
+    c->pinned_bytes += (uint64_t)per * n;
     *d_out = d;
     *h_out = h;
     for (uint32_t i = 0; i < n; i++) {
@@ -530,12 +568,18 @@ int rt_set_filter(vgen_ctx *c, const vgen_filter *f) {
     if (f->format != c->format) return c->fail(VGEN_E_INVALID, "filter was compiled for another address format");
     c->h_filter = f->dev;
     if (f->dev.chk_lut) {   // Bech32 checksum tables: upload and point the device copy at them
-        if (!c->d_chk_lut) HIP_TRY(c, hipMalloc((void **)&c->d_chk_lut, 32 * 256 * sizeof(uint32_t)));
+        if (!c->d_chk_lut) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_chk_lut, 32 * 256 * sizeof(uint32_t)));
+            c->mode_bytes += 32 * 256 * sizeof(uint32_t);
+        }
         if (int rc = upload(c, c->d_chk_lut, f->chk_lut.data(), f->chk_lut.size() * sizeof(uint32_t))) return rc;
         c->h_filter.chk_lut = c->d_chk_lut;
     }
     if (f->dev.kind == DEVF_DFA) {   // the pattern's automaton: upload, point the device copy at it
-        if (!c->d_dfa) HIP_TRY(c, hipMalloc((void **)&c->d_dfa, 48 * 1024));
+        if (!c->d_dfa) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_dfa, 48 * 1024));
+            c->mode_bytes += 48 * 1024;
+        }
         if (int rc = upload(c, c->d_dfa, f->dfa_blob.data(), f->dfa_blob.size() * 4)) return rc;
         c->h_filter.dfa_blob = c->d_dfa;
     }
@@ -595,9 +639,11 @@ int finish_dispatch(vgen_ctx *c, vgen_ctx::Frame &f, bool dump, uint64_t keys, b
     return VGEN_OK;
 }
 
+// ---- generator tables: who decides how much device memory they take, and how a table in use is replaced ---------------------------
+//
 // Wide generator tables are shared by the contexts of a process that sit on the same device (tests, multi-tenant hosts,
 // several scans in one host application): 11.8 GB at the default width is paid once per device, not once per context.
-// Reference-counted; the last context to go frees the table.  The lock is held across a build (~20 ms, once).
+// Reference-counted; the last context to go frees the table.
 struct GtabShared {
     int device;
     uint32_t bits;
@@ -607,40 +653,337 @@ struct GtabShared {
 struct GtabCache {
     std::mutex mu;
     std::vector<GtabShared> tabs;
+    std::vector<std::pair<int, uint32_t>> building;   // (device, bits) some context of the process is building in the background
 };
 GtabCache &gtab_cache() {
     static GtabCache *g = new GtabCache();   // (never destroyed: contexts may outlive static teardown order)
     return *g;
 }
 
-// Drops the context's reference on its wide table (rt_destroy).
-void release_gtab(vgen_ctx *c) {
-    if (!c->d_gtab16) return;
+uint64_t gtab_bytes(uint32_t bits) { return bits <= 8 ? 0 : ((uint64_t)ec_table_words(bits) + ec_table_small_words(bits)) * sizeof(uint32_t); }
+bool gtab_width_ok(uint32_t b) { return b == 8 || b == 16 || b == 20 || b == 22 || b == 24 || b == 26 || b == 25 || b == 27 || b == 29; }
+// additions per multiplication of a width: what "wider" means across signed and unsigned tables
+uint32_t gtab_additions(uint32_t b) { return b <= 8 ? 31u : ec_table_signed(b) ? ec_signed_windows(b) - 1u : ec_wide_windows(b) - 1u; }
+// every width, by (additions per multiplication, bytes): 29s (8; 138 GB) | 27s, 26 (9; 21.5 / 43 GB) | 25s, 24 (10; 5.9 / 11.8 GB) | 22 | 20 | 16
+const uint32_t GTAB_WIDTHS[] = {29, 27, 26, 25, 24, 22, 20, 16};
+
+// Drops one reference on a shared table; the last one frees it (hipFree synchronises the device: callers pick their moment).
+void gtab_unref(int device, uint32_t *wide) {
+    if (!wide) return;
     GtabCache &g = gtab_cache();
     std::lock_guard<std::mutex> lk(g.mu);
     for (size_t i = 0; i < g.tabs.size(); i++) {
         GtabShared &t = g.tabs[i];
-        if (t.device != c->device || t.wide != c->d_gtab16) continue;
+        if (t.device != device || t.wide != wide) continue;
         if (--t.refs == 0) {
             (void)hipFree(t.wide);
             (void)hipFree(t.small);
             g.tabs.erase(g.tabs.begin() + (long)i);
         }
-        break;
+        return;
     }
+}
+
+uint32_t gtab_bits_of(int device, const uint32_t *wide) {
+    if (!wide) return 0;
+    GtabCache &g = gtab_cache();
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (GtabShared &t : g.tabs)
+        if (t.device == device && t.wide == wide) return t.bits;
+    return 0;
+}
+
+bool gtab_adopt_shared_peek(int device, uint32_t bits) {
+    GtabCache &g = gtab_cache();
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (GtabShared &t : g.tabs)
+        if (t.device == device && t.bits == bits) return true;
+    return false;
+}
+
+// Takes a reference on the device's table of `bits` bits if some context of the process has built it.
+uint32_t *gtab_adopt_shared(int device, uint32_t bits) {
+    GtabCache &g = gtab_cache();
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (GtabShared &t : g.tabs)
+        if (t.device == device && t.bits == bits) {
+            t.refs++;
+            return t.wide;
+        }
+    return nullptr;
+}
+
+// Joins the allocating thread of a background build and gives back whatever it holds (vgen_destroy; a failed or abandoned build).
+void gtab_job_drop(vgen_ctx *c) {
+    if (!c->gtab_job) return;
+    vgen_ctx::GtabJob &j = *c->gtab_job;
+    if (j.alloc.joinable()) j.alloc.join();
+    if (j.wide) (void)hipFree(j.wide);
+    if (j.small) (void)hipFree(j.small);
+    {
+        GtabCache &g = gtab_cache();
+        std::lock_guard<std::mutex> lk(g.mu);
+        auto it = std::find(g.building.begin(), g.building.end(), std::make_pair(c->device, j.bits));
+        if (it != g.building.end()) g.building.erase(it);
+    }
+    c->gtab_job.reset();
+}
+
+// Drops the context's references on its wide tables (rt_destroy).
+void release_gtab(vgen_ctx *c) {
+    gtab_job_drop(c);
+    gtab_unref(c->device, c->gtab_old);
+    c->gtab_old = nullptr;
+    gtab_unref(c->device, c->d_gtab16);
     c->d_gtab16 = nullptr;
     c->gtab_bits = 0;
+}
+
+// The retired table goes when nothing of this context is in flight (no launched kernel can hold its address, and the
+// device-wide synchronisation inside hipFree costs nothing then).
+void gtab_release_old_if_idle(vgen_ctx *c) {
+    if (!c->gtab_old) return;
+    for (auto &f : c->fr)
+        if (f.in_flight) return;
+    gtab_unref(c->device, c->gtab_old);
+    c->gtab_old = nullptr;
+}
+
+uint64_t gtab_held_bytes(const vgen_ctx *c) {
+    uint64_t b = 0;
+    if (c->d_gtab16) b += gtab_bytes(c->gtab_bits);
+    if (c->gtab_old) b += gtab_bytes(gtab_bits_of(c->device, c->gtab_old));
+    if (c->gtab_job) b += gtab_bytes(c->gtab_job->bits);
+    return b;
+}
+
+// May this context take `extra` more bytes of device memory?  With a budget (vgen_params.device_mem_budget_bytes): everything it holds
+// plus `extra` stays within it.  Without one, generator tables chosen AUTOMATICALLY (table = true, nobody asked for that width by
+// name) must fit half of what the device has free right now — the rule that keeps a scan from taking 138 GB of a device another
+// tenant is using.  `why` says which rule refused.
+bool mem_allows(vgen_ctx *c, uint64_t extra, bool table, bool by_name, std::string *why) {
+    if (c->mem_budget) {
+        const uint64_t held = c->frames_bytes + c->mode_bytes + gtab_held_bytes(c);
+        if (held + extra <= c->mem_budget) return true;
+        if (why) *why = "device_mem_budget_bytes " + std::to_string(c->mem_budget) + " < " + std::to_string(held) + " held + " + std::to_string(extra);
+        return false;
+    }
+    if (!table || by_name) return true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    if (extra <= free_b / 2) return true;
+    if (why) *why = std::to_string(extra >> 20) + " MiB is more than half of the " + std::to_string(free_b >> 20) + " MiB free on the device";
+    return false;
+}
+
+// The width the context should be using: the test override, else the caller's choice for the context, else the running scan's
+// (bounded by its cap), else 24 bits.  by_name: somebody asked for exactly this width.
+uint32_t wanted_table_bits(const vgen_ctx *c, bool *by_name) {
+    if (by_name) *by_name = c->gtab_env || c->gtab_param;
+    if (c->gtab_env) return c->gtab_env;
+    if (c->gtab_param) return c->gtab_param;
+    uint32_t want = c->gtab_bits_pref ? c->gtab_bits_pref : 24;
+    if (c->gtab_bits_cap && gtab_additions(want) < gtab_additions(c->gtab_bits_cap)) want = c->gtab_bits_cap;
+    return want;
+}
+
+#ifdef VGEN_TEST_HOOKS
+// fault injection (test build only): widths >= VGEN_DEBUG_GTAB_FAIL behave as if their allocation had failed
+uint32_t gtab_hook_fail_from() { return env_u32("VGEN_DEBUG_GTAB_FAIL", 0); }
+#else
+constexpr uint32_t gtab_hook_fail_from() { return 0; }
+#endif
+
+// First wide table of a context, built here and now on frame 0's stream (24 bits: ~20 ms): `first`, or — when that cannot be
+// allocated, fails to build or is refused by the memory policy — the next width in order of (additions, bytes).  Under the
+// cache lock, so that two contexts of a device do not build the same table side by side.
+void gtab_build_first(vgen_ctx *c, uint32_t first, bool by_name, const std::function<void(const char *)> &lap) {
+    GtabCache &g = gtab_cache();
+    std::lock_guard<std::mutex> lk(g.mu);
+    std::string why;
+    std::vector<uint32_t> order{first};
+    for (uint32_t b : GTAB_WIDTHS)
+        if (b != first && gtab_additions(b) >= gtab_additions(first)) order.push_back(b);
+    const uint32_t hook_fail_from = gtab_hook_fail_from();
+    for (uint32_t bits : order) {
+        bool shared = false;   // somebody on this device has it already
+        for (GtabShared &t : g.tabs)
+            if (t.device == c->device && t.bits == bits) {
+                t.refs++;
+                c->d_gtab16 = t.wide;
+                c->gtab_bits = bits;
+                shared = true;
+                break;
+            }
+        if (shared) break;
+        std::string refused;
+        if (!mem_allows(c, gtab_bytes(bits), true, by_name && bits == first, &refused)) {
+            if (why.empty()) why = refused + " at " + std::to_string(bits) + " bits";
+            continue;
+        }
+        uint32_t *wide_tab = nullptr, *small = nullptr;   // small: the half-width table the wide one is combined from
+        hipError_t e = hook_fail_from && bits >= hook_fail_from ? hipErrorOutOfMemory
+                                                                : hipMalloc((void **)&wide_tab, (size_t)ec_table_words(bits) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_table_small_words(bits) * sizeof(uint32_t));
+        lap("hipMalloc wide + scratch");
+        hipStream_t st0 = nullptr;
+        if (e == hipSuccess && frame_stream(c, 0, &st0) != VGEN_OK) e = hipErrorUnknown;
+        if (e == hipSuccess) e = launch_gen_table_wide(c->d_gtab, wide_tab, small, bits, st0);
+        if (e == hipSuccess) e = hipStreamSynchronize(st0);
+        lap("two kernels + sync");
+        if (e == hipSuccess) {
+            g.tabs.push_back(GtabShared{c->device, bits, wide_tab, small, 1});
+            c->d_gtab16 = wide_tab;
+            c->gtab_bits = bits;
+            break;
+        }
+        (void)hipGetLastError();
+        if (wide_tab) (void)hipFree(wide_tab);
+        if (small) (void)hipFree(small);
+        if (why.empty()) why = std::string(hipGetErrorString(e)) + " at " + std::to_string(bits) + " bits";
+    }
+    if (!c->d_gtab16) c->gtab_wide_failed = true;
+    if (!why.empty())
+        c->gtab_note = "wide generator table unavailable (" + why + "): continuing on " +
+                       (c->d_gtab16 ? "a " + std::to_string(c->gtab_bits) + "-bit table" : std::string("the 8-bit table"));
+}
+
+// ---- replacing the table in use by a wider one, without pausing anything --------------------------------------------------------
+// (round 4 drained the frames, freed the old table — hipFree synchronises the device — and built the new one before the next
+//  dispatch: 0.7 - 2.3 s of pause for 29 bits, and no way back when the 138 GB allocation then failed.)  Now: the two buffers are
+// allocated by a thread of their own; the build then advances one SLICE per dispatch, launched in front of the dispatch's own
+// kernels on the frame's own stream (a stream of its own would have to share a hardware queue with a frame and hold that
+// frame's dispatches up behind a 0.2 s kernel: all twelve queues are taken); phase 1 starts when every slice of phase 0 has
+// completed; the first dispatch after the last slice has completed takes the new table, and the old one is freed when the
+// context next has nothing in flight.  A slice is sized to ~1/8 of the dispatch it rides with, so a scan runs ~12 % slower
+// for the ~4 000 dispatches (3 s at 2^20 keys each) the 29-bit table takes, and never stops.
+
+// Starts the background build of `bits` (the caller has checked that it is wanted, wider than the table in use and allowed).
+void gtab_job_start(vgen_ctx *c, uint32_t bits) {
+    GtabCache &g = gtab_cache();
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (std::find(g.building.begin(), g.building.end(), std::make_pair(c->device, bits)) != g.building.end()) {
+            c->gtab_waiting_bits = bits;   // somebody else's build: take it when it is there
+            return;
+        }
+        g.building.emplace_back(c->device, bits);
+    }
+    c->gtab_job.reset(new vgen_ctx::GtabJob());
+    vgen_ctx::GtabJob *j = c->gtab_job.get();
+    j->bits = bits;
+    const int device = c->device;
+    j->alloc = std::thread([j, device, bits]() {
+        const uint32_t hook_fail_from = gtab_hook_fail_from();
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hook_fail_from && bits >= hook_fail_from ? hipErrorOutOfMemory : hipMalloc((void **)&j->wide, (size_t)ec_table_words(bits) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&j->small, (size_t)ec_table_small_words(bits) * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            j->why = std::string(hipGetErrorString(e)) + " at " + std::to_string(bits) + " bits";
+            j->alloc_state.store(2);
+        } else {
+            j->alloc_state.store(1);
+        }
+    });
+}
+
+// The widest table the context may move to from the one in use: `want`, or the next width towards the one in use that the memory
+// policy allows (0 = none).  Both tables exist side by side until the old one can be freed.
+uint32_t gtab_upgrade_target(vgen_ctx *c, uint32_t want, bool by_name, std::string *why) {
+    std::vector<uint32_t> order{want};
+    for (uint32_t b : GTAB_WIDTHS)
+        if (b != want && gtab_additions(b) >= gtab_additions(want)) order.push_back(b);
+    for (uint32_t bits : order) {
+        if (gtab_additions(bits) >= gtab_additions(c->gtab_bits)) break;   // no better than what is in use
+        if (bits == c->gtab_job_failed_bits) continue;
+        std::string refused;
+        if (mem_allows(c, gtab_bytes(bits), true, by_name && bits == want, &refused)) return bits;
+        if (why && why->empty()) *why = refused + " at " + std::to_string(bits) + " bits";
+    }
+    return 0;
+}
+
+// One step of the background build, called on the dispatch path with the frame about to be dispatched to (its stream exists, it
+// has nothing in flight).
+int gtab_job_step(vgen_ctx *c, vgen_ctx::Frame &f) {
+    if (c->gtab_waiting_bits) {   // another context's build of the width this one wants
+        if (uint32_t *t = gtab_adopt_shared(c->device, c->gtab_waiting_bits)) {
+            if (c->gtab_old) gtab_unref(c->device, t);   // (still holding a retired table: keep it simple, try again later)
+            else {
+                c->gtab_old = c->d_gtab16;
+                c->d_gtab16 = t;
+                c->gtab_bits = c->gtab_waiting_bits;
+                c->gtab_waiting_bits = 0;
+                c->gtab_note.clear();
+            }
+        } else {
+            GtabCache &g = gtab_cache();
+            std::lock_guard<std::mutex> lk(g.mu);
+            if (std::find(g.building.begin(), g.building.end(), std::make_pair(c->device, c->gtab_waiting_bits)) == g.building.end())
+                c->gtab_waiting_bits = 0;   // the builder gave up (or went away): decide afresh
+        }
+        return VGEN_OK;
+    }
+    if (!c->gtab_job) return VGEN_OK;
+    vgen_ctx::GtabJob &j = *c->gtab_job;
+    const int st = j.alloc_state.load();
+    if (st == 0) return VGEN_OK;   // still allocating
+    if (st == 2) {
+        c->gtab_job_failed_bits = j.bits;
+        c->gtab_note = "wider generator table unavailable (" + j.why + "): continuing on the " + std::to_string(c->gtab_bits) + "-bit table";
+        gtab_job_drop(c);
+        return VGEN_OK;
+    }
+    if (j.phase < 2) {
+        const unsigned long long total = gen_table_phase_lanes(j.bits, j.phase);
+        if (j.next < total) {
+            // ~1/8 of the dispatch's own work: a lane of phase 0 is a whole 8-bit multiplication + inversion (~3 keys' worth of a
+            // scalar-multiplication dispatch), a lane of phase 1 makes eight entries (~2 keys' worth)
+            unsigned long long count = j.phase == 0 ? c->batch / 32 : c->batch / 16;
+            count = std::max<unsigned long long>(256, count & ~255ull);
+            HIP_TRY(c, launch_gen_table_slice(c->d_gtab, j.wide, j.small, j.bits, j.phase, j.next, count, f.s));
+            j.next += count;
+            j.slices++;
+            j.pending++;
+            f.carries_slice = true;
+        } else if (j.pending == 0) {
+            j.phase++;
+            j.next = 0;
+        }
+    }
+    if (j.phase == 2 && !c->gtab_old) {
+        // complete: publish it for the device's other contexts and take it into use from this dispatch on
+        if (j.alloc.joinable()) j.alloc.join();
+        {
+            GtabCache &g = gtab_cache();
+            std::lock_guard<std::mutex> lk(g.mu);
+            g.tabs.push_back(GtabShared{c->device, j.bits, j.wide, j.small, 1});
+            auto it = std::find(g.building.begin(), g.building.end(), std::make_pair(c->device, j.bits));
+            if (it != g.building.end()) g.building.erase(it);
+        }
+        c->gtab_old = c->d_gtab16;
+        c->d_gtab16 = j.wide;
+        c->gtab_bits = j.bits;
+        c->gtab_note.clear();
+        if (c->trace_create) fprintf(stderr, "[generator tables] %u-bit table in use after %llu slices\n", j.bits, (unsigned long long)j.slices);
+        c->gtab_job.reset();
+    }
+    return VGEN_OK;
 }
 
 // Generator tables of the paths that multiply a scalar per key.  `wide`: the dispatch is worth the wide-window table
 // (every P2TR dispatch, arbitrary-scalar dispatches of a few thousand keys or more); a handful of keys, or the rare
 // sequential batch that touches the group order, runs on the always-present 8-bit table instead of paying 11.8 GB and
-// ~19 ms for it.  A wide table that cannot be had (allocation or build failure) is not an error either: the context steps
-// down through the narrower widths (24 -> 22 -> 20 -> 16 bits: 10 / 11 / 12 / 15 additions per multiplication) before it
-// settles on the 8-bit table (31), and says what it got through vgen_get_resources (never through vgen_last_error: the
-// call succeeded).
-int ensure_gtab(vgen_ctx *c, bool wide) {
-    const bool trace = getenv("VGEN_TRACE_CREATE") != nullptr;
+// ~19 ms for it.  A wide table that cannot be had (allocation or build failure, the memory policy) is not an error either: the
+// context steps down through the other widths in order of (additions per multiplication, bytes) before it settles on the 8-bit
+// table (31), and says what it got through vgen_get_resources (never through vgen_last_error: the call succeeded).
+// `f`: the frame being dispatched to (carries the background build's next slice).
+int ensure_gtab(vgen_ctx *c, bool wide, vgen_ctx::Frame *f) {
+    const bool trace = c->trace_create;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tlast = now();
     auto lap = [&](const char *what) { if (trace) { double t = now(); fprintf(stderr, "[generator tables] %-28s %.2f ms\n", what, t - tlast); tlast = t; } };
@@ -648,96 +991,63 @@ int ensure_gtab(vgen_ctx *c, bool wide) {
         std::vector<uint32_t> tab;
         host_gen_table8_limbs(tab);   // 8-bit windows, 652 800 B (core/ec.h)
         lap("host: 8-bit table");
+        if (!mem_allows(c, tab.size() * sizeof(uint32_t), false, false, nullptr)) return c->fail(VGEN_E_NOMEM, "generator table: device_mem_budget_bytes exhausted");
         HIP_TRY(c, hipMalloc((void **)&c->d_gtab, tab.size() * sizeof(uint32_t)));
         if (int rc = upload(c, c->d_gtab, tab.data(), tab.size() * sizeof(uint32_t))) {
             (void)hipFree(c->d_gtab);
             c->d_gtab = nullptr;
             return rc;
         }
+        c->mode_bytes += tab.size() * sizeof(uint32_t);
         lap("upload");
     }
+    gtab_release_old_if_idle(c);
+    if (!wide) return VGEN_OK;
     // The wide-window table, built on the device from the 8-bit one, once per DEVICE: 24-bit windows by default (11 windows,
     // 10 additions per multiplication instead of the 8-bit table's 31; 11.8 GB of the 288 GB).  Every entry is the affine sum
     // of two entries of a table of half the width, eight entries per lane sharing an inversion (gen_table_combine_kernel).
     // Measured in round 3 (profiles/r03_gtab26.txt; random-key mode Mkeys/s, build incl. allocation): 22 bits (3.2 GB) 1272,
     // 6 ms; 24 bits 1362, 19 ms; 26 bits (43 GB, 9 additions) 1451, but its first hipMalloc takes ~1 s and the gathers begin
     // to show (VALU-busy 0.97).  The paths are issue-bound (profiles/pmc_keys.json), so the rate follows the additions saved.
-    // VGEN_GTAB_BITS = 8 | 16 | 20 | 22 | 24 | 26 selects.
-    const uint32_t want_now = env_u32("VGEN_GTAB_BITS", c->gtab_bits_pref ? c->gtab_bits_pref : 24);
-    // additions per multiplication of a width: what "wider" means across signed and unsigned tables
-    auto additions = [](uint32_t b) { return ec_table_signed(b) ? ec_signed_windows(b) - 1u : ec_wide_windows(b) - 1u; };
-    if (wide && c->d_gtab16 && c->gtab_bits != want_now && c->gtab_bits_wanted != want_now &&
-        (getenv("VGEN_GTAB_BITS") != nullptr || additions(want_now) < additions(c->gtab_bits))) {
-        // a WIDER table is wanted than the one in use (the scan loop's preference for a longer scan; a context never steps back down
-        // by itself): switch while no frame holds the old table's address in a launched kernel
-        bool busy = false;
-        for (auto &f : c->fr) busy = busy || f.in_flight;
-        if (!busy) {
-            release_gtab(c);
-            c->gtab_wide_failed = false;
-            c->gtab_note.clear();
-        }
-    }
-    if (wide && !c->d_gtab16 && !c->gtab_wide_failed) {
-        const uint32_t want = want_now;
-        if (want != 8 && want != 16 && want != 20 && want != 22 && want != 24 && want != 26 && want != 25 && want != 27 && want != 29)
-            return c->fail(VGEN_E_INVALID, "VGEN_GTAB_BITS must be 8, 16, 20, 22, 24 or 26 (unsigned windows) or 25, 27 or 29 (signed windows)");
+    bool by_name = false;
+    const uint32_t want = wanted_table_bits(c, &by_name);
+    if (!gtab_width_ok(want))
+        return c->fail(VGEN_E_INVALID, "generator table width must be 8, 16, 20, 22, 24 or 26 (unsigned windows) or 25, 27 or 29 (signed windows)");
+    if (!c->d_gtab16 && !c->gtab_wide_failed) {
         c->gtab_bits_wanted = want;
         if (want == 8) {
             c->gtab_wide_failed = true;   // (asked for: nothing to build)
             return VGEN_OK;
         }
-#ifdef VGEN_TEST_HOOKS
-        // fault injection (test build only): widths >= VGEN_DEBUG_GTAB_FAIL behave as if their allocation had failed
-        const uint32_t hook_fail_from = env_u32("VGEN_DEBUG_GTAB_FAIL", 0);
-#else
-        const uint32_t hook_fail_from = 0;
-#endif
-        // by additions per multiplication: 29 signed (8; 138 GB) | 27 signed, 26 (9; 21.5 / 43 GB) | 25 signed, 24 (10; 5.9 / 11.8 GB) | 22 | 20 | 16.
-        // A signed width is only ever tried when it was asked for; stepping down goes through the unsigned ones below it.
-        static const uint32_t widths[] = {29, 27, 26, 25, 24, 22, 20, 16};
-        GtabCache &g = gtab_cache();
-        std::lock_guard<std::mutex> lk(g.mu);
-        std::string why;
-        for (uint32_t bits : widths) {
-            if (bits > want || (ec_table_signed(bits) && bits != want)) continue;
-            // somebody on this device has it already
-            bool shared = false;
-            for (GtabShared &t : g.tabs)
-                if (t.device == c->device && t.bits == bits) {
-                    t.refs++;
-                    c->d_gtab16 = t.wide;
-                    c->gtab_bits = bits;
-                    shared = true;
-                    break;
-                }
-            if (shared) break;
-            uint32_t *wide_tab = nullptr, *small = nullptr;   // small: the half-width table the wide one is combined from
-            hipError_t e = hook_fail_from && bits >= hook_fail_from ? hipErrorOutOfMemory
-                                                                    : hipMalloc((void **)&wide_tab, (size_t)ec_table_words(bits) * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMalloc((void **)&small, (size_t)ec_table_small_words(bits) * sizeof(uint32_t));
-            lap("hipMalloc wide + scratch");
-            hipStream_t st0 = nullptr;
-            if (e == hipSuccess && frame_stream(c, 0, &st0) != VGEN_OK) e = hipErrorUnknown;
-            if (e == hipSuccess) e = launch_gen_table_wide(c->d_gtab, wide_tab, small, bits, st0);
-            if (e == hipSuccess) e = hipStreamSynchronize(st0);
-            lap("two kernels + sync");
-            if (e == hipSuccess) {
-                g.tabs.push_back(GtabShared{c->device, bits, wide_tab, small, 1});
-                c->d_gtab16 = wide_tab;
-                c->gtab_bits = bits;
-                break;
-            }
-            (void)hipGetLastError();
-            if (wide_tab) (void)hipFree(wide_tab);
-            if (small) (void)hipFree(small);
-            if (why.empty()) why = std::string(hipGetErrorString(e)) + " at " + std::to_string(bits) + " bits";
-        }
-        if (!c->d_gtab16) c->gtab_wide_failed = true;
-        if (!why.empty())
-            c->gtab_note = "wide generator table unavailable (" + why + "): continuing on " +
-                           (c->d_gtab16 ? "a " + std::to_string(c->gtab_bits) + "-bit table" : std::string("the 8-bit table"));
+        // A width somebody named is built at once (tests, bench legs: what they then measure is that width).  The scan loop's own
+        // choice starts on the 24-bit table (there in ~20 ms) when it is the 29-bit one (0.7 - 2.3 s to allocate and build), which
+        // then arrives in the background; 27 bits (~60 ms) is not worth two builds.
+        uint32_t first = want;
+        if (!by_name && gtab_additions(want) < gtab_additions(27) && !gtab_adopt_shared_peek(c->device, want)) first = 24;
+        gtab_build_first(c, first, by_name, lap);
     }
+    if (c->d_gtab16 && gtab_additions(want) < gtab_additions(c->gtab_bits)) {
+        // a WIDER table is wanted than the one in use (a longer scan than the context has seen so far; a context never steps back
+        // down by itself)
+        c->gtab_bits_wanted = want;
+        if (!c->gtab_job && !c->gtab_waiting_bits && !c->gtab_old) {
+            std::string why;
+            const uint32_t target = gtab_upgrade_target(c, want, by_name, &why);
+            if (target) {
+                if (uint32_t *t = gtab_adopt_shared(c->device, target)) {   // the device has it already
+                    c->gtab_old = c->d_gtab16;
+                    c->d_gtab16 = t;
+                    c->gtab_bits = target;
+                    c->gtab_note.clear();
+                } else {
+                    gtab_job_start(c, target);
+                }
+            }
+            if (target != want && !why.empty() && c->gtab_note.empty())
+                c->gtab_note = "wider generator table not taken (" + why + "): " + (target ? "moving to " + std::to_string(target) + " bits" : "staying on the " + std::to_string(c->gtab_bits) + "-bit table");
+        }
+    }
+    if (f && (c->gtab_job || c->gtab_waiting_bits)) return gtab_job_step(c, *f);
     return VGEN_OK;
 }
 
@@ -769,7 +1079,10 @@ int ensure_keys_slab(vgen_ctx *c) {
     const size_t scratch_b = up256(((size_t)27 * max_groups * KEYS_WG + (size_t)max_groups * 9 * KEYS_WG + (size_t)9 * max_groups) * sizeof(uint32_t));
     const size_t stage_b = up256(p2tr_stage_words(c) * sizeof(uint32_t));   // taproot contexts: internal keys + the stage's own scratch
     const size_t per = keys_b + scratch_b + stage_b;
+    std::string refused;
+    if (!mem_allows(c, (uint64_t)per * c->frames, false, false, &refused)) return c->fail(VGEN_E_NOMEM, "arbitrary-scalar buffers: " + refused);
     HIP_TRY(c, hipMalloc((void **)&c->d_keys_slab, per * c->frames));
+    c->mode_bytes += (uint64_t)per * c->frames;
     for (uint32_t i = 0; i < c->frames; i++) {
         c->fr[i].d_keys = c->d_keys_slab + per * i;
         c->fr[i].d_keys_scratch = reinterpret_cast<uint32_t *>(c->d_keys_slab + per * i + keys_b);
@@ -782,8 +1095,9 @@ int ensure_keys_slab(vgen_ctx *c) {
 // (keys_dev != nullptr) or base + i.
 int enqueue_keys(vgen_ctx *c, vgen_ctx::Frame &f, const uint8_t *keys_dev, const Scalar *base, uint32_t n) {
     // worth the wide table: taproot contexts (their sequential path builds it anyway) and real arbitrary-scalar batches
-    // (an explicit VGEN_GTAB_BITS is honoured whatever the batch: the parity tests of every width rely on it)
-    if (int rc = ensure_gtab(c, c->format == VGF_P2TR || (keys_dev != nullptr && n >= 4096) || getenv("VGEN_GTAB_BITS") != nullptr)) return rc;
+    // (a width named by the caller — vgen_params.table_bits, the test override — is honoured whatever the batch: the parity tests of
+    //  every width rely on it)
+    if (int rc = ensure_gtab(c, c->format == VGF_P2TR || (keys_dev != nullptr && n >= 4096) || c->gtab_env || c->gtab_param, &f)) return rc;
     if (int rc = ensure_keys_slab(c)) return rc;
     KeysArgs a;
     memset(&a, 0, sizeof a);
@@ -902,7 +1216,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     const bool endo_now = c->endo && !(a.dfa_bytes && parks_y && a.dfa_bytes + 2u * 9u * SEQ_WG * 4u > 64u * 1024u);
     a.endo = endo_now ? 1u : 0u;
     if (c->format == VGF_P2TR) {   // the tweak multiplication t*G needs the fixed-window table ...
-        if (int rc = ensure_gtab(c, true)) return rc;
+        if (int rc = ensure_gtab(c, true, &f)) return rc;
         a.gtab = c->d_gtab;
         a.gtab16 = c->d_gtab16;
         a.gtab_bits = c->gtab_bits;
@@ -961,6 +1275,10 @@ int rt_wait(vgen_ctx *c, uint32_t frame, vgen_match *out, uint32_t cap, uint32_t
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = wait_done(c, f)) return rc;
     f.in_flight = false;
+    if (f.carries_slice) {   // the slice of the background table build that rode in front of this dispatch has completed with it
+        f.carries_slice = false;
+        if (c->gtab_job && c->gtab_job->pending) c->gtab_job->pending--;
+    }
     f.timing_fresh = false;   // elapsed times are read from the events on demand (rt_frame_times)
     if (keys_tested) *keys_tested = f.keys_tested;
     uint32_t found = 0;
@@ -1067,8 +1385,25 @@ int rt_read_dump(vgen_ctx *c, uint32_t frame, uint8_t *out, size_t out_len) {
     return VGEN_OK;
 }
 
-void rt_prefer_table_bits(vgen_ctx *c, uint32_t bits) {
-    if (bits == 0 || bits == 16 || bits == 20 || bits == 22 || bits == 24 || bits == 26 || bits == 25 || bits == 27 || bits == 29) c->gtab_bits_pref = bits;
+void rt_prefer_table_bits(vgen_ctx *c, uint32_t bits, uint32_t cap) {
+    if (bits == 0 || (bits != 8 && gtab_width_ok(bits))) c->gtab_bits_pref = bits;
+    c->gtab_bits_cap = cap && gtab_width_ok(cap) ? cap : 0;
+}
+
+// Device and pinned host memory of the context, and what the device has left: vgen_get_memory.
+int rt_get_memory(const vgen_ctx *c, vgen_memory_info *out) {
+    if (!out || out->struct_size != sizeof(vgen_memory_info)) return VGEN_E_INVALID;
+    out->table_bits = c->d_gtab16 ? c->gtab_bits : c->d_gtab ? 8u : 0u;
+    out->frames_bytes = c->frames_bytes;
+    out->mode_bytes = c->mode_bytes;
+    out->table_bytes = gtab_held_bytes(c);
+    out->pinned_host_bytes = c->pinned_bytes;
+    out->budget_bytes = c->mem_budget;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
+    out->device_free_bytes = free_b;
+    out->device_total_bytes = total_b;
+    return VGEN_OK;
 }
 
 // What dump mode and the scalar-multiplication paths have (or will get) of what they ask for: vgen_get_resources.
@@ -1076,7 +1411,7 @@ int rt_get_resources(const vgen_ctx *c, uint32_t *dump_frames, uint32_t *table_b
     if (dump_frames) *dump_frames = dump_frames_for(c);
     // 0 = no generator table yet (no P2TR / arbitrary-scalar dispatch so far); 8 = the 8-bit table only
     if (table_bits) *table_bits = c->d_gtab16 ? c->gtab_bits : c->d_gtab ? 8u : 0u;
-    if (table_bits_wanted) *table_bits_wanted = c->gtab_bits_wanted ? c->gtab_bits_wanted : env_u32("VGEN_GTAB_BITS", c->gtab_bits_pref ? c->gtab_bits_pref : 24);
+    if (table_bits_wanted) *table_bits_wanted = c->gtab_bits_wanted ? c->gtab_bits_wanted : wanted_table_bits(c, nullptr);
     if (note) *note = c->gtab_note;
     return VGEN_OK;
 }

@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -35,10 +36,38 @@ struct vgen_ctx {
     uint32_t *d_gtab16 = nullptr;        // wide fixed-window generator table (gtab_bits bits): built on the device from d_gtab at first use and
                                          // SHARED by the process's contexts on this device (runtime.cpp: GtabCache; a reference, not owned)
     uint32_t gtab_bits = 0;              // width of d_gtab16
-    uint32_t gtab_bits_wanted = 0;       // width asked for (VGEN_GTAB_BITS, else gtab_bits_pref, else 24) once a dispatch wanted a wide table
+    uint32_t gtab_bits_wanted = 0;       // width asked for (see wanted_table_bits in runtime.cpp) once a dispatch wanted a wide table
+    uint32_t gtab_param = 0;             // vgen_params.table_bits: the caller's choice for this context (0 = automatic)
+    uint32_t gtab_env = 0;               // VGEN_GTAB_BITS as it stood at vgen_create: test override of everything else (0 = unset)
     uint32_t gtab_bits_pref = 0;         // the scan loop's choice for this scan (rt_prefer_table_bits): wider tables pay off on long scans
-    bool gtab_wide_failed = false;       // no wide table could be had (or VGEN_GTAB_BITS=8): stay on the 8-bit one
+    uint32_t gtab_bits_cap = 0;          // ... and its cap (vgen_scan_config.table_bits_max; 0 = none)
+    bool gtab_wide_failed = false;       // no wide table could be had (or the 8-bit one was asked for): stay on the 8-bit one
     std::string gtab_note;               // why the table in use is narrower than the one asked for (vgen_get_resources)
+    // A table replaced by a wider one stays allocated while dispatches that read it may be in flight; it is let go at the next
+    // moment the context has nothing in flight (hipFree synchronises the device: never beside a running scan).
+    uint32_t *gtab_old = nullptr;
+    // The wider table on its way (runtime.cpp: "replacing the table in use"): its two buffers are allocated by a thread of
+    // their own (hipMalloc of 138 GB takes ~0.5 s), then built in SLICES that ride in front of the context's dispatches on
+    // the frames' own streams — no extra stream (all twelve hardware queues belong to the frames), no pause.
+    struct GtabJob {
+        uint32_t bits = 0;
+        std::thread alloc;
+        std::atomic<int> alloc_state{0};     // 0 running, 1 done, 2 failed
+        uint32_t *wide = nullptr, *small = nullptr;
+        std::string why;
+        int phase = 0;                       // 0: half-width table, 1: the wide table from it, 2: complete
+        unsigned long long next = 0;         // lanes of the phase already issued
+        uint32_t pending = 0;                // frames in flight that carry a slice of the current phase
+        uint64_t slices = 0;
+    };
+    std::unique_ptr<GtabJob> gtab_job;
+    uint32_t gtab_job_failed_bits = 0;   // a width whose background build failed: not tried again by this context
+    uint32_t gtab_waiting_bits = 0;      // another context of this process is building this width for the device: adopt it when it is there
+    uint64_t mem_budget = 0;             // vgen_params.device_mem_budget_bytes (0 = automatic)
+    uint64_t frames_bytes = 0;           // device memory fixed at vgen_create (scratch slab, match rings, offset table, filter program)
+    uint64_t mode_bytes = 0;             // device memory made at first use (dump buffers, arbitrary-scalar slab, 8-bit table, automaton, LUT)
+    uint64_t pinned_bytes = 0;           // page-locked host memory (match-ring and dump mirrors)
+    bool trace_create = false;           // VGEN_TRACE_CREATE at vgen_create
     vg::DevFilter *d_filter = nullptr;   // current device filter program
     uint32_t *d_dfa = nullptr;           // DEVF_DFA automaton of the current filter
     uint32_t *d_chk_lut = nullptr;       // Bech32 checksum tables of the current filter (when it tests the checksum)
@@ -68,6 +97,7 @@ struct vgen_ctx {
         bool timing_fresh = true;        // last_ms / last_total_ms already read from the events
         float last_ms = 0.f;             // dominant kernel (seq_bwd) of the last completed dispatch
         float last_total_ms = 0.f;       // whole dispatch: fwd + inv + bwd
+        bool carries_slice = false;      // the dispatch in flight has a slice of the table build in front of it (GtabJob::pending)
         uint32_t clk_cycles_seen = 0, clk_ticks_seen = 0;   // match-header clock sums at the last vgen_wait
         uint32_t last_clk_cycles = 0, last_clk_ticks = 0;   // ... and what the last dispatch added to them
     };
@@ -153,8 +183,10 @@ int rt_clock_probe_read(vgen_ctx *ctx, double *mhz);
 // The generator-table width the next scalar-multiplication dispatches should use when VGEN_GTAB_BITS does not say (0 = the default, 24).
 // A wider table costs more to make (24 bits: 11.8 GB, ~30 ms; 27 signed: 21.5 GB, ~60 ms; 29 signed: 138 GB, 0.7 - 2.3 s) and saves additions on
 // every key after (10 / 9 / 8 per multiplication: +5 % / +12.5 %): the scan loop asks for what the expected length of the scan pays for.
-// Takes effect at the next dispatch that finds no frame of the context in flight.
-void rt_prefer_table_bits(vgen_ctx *ctx, uint32_t bits);
+// `cap` (vgen_scan_config.table_bits_max; 0 = none) bounds it by additions per multiplication.  A wider table than the one in use is
+// built in the background while the dispatches go on (runtime.cpp) and taken into use when complete: nothing waits for it.
+void rt_prefer_table_bits(vgen_ctx *ctx, uint32_t bits, uint32_t cap = 0);
+int rt_get_memory(const vgen_ctx *ctx, vgen_memory_info *out);
 int rt_get_resources(const vgen_ctx *ctx, uint32_t *dump_frames, uint32_t *table_bits, uint32_t *table_bits_wanted, std::string *note);
 
 }  // namespace vg

@@ -471,7 +471,7 @@ struct SlotProgress {
 // (another context committed them before it failed) and every batch committed here is counted in.
 // *range_done: the shard stopped because its range ran out.
 int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cfg, vgen_progress_cb cb, void *user,
-               volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
+               const volatile int32_t *stop, std::atomic<uint64_t> *shared_found, std::atomic<uint64_t> *shared_ops,
                MatchList &matches, uint64_t &total_ops, Checkpoint *ck = nullptr, uint32_t ck_slot = 0,
                bool *range_done = nullptr, SlotProgress *slot = nullptr, const RndSeed *scan_seed = nullptr) {
     if (cfg->format != ctx->format) return ctx->fail(VGEN_E_INVALID, "scan format differs from the context's format");
@@ -520,6 +520,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
     // 21.5 GB; the 29-bit signed one (8 additions, +12.5 %) takes 0.7 - 2.3 s and 138 of the device's 288 GB (profiles/r04_gtab_signed.txt):
     // from 3 s of expected scanning the first pays for itself several times over, from 30 s the second.
     // From the keys the scan can expect to test — the range, max_batches, or count / the filter's selectivity — at the path's rate.
+    // This is a PREFERENCE: the caller bounds it (cfg->table_bits_max, vgen_params.table_bits / device_mem_budget_bytes), the runtime
+    // checks it against the device's free memory, builds the wider table in the background while this loop dispatches on the one
+    // it has, and takes it into use when it is complete (runtime.cpp) — the scan never waits for a table.
     if (random_keys || ctx->format == VGF_P2TR) {
         // (a count-limited scan whose pattern has no selectivity estimate — the whole DFA on the device — is taken for short)
         double keys = cfg->count == UINT64_MAX ? 1e30 : 0.0;
@@ -538,7 +541,7 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
             }
         }
         const double seconds = keys / (random_keys && ctx->endo ? 5.5e9 : 1.35e9) / (double)shards;
-        rt_prefer_table_bits(ctx, seconds >= 30.0 ? 29u : seconds >= 3.0 ? 27u : 0u);
+        rt_prefer_table_bits(ctx, seconds >= 30.0 ? 29u : seconds >= 3.0 ? 27u : 0u, cfg->table_bits_max);
     }
 
     // independent random keys: candidate index = batch number x N within stream `shard` of the seed
@@ -677,12 +680,12 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         return true;
     };
     // A scan of the scalar-multiplication paths that turns out LONG although nothing said so up front (no selectivity estimate, a
-    // count that keeps not being reached): after 5 s it drains its frames once, moves to the 29-bit signed table (0.7 - 2.3 s,
-    // +12.5 % from then on) and goes on.  Never when VGEN_GTAB_BITS fixes the width.
+    // count that keeps not being reached): after 5 s it asks for the 29-bit signed table (+12.5 % once it is there) and simply goes
+    // on — the runtime builds it behind the dispatches (round 4 drained the frames and paused 0.7 - 2.3 s here).
     const bool table_path = random_keys || ctx->format == VGF_P2TR;
     const auto scan_t0 = std::chrono::steady_clock::now();
-    bool upgrade_pending = false, upgrade_done = getenv("VGEN_GTAB_BITS") != nullptr;
-    auto may_launch = [&]() { return !upgrade_pending && can_dispatch() && !stopped() && found() < count; };
+    bool upgrade_asked = false;
+    auto may_launch = [&]() { return can_dispatch() && !stopped() && found() < count; };
     // (a frame's stream — a hardware queue of its own — is created at its first dispatch and takes ~8 ms: a fresh context
     // starts on frame 0 alone, so that an easy pattern's first match does not wait for a second queue it never needs)
     auto prime = [&]() {
@@ -832,16 +835,9 @@ int scan_shard(vgen_ctx *ctx, const vgen_filter &flt, const vgen_scan_config *cf
         batch_matches.clear();
         if (cb) cb(shared_ops ? tested : total_ops, user);   // multi-device: the wrapper adds N to the shared count under its lock
         if (found() >= count && !dispatched_next) break;   // gpu.rs:1111
-        if (table_path && !upgrade_done && !upgrade_pending && ctx->gtab_bits != 29 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - scan_t0).count() >= 5.0)
-            upgrade_pending = true;                        // stop launching: the frames in flight drain through this loop
-        if (upgrade_pending && order.empty()) {
-            rt_prefer_table_bits(ctx, 29);                 // the next dispatch finds no frame in flight and switches (runtime.cpp: ensure_gtab)
-            upgrade_pending = false;
-            upgrade_done = true;
-            active = 0;
-            prime();
-            continue;
+        if (table_path && !upgrade_asked && std::chrono::duration<double>(std::chrono::steady_clock::now() - scan_t0).count() >= 5.0) {
+            rt_prefer_table_bits(ctx, 29, cfg->table_bits_max);   // taken into use when it is complete; nothing waits
+            upgrade_asked = true;
         }
         if (ramp_later && active < nf && may_launch()) {
             // not ready and no helper for this stream kind: create it here and now, as before
@@ -961,9 +957,21 @@ int finish_result(vgen_ctx *ctx, uint32_t format, std::vector<LiteMatch> &matche
 
 }  // namespace
 
-extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg, vgen_progress_cb cb,
-                         void *user, volatile int32_t *stop, vgen_scan_result *out) {
-    if (!ctx || !pattern || !cfg || !out || cfg->struct_size != sizeof(vgen_scan_config)) return VGEN_E_INVALID;
+// ABI 4's vgen_scan_config, or ABI 3's 136 bytes (no table_bits_max: no cap): -> the full structure, fields beyond the caller's zero.
+static bool normalise_scan_config(const vgen_scan_config *in, vgen_scan_config &full) {
+    constexpr uint32_t CONFIG_ABI3 = 136;
+    if (!in || (in->struct_size != sizeof(vgen_scan_config) && in->struct_size != CONFIG_ABI3)) return false;
+    memset(&full, 0, sizeof full);
+    memcpy(&full, in, in->struct_size);
+    full.struct_size = sizeof full;
+    return true;
+}
+
+extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_config *cfg_in, vgen_progress_cb cb,
+                         void *user, const volatile int32_t *stop, vgen_scan_result *out) {
+    vgen_scan_config cfg_full;
+    if (!ctx || !pattern || !out || !normalise_scan_config(cfg_in, cfg_full)) return VGEN_E_INVALID;
+    const vgen_scan_config *cfg = &cfg_full;
     memset(out, 0, sizeof *out);
     const auto t0 = std::chrono::steady_clock::now();
     vgen_filter flt;
@@ -1024,9 +1032,11 @@ extern "C" int vgen_scan(vgen_ctx *ctx, const char *pattern, const vgen_scan_con
 // Multi-device scan: one host thread per context, batches striped over the contexts (context i takes
 // global batches b = i mod n), a shared match counter and stop flag, results merged in ascending key
 // order and truncated to `count` (no collective, host-side aggregation only).
-extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *pattern, const vgen_scan_config *cfg,
-                               vgen_progress_cb cb, void *user, volatile int32_t *stop, vgen_scan_result *out) {
-    if (!ctxs || n_ctx == 0 || !pattern || !cfg || !out || cfg->struct_size != sizeof(vgen_scan_config)) return VGEN_E_INVALID;
+extern "C" int vgen_scan_multi(vgen_ctx **ctxs, uint32_t n_ctx, const char *pattern, const vgen_scan_config *cfg_in,
+                               vgen_progress_cb cb, void *user, const volatile int32_t *stop, vgen_scan_result *out) {
+    vgen_scan_config cfg_full;
+    if (!ctxs || n_ctx == 0 || !pattern || !out || !normalise_scan_config(cfg_in, cfg_full)) return VGEN_E_INVALID;
+    const vgen_scan_config *cfg = &cfg_full;
     for (uint32_t i = 0; i < n_ctx; i++)
         if (!ctxs[i] || ctxs[i]->batch != ctxs[0]->batch) return VGEN_E_INVALID;
     memset(out, 0, sizeof *out);
