@@ -176,12 +176,14 @@ class Pipeline:
         first = self.next_step
         clock = time.perf_counter
         td = tw = 0.0
+        stamps, t_last_issue = [], None    # host_times: when each step was seen complete; when the last dispatch call returned
         while issued < min(F, n_steps):
             if host_times:
                 t = clock()
             r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), fi)
             if host_times:
-                td += clock() - t
+                t_last_issue = clock()
+                td += t_last_issue - t
             issued += 1
             fi = (fi + 1) % F
         while done < n_steps:
@@ -189,7 +191,9 @@ class Pipeline:
                 t = clock()
             n, _ = r.wait(fw)
             if host_times:
-                tw += clock() - t
+                t_done = clock()
+                tw += t_done - t
+                stamps.append(t_done)
             if collect:
                 kms.append(r.kernel_ms(fw))
             cand += n
@@ -199,11 +203,13 @@ class Pipeline:
                     t = clock()
                 r.dispatch(batch_key(self.k0, first + issued, self.world, self.rank, self.n), fw)
                 if host_times:
-                    td += clock() - t
+                    t_last_issue = clock()
+                    td += t_last_issue - t
                 issued += 1
             fw = (fw + 1) % F
         self.next_step = first + n_steps
         self.host_dispatch_s, self.host_wait_s = td, tw
+        self.completion_stamps, self.last_issue_stamp = stamps, t_last_issue
         return cand, kms
 
     def run_seconds(self, seconds, min_steps=0, clock=False):
@@ -801,6 +807,22 @@ def main():
         elapsed = slowest_rank_s = t1 - t0
     keys = world * args.steps * N * K6
     value = keys / elapsed / 1e6
+    # What the region is made of, from this rank's own clock reads (no extra call in the timed loop: the stamps are the ones
+    # host_times already takes): fill = start -> the first step seen complete (the chain seq_fwd -> seq_inv -> seq_bwd of the
+    # first dispatches, with nothing to overlap it); steady = first completion -> the last dispatch call returning (every
+    # completion is answered by a new dispatch: the device stays full); drain = last issue -> the closing synchronize (the last
+    # `frames` dispatches run out, the final launches below four waves per SIMD).
+    region = None
+    if pipe.completion_stamps and pipe.last_issue_stamp:
+        st, li = pipe.completion_stamps, max(pipe.last_issue_stamp, pipe.completion_stamps[0])
+        in_steady = sum(1 for x in st if st[0] < x <= li)
+        region = {"fill_us": round((st[0] - t0) * 1e6, 1), "steady_us": round((li - st[0]) * 1e6, 1), "drain_us": round((t1 - li) * 1e6, 1),
+                  "steps_completed_in_steady": in_steady,
+                  "steady_mkeys": round(in_steady * N * K6 / (li - st[0]) / 1e6, 1) if li > st[0] and in_steady else None,
+                  "drain_steps": len(st) - 1 - in_steady, "closing_sync_us": round((t1 - st[-1]) * 1e6, 1),
+                  "completion_us": [round((x - t0) * 1e6, 1) for x in st[:64]],
+                  "how": "host clock of this rank: fill = region start -> first step seen complete; steady = -> return of the last dispatch call; "
+                         "drain = -> after the closing synchronize.  completion_us: when each step's wait returned (in order, first 64)"}
     # shader clock during the region, from the samples its last min(F, steps) seq_bwd launches left in their frames
     # (read after the region: nothing is added to the timed loop)
     region_mhz = None
@@ -910,6 +932,7 @@ def main():
                    "cpu_affinity": {k: pin.get(k) for k in ("pinned", "numa_node", "cpus", "pci", "why_not") if pin.get(k) is not None},
                    "host_us_per_step": {"dispatch": mine["host_dispatch_us"], "wait": mine["host_wait_us"]}},
         "sustained": sustained,
+        "timing_region": region,
         "roofline": roofline,
     }
     if world > 1:

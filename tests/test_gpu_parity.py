@@ -196,20 +196,22 @@ def test_both_frames_and_repeat_are_consistent(vg, vo):
 
 @pytest.mark.parametrize("fmt,pattern", [(0, "^1Cat"), (1, "^bc1qaa")])
 def test_one_frame_contexts_run_the_variant_without_yields_and_find_the_same_keys(vg, vo, fmt, pattern, monkeypatch):
-    """A context with ONE frame in flight launches seq_bwd_kernel<.., LONE> (hipcc's schedule of core/hash.h instead of the
-    scheduled hash block, kernels.hip: payload_from_point): dump and filter mode of both variants against the oracle."""
+    """A dispatch issued while at most one other frame of its context is in flight launches seq_bwd_kernel<.., LONE> (hipcc's schedule
+    of core/hash.h instead of the scheduled hash block, kernels.hip: payload_from_point; runtime.cpp: rt_dispatch) — whatever the number
+    of frames the context was created with: dump and filter mode of both variants against the oracle."""
     batch = 1 << 16
     start = vo.seed_key(11, fmt)
     ref = vo.payload_seq(fmt, start, batch)
     p = vg.Pattern(pattern, False, vg.AddressFormat(fmt))
     assert p.device_kind != 0
     found = []
-    for frames, twin in ((1, "1"), (3, "1"), (1, "0")):      # the last: one frame, but the steady-state kernel (the counter passes' switch)
+    # one frame; twelve frames driven one dispatch at a time (the twin); the same with the twin switched off (the steady-state kernel)
+    for frames, twin in ((1, "1"), (12, "1"), (3, "0"), (1, "0")):
         monkeypatch.setenv("VGEN_LONE_VARIANT", twin)
         r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=frames, match_cap=65536)
         r.set_filter(None)
-        r.dispatch(start, 0)
-        assert r.await_result(0)[0] == ref
+        r.dispatch(start, frames - 1)
+        assert r.await_result(frames - 1)[0] == ref
         r.set_filter(p)
         r.dispatch(start, 0)
         recs, _, _ = r.await_result(0)
@@ -217,8 +219,43 @@ def test_one_frame_contexts_run_the_variant_without_yields_and_find_the_same_key
             assert payload == ref[20 * i:20 * i + 20]
         found.append([i for i, payload in recs if p.matches(vg.address_from_payload(fmt, payload))])
         r.close()
-    assert found[0] == found[1] == found[2]
+    assert found[0] == found[1] == found[2] == found[3]
     assert found[0] == [i for i in range(batch) if p.matches(vg.address_from_payload(fmt, ref[20 * i:20 * i + 20]))]
+    # a burst on a six-frame context: the first two dispatches find at most one other in flight (the twin), the rest run the
+    # steady-state kernel beside them — every frame's dump is the oracle's
+    monkeypatch.setenv("VGEN_LONE_VARIANT", "1")
+    r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=6, match_cap=65536)
+    r.set_filter(None)
+    for f in range(6):
+        r.dispatch(start + f * batch, f)
+    for f in range(6):
+        assert r.await_result(f)[0] == (ref if f == 0 else vo.payload_seq(fmt, start + f * batch, batch)), f
+    r.close()
+
+
+@pytest.mark.parametrize("fmt,pattern", [(0, "^1Cat"), (1, "dead$"), (2, "^3Cat"), (0, "1[Oo]ri")])
+def test_split_form_point_arithmetic_and_hash_kernels_give_the_fused_kernels_results(vg, vo, fmt, pattern, monkeypatch):
+    """VGEN_SPLIT=1 (an A/B switch, profiles/r05_occupancy_ab.txt): seq_bwd_kernel<.., SPLIT> parks x and the prefix byte of every key,
+    seq_hash_kernel hashes 1 / 4 / 16 keys per lane — dump, prefilter and on-device DFA against the oracle."""
+    batch = 1 << 16
+    start = vo.seed_key(12, fmt)
+    ref = vo.payload_seq(fmt, start, batch)
+    p = vg.Pattern(pattern, False, vg.AddressFormat(fmt))
+    want = [i for i in range(batch) if p.matches(vg.address_from_payload(fmt, ref[20 * i:20 * i + 20]))]
+    monkeypatch.setenv("VGEN_SPLIT", "1")
+    for kpl in ("1", "4", "16"):
+        monkeypatch.setenv("VGEN_HASH_KPL", kpl)
+        r = vg.GpuRunner(batch_size=batch, fmt=vg.AddressFormat(fmt), frames=2, match_cap=65536)
+        r.set_filter(None)
+        r.dispatch(start, 0)
+        assert r.await_result(0)[0] == ref
+        r.set_filter(p)
+        r.dispatch(start, 1)
+        recs, _, _ = r.await_result(1)
+        for i, payload in recs:
+            assert payload == ref[20 * i:20 * i + 20]
+        assert [i for i, payload in recs if p.matches(vg.address_from_payload(fmt, payload))] == want
+        r.close()
 
 
 CASES = [

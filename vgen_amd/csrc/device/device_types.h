@@ -98,6 +98,8 @@ struct SeqArgs {
     uint32_t *pre;             // scratch: prefix products [S][9][lanes]
     uint32_t *tree;            // scratch: product-tree nodes [groups][9][SEQ_WG]
     uint32_t *root;            // scratch: tree roots / their inverses [9][groups]
+    uint32_t *xs;              // scratch of the split form (compressed-key formats): [9][N] — eight words of x and the prefix byte 0x02 | parity(y) of
+                               // every key, slot (2j + sgn) * lanes + u; nullptr = the fused seq_bwd_kernel does everything
     uint32_t lanes;            // N / (2*S)
     uint32_t groups;           // lanes / SEQ_WG
     uint32_t n;                // N
@@ -110,7 +112,7 @@ struct SeqArgs {
     uint32_t gtab_bits;        // window width of gtab16 (16 | 20 | 22 | 24)
     uint32_t dfa_bytes;        // 0 = prefilter mode
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
-    uint32_t reserved0;
+    uint32_t hash_kpl;         // split form: keys per lane of seq_hash_kernel (a divisor of 2S)
     uint32_t endo;             // seq_bwd: test the six endomorphism / negation images of every point (kernels.hip: ENDO)
     uint32_t lone;             // seq_bwd: this context keeps ONE frame in flight (frames = 1): launch the variant without issue-slot yields
     // P2TR only: the tweaked points Q = P + t*G of a dispatch wait for a second shared inversion.

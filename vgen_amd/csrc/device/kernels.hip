@@ -280,6 +280,18 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 #ifndef VG_SEQ_WAVES_FULL20
 #define VG_SEQ_WAVES_FULL20 4
 #endif
+#ifndef VG_SEQ_WAVES_EC
+#define VG_SEQ_WAVES_EC 4      // seq_bwd_kernel<.., SPLIT>: the point arithmetic alone
+#endif
+#ifndef VG_SEQ_WAVES_HASH
+#define VG_SEQ_WAVES_HASH 8    // seq_hash_kernel: the generated hash block needs 28 registers + the key's nine words
+#endif
+#ifndef VG_EC_PRIO
+#define VG_EC_PRIO 0
+#endif
+#ifndef VG_SEQ_WAVES_HASH_FULL
+#define VG_SEQ_WAVES_HASH_FULL 6
+#endif
 template <int FMT, bool FULL>
 struct SeqWaves {
     static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH
@@ -297,9 +309,16 @@ struct SeqWaves {
 // their negations — so six keys are hashed for one point's arithmetic plus two multiplications by beta.  Image `variant`
 // = s * 3 + e (e = power of beta, s = negated) of key index i is reported / dumped at variant * n + i.
 // LONE (P2PKH / P2WPKH with a prefilter only): the variant for contexts that keep one frame in flight, see payload_from_point.
-template <int FMT, bool FULL, bool ENDO = false, bool LONE = false>
-__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SeqWaves<FMT, FULL>::value, SeqWaves<FMT, FULL>::value)))
+// SPLIT (the compressed-key formats without ENDO): the kernel stops at the affine point — it parks the eight words of x and the
+// key's prefix byte (0x02 | parity of y) per key in args.xs and leaves hashes, filter and output to seq_hash_kernel, which runs one
+// key per lane at eight waves per SIMD (see there).
+template <int FMT, bool FULL, bool ENDO = false, bool LONE = false, bool SPLIT = false>
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL>::value, SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL>::value)))
 seq_bwd_kernel(const SeqArgs args) {
+#if VG_EC_PRIO
+    if (SPLIT) __builtin_amdgcn_s_setprio(VG_EC_PRIO);   // the point arithmetic has the memory bubbles: it goes first when it can issue, the hash waves fill in
+#endif
+    static_assert(!SPLIT || (!FULL && !ENDO && !LONE && FMT == VGF_P2PKH), "the split form parks compressed keys: x and the parity of y");
     __shared__ u32 tree[9 * WG];
     __shared__ u32 ypark[ENDO && (FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM) ? 9 * WG : 1];   // ENDO: the point's y
     extern __shared__ u32 dyn_lds[];   // FULL: the DFA blob
@@ -321,7 +340,7 @@ seq_bwd_kernel(const SeqArgs args) {
     // shader-clock sample: the first wave of the launch reads the shader-clock counter (s_memtime) and the constant
     // 100 MHz counter (s_memrealtime) when it starts and when it ends, and adds both spans to the frame's match
     // header — the clock the CUs really ran at while this very kernel executed, at the cost of four scalar reads
-    const bool stamp = FMT != VGF_P2TR && blockIdx.x == 0 && args.mhdr != nullptr;
+    const bool stamp = FMT != VGF_P2TR && !SPLIT && blockIdx.x == 0 && args.mhdr != nullptr;
     const unsigned long long stamp_c0 = stamp ? clock64() : 0ull, stamp_w0 = stamp ? wall_clock64() : 0ull;
 
     const u32 *tg = args.tree + (size_t)blockIdx.x * 9 * WG;
@@ -464,6 +483,16 @@ seq_bwd_kernel(const SeqArgs args) {
                 continue;
             }
 
+            if (SPLIT) {
+                // key step (2j + sgn) of lane u -> slot (2j + sgn) * lanes + u of the dispatch, word-major: a wave's stores are 64 consecutive dwords
+                u32 xw[8];
+                fe_to_words(x3, xw);
+                u32 *o = args.xs + (size_t)((u32)j * 2u + (u32)sgn) * lanes + u;
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[(size_t)i * args.n] = xw[i];
+                o[(size_t)8 * args.n] = 2u | (y3.n[0] & 1u);
+                continue;
+            }
             const u32 index = sgn ? (half - (u + 1) * S + (u32)j) : (half + u * S + (u32)j);
             if (ENDO) {
                 // compressed-key formats need only the parity of y (flipped for the negations); the others the canonical
@@ -566,6 +595,77 @@ seq_bwd_kernel(const SeqArgs args) {
 #pragma unroll
         for (int i = 0; i < 9; i++) t2[i * WG + tid] = tree[i * WG + tid];
         if (tid < 9) args.root2[(size_t)tid * args.groups + blockIdx.x] = tree[tid * WG + 1];
+    }
+}
+
+// ---- stage 4 (split form): one key per lane — hashes, filter, output -------------------------------------------------
+//
+// The hash pair is three quarters of a key's instructions and needs 28 registers; the point arithmetic in front of it needs 128.
+// In one kernel the pair therefore runs at FOUR waves per SIMD and one launch of 2^20 keys is one wave per SIMD: the device is
+// only full with a dozen dispatches in flight, and a short run is mostly fill and drain.  Split, the pair runs at EIGHT waves per
+// SIMD (where its issue-slot yields pay most, profiles/r04_hash_yield_ubench.jsonl) and ONE launch is sixteen waves per SIMD:
+// the device is full from the first dispatch.  The price: 36 B per key through L2 / Infinity Cache between the two kernels.
+// grid = (lanes / WG, 2S / hash_kpl): a lane hashes hash_kpl keys, the key steps 2j + sgn = blockIdx.y * hash_kpl + k of lane
+// u = blockIdx.x * WG + tid of seq_bwd_kernel<.., SPLIT>.  hash_kpl sets how many waves per SIMD ONE launch brings (16 / hash_kpl at
+// 2^20 keys): launches that fill the SIMDs' wave slots by themselves (hash_kpl = 1, 2) keep the other frames' short kernels waiting
+// for slots and the command processor's pipes busy placing workgroups; 4 leaves room for a second launch and for the point
+// arithmetic of the next dispatches beside it (profiles/r05_split_ab.txt).
+template <int FMT, bool FULL>
+struct HashWaves {   // the Base58Check encoder + DFA walk of the P2PKH matcher need 80 registers (64: 44 B of scratch)
+    static constexpr int value = FULL && FMT == VGF_P2PKH ? VG_SEQ_WAVES_HASH_FULL : VG_SEQ_WAVES_HASH;
+};
+template <int FMT, bool FULL>
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(HashWaves<FMT, FULL>::value, HashWaves<FMT, FULL>::value)))
+seq_hash_kernel(const SeqArgs args) {
+    static_assert(FMT == VGF_P2PKH || FMT == VGF_P2SH_P2WPKH, "compressed-key formats (P2WPKH shares P2PKH's payload)");
+    extern __shared__ u32 dfa_lds[];   // FULL: the DFA blob
+    const int tid = threadIdx.x;
+    if (FULL) {
+        for (u32 i = tid; i < args.dfa_bytes / 4; i += WG) dfa_lds[i] = args.dfa_blob[i];
+        __syncthreads();
+    }
+    const u32 lanes = args.lanes, S = args.s, half = args.n >> 1;
+    const u32 u = blockIdx.x * WG + tid;
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && args.mhdr != nullptr;   // shader-clock sample, as seq_bwd_kernel's
+    const unsigned long long stamp_c0 = stamp ? clock64() : 0ull, stamp_w0 = stamp ? wall_clock64() : 0ull;
+    const bool dump = args.dump != nullptr;
+#pragma unroll 1
+    for (u32 k = 0; k < args.hash_kpl; k++) {
+        const u32 step = blockIdx.y * args.hash_kpl + k;
+        const u32 *in = args.xs + (size_t)step * lanes + u;
+        u32 xw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) xw[i] = in[(size_t)i * args.n];
+        const u32 prefix = in[(size_t)8 * args.n];
+        u32 pl[5];
+        if (FMT == VGF_P2SH_P2WPKH) {
+            u32 h[5];
+            hash160_pub33_block(prefix, xw, h);
+            hash160_script22_block(h, pl);
+        } else {
+            hash160_pub33_block(prefix, xw, pl);
+        }
+        const u32 j = step >> 1, sgn = step & 1u;
+        const u32 index = sgn ? (half - (u + 1) * S + j) : (half + u * S + j);
+        if (dump) {
+            u32 *o = args.dump + (size_t)index * 5;
+#pragma unroll
+            for (int i = 0; i < 5; i++) o[i] = pl[i];
+        } else {
+            const bool hit = FULL ? dfa_match_payload_n<5, MatchFmt<FMT>::value>(dfa_lds, (int)args.fmt, pl) : filter_eval_n<5>(args.filter, pl);
+            const u32 slot = match_slot(args.mhdr, hit, args.match_base);   // one atomic per wave
+            if (hit && slot < args.match_cap) {
+                DevMatch *m = args.mrec + slot;
+                m->index = index;
+                m->reserved = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) m->payload[i] = i < 5 ? pl[i] : 0u;
+            }
+        }
+    }
+    if (stamp && tid == 0) {
+        args.mhdr->clk_cycles += (u32)(clock64() - stamp_c0);
+        args.mhdr->clk_ticks += (u32)(wall_clock64() - stamp_w0);
     }
 }
 
@@ -1641,6 +1741,17 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         if (full) hipLaunchKernelGGL((p2tr_finish_kernel<true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
         else hipLaunchKernelGGL((p2tr_finish_kernel<false>), dim3(a.groups), dim3(WG), 0, stream, a);
+        return hipGetLastError();
+    }
+    if (a.xs && !a.endo && (FMT == VGF_P2PKH || FMT == VGF_P2SH_P2WPKH)) {
+        // the split form: point arithmetic (x and the prefix byte parked per key), then one key per lane through the hashes
+        constexpr int HF = FMT == VGF_P2SH_P2WPKH ? VGF_P2SH_P2WPKH : VGF_P2PKH;
+        hipLaunchKernelGGL((seq_bwd_kernel<VGF_P2PKH, false, false, false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (a.hash_kpl == 0 || (2 * a.s) % a.hash_kpl != 0) return hipErrorInvalidValue;
+        if (full) hipLaunchKernelGGL((seq_hash_kernel<HF, true>), dim3(a.groups, 2 * a.s / a.hash_kpl), dim3(WG), a.dfa_bytes, stream, a);
+        else hipLaunchKernelGGL((seq_hash_kernel<HF, false>), dim3(a.groups, 2 * a.s / a.hash_kpl), dim3(WG), 0, stream, a);
         return hipGetLastError();
     }
     if (full && a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), true, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);

@@ -36,9 +36,15 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
     return x > 0 ? (uint32_t)x : dflt;
 }
 
-// pre [S][9][lanes] | tree [groups][9][WG] | root [9][groups]
+// The compressed-key formats run the per-key stage split in two (kernels.hip: seq_bwd_kernel<.., SPLIT> -> seq_hash_kernel): x and the
+// prefix byte of every key wait in the frame's scratch between them.
+bool split_format(const vgen_ctx *c) {
+    return c->split && (c->format == VGF_P2PKH || c->format == VGF_P2WPKH || c->format == VGF_P2SH_P2WPKH);
+}
+
+// pre [S][9][lanes] | tree [groups][9][WG] | root [9][groups] | split form: xs [9][batch]
 size_t scratch_words(const vgen_ctx *c) {
-    return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups;
+    return (size_t)c->S * 9 * c->lanes + (size_t)c->groups * 9 * SEQ_WG + (size_t)9 * c->groups + (split_format(c) ? (size_t)9 * c->batch : 0);
 }
 
 // P2TR: tq [2S][27][lanes] | tq_flag [2S][lanes] | tree2 [groups][9][WG] | root2 [9][groups]
@@ -267,9 +273,13 @@ int rt_create(const vgen_params *p_in, vgen_ctx **out, std::string &err) {
     c->timing = (p->flags & VGEN_FLAG_TIMING) != 0;
     c->endo = (p->flags & VGEN_FLAG_ENDO) != 0 && p->format != VGF_P2TR;
     c->S = env_u32("VGEN_SEQ_S", 8);
+    c->hash_kpl = env_u32("VGEN_HASH_KPL", 4);   // (A/B: tools/split_ab.sh)
+    if (const char *v = getenv("VGEN_SPLIT")) c->split = v[0] == '1';   // A/B switch (profiles/r05_occupancy_ab.txt: measured, not shipped)
     {   // "0": one-frame contexts launch the steady-state kernel too (counter passes: tools/pmc_valu.sh)
         const char *v = getenv("VGEN_LONE_VARIANT");
         c->lone_variant = !(v && v[0] == '0');
+        c->lone_max_others = env_u32("VGEN_LONE_MAX_OTHERS", 1);   // A/B override (tools/frames_lone_ab.sh); 0 is a value here
+        if (const char *w = getenv("VGEN_LONE_MAX_OTHERS")) if (w[0] == '0') c->lone_max_others = 0;
     }
     auto bail = [&](int st, const std::string &m) {
         err = m;
@@ -281,6 +291,7 @@ int rt_create(const vgen_params *p_in, vgen_ctx **out, std::string &err) {
                                     "collapses to ~1 Gkeys/s)");
     c->hw_queues = env_u32("GPU_MAX_HW_QUEUES", 4);   // the HIP runtime's own setting: queues per priority level
     if (c->S < 2 || c->S > SEQ_MAX_S || (c->S & (c->S - 1))) return bail(VGEN_E_INVALID, "VGEN_SEQ_S must be a power of two in [2, 16]");
+    if (c->hash_kpl == 0 || (2 * c->S) % c->hash_kpl != 0) c->hash_kpl = 1;
     if (c->batch % 8192 != 0 || c->batch % (2 * SEQ_WG * c->S) != 0 || c->batch < 8192)
         return bail(VGEN_E_INVALID, "batch_size must be a multiple of 8192 (and of 512*S)");
     // the largest dispatch the kernels are laid out and tested for: 32-bit indices into 6 x batch payload slots, 24 bits of
@@ -943,7 +954,10 @@ int gtab_job_step(vgen_ctx *c, vgen_ctx::Frame &f) {
         if (j.next < total) {
             // ~1/8 of the dispatch's own work: a lane of phase 0 is a whole 8-bit multiplication + inversion (~3 keys' worth of a
             // scalar-multiplication dispatch), a lane of phase 1 makes eight entries (~2 keys' worth)
-            unsigned long long count = j.phase == 0 ? c->batch / 32 : c->batch / 16;
+            // ... but never less than one wave per SIMD of the device (phase 0: half a wave): a small dispatch is a chain of
+            // latency-bound launches on a mostly idle device, where such a slice costs its own latency (~0.1 ms) and nothing else —
+            // sized by the batch alone, a context of 8 192-key dispatches needed 300 000 of them for the 27-bit table
+            unsigned long long count = j.phase == 0 ? std::max<unsigned long long>(c->batch / 32, 32768) : std::max<unsigned long long>(c->batch / 16, 65536);
             count = std::max<unsigned long long>(256, count & ~255ull);
             HIP_TRY(c, launch_gen_table_slice(c->d_gtab, j.wide, j.small, j.bits, j.phase, j.next, count, f.s));
             j.next += count;
@@ -1189,11 +1203,23 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     a.pre = f.d_scratch;
     a.tree = a.pre + (size_t)S * 9 * c->lanes;
     a.root = a.tree + (size_t)c->groups * 9 * SEQ_WG;
+    if (split_format(c)) {
+        a.xs = a.root + (size_t)9 * c->groups;
+        a.hash_kpl = c->hash_kpl;
+    }
     a.lanes = c->lanes;
     a.groups = c->groups;
     a.n = c->batch;
     a.s = S;
-    a.lone = c->frames == 1 && c->lone_variant;
+    // The twin without issue-slot yields serves launches that will have their SIMDs (nearly) to themselves: decided by what is
+    // IN FLIGHT when this dispatch is issued — at most lone_max_others other frames of this context —, not by how many frames the
+    // context was created with: a caller that keeps one or two dispatches going on a 12-frame context (the reference's own loop keeps
+    // 2, src/gpu.rs:399) gets the kernel that is 17 % faster alone, and so do the first dispatches of a burst.
+    if (c->lone_variant) {
+        uint32_t others = 0;
+        for (const vgen_ctx::Frame &g : c->fr) others += (&g != &f && g.in_flight) ? 1u : 0u;
+        a.lone = others <= c->lone_max_others;
+    }
     const bool dump = dump_mode(c);
     if (dump) {
         if (int rc = ensure_dump_frame(c, (uint32_t)(&f - c->fr.data()))) return rc;

@@ -25,7 +25,11 @@ struct vgen_ctx {
     int device = 0;
     uint32_t batch = 0, frames = 0, match_cap = 0, format = 0;
     uint32_t S = 0, lanes = 0, groups = 0;
-    bool lone_variant = true;   // frames == 1: launch seq_bwd_kernel<.., LONE> (VGEN_LONE_VARIANT=0 turns that off)
+    bool lone_variant = true;   // dispatches issued while at most lone_max_others other frames are in flight launch seq_bwd_kernel<.., LONE>
+                                // (VGEN_LONE_VARIANT=0 turns that off)
+    uint32_t lone_max_others = 1;
+    uint32_t hash_kpl = 4;      // split form: keys per lane of seq_hash_kernel (16 / hash_kpl waves per SIMD per launch at 2^20 keys)
+    bool split = false;         // VGEN_SPLIT=1 (A/B only): compressed-key formats run point arithmetic and hashes as two kernels
     vg::SeqBaseCache base_cache;         // host-side incremental base points (host_ec.h)
     uint32_t payload_words = 5;
     bool timing = false;                 // VGEN_FLAG_TIMING: events around every dispatch
