@@ -244,11 +244,11 @@ class Pipeline:
         return issued, time.perf_counter() - t0
 
 
-def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, label, note=None, endo=False, k0=None):
+def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, label, note=None, endo=False, k0=None, table_bits=0):
     """One `other_configs` entry: sustained rate of the dispatch loop for another format / pattern (keys from k0, default
-    the seeded base key)."""
+    the seeded base key).  table_bits: vgen_params.table_bits of the context (0 = the default 24-bit generator table)."""
     fmt = vg.AddressFormat(FORMATS[fmt_name])
-    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False, endo=endo)
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False, endo=endo, table_bits=table_bits)
     pat = vg.Pattern(pattern, ci, fmt)
     r.set_filter(pat if pat.device_kind != 0 else None)
     p = Pipeline(r, seed_key(42, 0) if k0 is None else k0)
@@ -262,7 +262,7 @@ def timed_config(vg, fmt_name, pattern, ci, batch, frames, device, seconds, labe
     if fmt_name == "p2tr":
         # no frozen yardstick describes the taproot path (a scalar multiplication per key over the wide-window table): its
         # roofline is the issue bound the counters name, from the measured instructions per key
-        roof = issue_roofline(rate, ("seq_fwd_kernel", "seq_inv_kernel", "seq_bwd_kernel", "p2tr_finish_kernel"), "p2tr", "seq_bwd_kernel")
+        roof = issue_roofline(rate, ("seq_fwd_kernel", "seq_inv_kernel", "seq_bwd_kernel", "p2tr_finish_kernel"), "p2tr29" if table_bits == 29 else "p2tr", "seq_bwd_kernel")
         if roof:
             out["chip_frac"], out["roofline"] = roof["frac"], roof
     if note:
@@ -300,13 +300,13 @@ def issue_roofline(rate_keys, kernels, pmc_mode, dominant):
                     "wide streaming reads; for these gathers the uncorrected figure (half) matches the algorithmic 64 B per window."}
 
 
-def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, endo=False):
+def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, endo=False, table_bits=0):
     """Arbitrary-scalar (KEYS) mode: the 'random 256-bit scalar' reading of north_star — a full fixed-base
     multiplication per key.  random_stream: the scalars are drawn on the device from the counter-based stream
     (vgen_dispatch_random: nothing uploaded); otherwise 32 B/key are uploaded by every dispatch (vgen_dispatch_keys)."""
     import random
     fmt = vg.AddressFormat.P2pkh
-    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False, endo=endo)
+    r = vg.GpuRunner(batch_size=batch, fmt=fmt, device=device, frames=frames, timing=False, endo=endo, table_bits=table_bits)
     r.set_filter(vg.Pattern("^1Cat", False, fmt))
     if random_stream:
         ctr = [0]
@@ -345,7 +345,7 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, en
     # (the counter passes are of the one-key-per-draw kernels: per multiplication, i.e. per draw, also for the six-image form)
     # (counters are per launch of 2^20 draws: the six-image form is priced per DRAW — keys per second / 6 x instructions per draw)
     roof = issue_roofline(rate / 6, kernels, "random_endo", "keys_fwd_kernel") if endo else \
-        issue_roofline(rate, kernels, "random" if random_stream else "keys", "keys_fwd_kernel")
+        issue_roofline(rate, kernels, "keys29" if table_bits == 29 else "random" if random_stream else "keys", "keys_fwd_kernel")
     if endo:
         return {"config": "independent random draws on an endomorphism context (VGEN_FLAG_ENDO): six keys per draw — k, lambda k, lambda^2 k and their negations",
                 "format": "p2pkh", "pattern": "^1Cat", "value": round(rate / 1e6, 1), "unit": "Mkeys/sec", "seconds": round(dt, 2), "dispatches": issued,
@@ -367,28 +367,19 @@ def keys_mode_config(vg, batch, frames, device, seconds, random_stream=False, en
 
 def wide_table_configs(vg, batch, frames, device, seconds):
     """The scalar-multiplication paths over the 29-bit SIGNED-window generator table (8 additions per multiplication instead of the
-    24-bit table's 10; 138 of the device's 288 GB; 0.7 - 2.3 s to allocate and build): what vgen_scan selects by itself for scans it
-    expects to run half a minute or more (scanner.cpp), forced here through VGEN_GTAB_BITS for the length of the leg."""
-    old = os.environ.get("VGEN_GTAB_BITS")
-    os.environ["VGEN_GTAB_BITS"] = "29"
+    24-bit table's 10; 138 of the device's 288 GB; 0.7 - 2.3 s to allocate and build): what vgen_scan moves to, in the background, for
+    scans it expects to run half a minute or more (scanner.cpp) — asked for here by name (vgen_params.table_bits = 29), so the context
+    builds it before its first dispatch.  Rooflines from the counter passes of the same table (profiles/pmc_keys.json: keys29 / p2tr29)."""
     out = []
-    try:
-        t0 = time.perf_counter()
-        e = keys_mode_config(vg, batch, frames, device, seconds, random_stream=True)
-        e["config"] += " — 29-bit signed-window table (8 additions)"
-        e["seconds_incl_table_build"] = round(time.perf_counter() - t0, 2)
-        e["chip_frac"] = e["roofline"] = None      # (the committed counter pass is of the 24-bit table's instruction count)
-        e["note"] = ("as the entry over the default table, with VGEN_GTAB_BITS=29: windows of 29 bits with signed digits, a table of magnitudes "
-                     "(m * 2^(29 w) * G, m <= 2^28; negative digits take (x, p - y)), 9 windows = 8 mixed additions; profiles/r04_gtab_signed.txt")
-        out.append(e)
-        e = timed_config(vg, "p2tr", "^bc1pqqq", False, batch, frames, device, seconds, "P2TR (taproot tweak on the device) — 29-bit signed-window table (8 additions)")
-        e["chip_frac"] = e["roofline"] = None
-        out.append(e)
-    finally:
-        if old is None:
-            os.environ.pop("VGEN_GTAB_BITS", None)
-        else:
-            os.environ["VGEN_GTAB_BITS"] = old
+    t0 = time.perf_counter()
+    e = keys_mode_config(vg, batch, frames, device, seconds, random_stream=True, table_bits=29)
+    e["config"] += " — 29-bit signed-window table (8 additions)"
+    e["seconds_incl_table_build"] = round(time.perf_counter() - t0, 2)
+    e["note"] = ("as the entry over the default table, on a context created with table_bits = 29: windows of 29 bits with signed digits, a table of magnitudes "
+                 "(m * 2^(29 w) * G, m <= 2^28; negative digits take (x, p - y)), 9 windows = 8 mixed additions; profiles/r04_gtab_signed.txt")
+    out.append(e)
+    out.append(timed_config(vg, "p2tr", "^bc1pqqq", False, batch, frames, device, seconds,
+                            "P2TR (taproot tweak on the device) — 29-bit signed-window table (8 additions)", table_bits=29))
     return out
 
 
@@ -420,6 +411,7 @@ def dump_mode_configs(vg, batch, device, seconds):
                 "format": "p2pkh", "pattern": "^1C", "value": round(res.operations / dt / 1e6, 1), "unit": "Mkeys/sec",
                 "seconds": round(dt, 2), "dispatches": res.operations // batch, "matches": len(res.matches),
                 "host_threads": usable_cores(),
+                "chip_frac": None, "roofline": host_roofline(len(res.matches) / dt, usable_cores()),
                 "note": "host-bound: every candidate is encoded and confirmed on the worker pool as it arrives (address only), the matches travel as "
                         "(key, address) blocks and are rendered — WIF, hex — once, in parallel, when vgen_scan hands them over; 75.6 Mkeys/s in round 3 "
                         "(profiles/r04_permissive.txt)"})
@@ -432,8 +424,19 @@ def dump_mode_configs(vg, batch, device, seconds):
                 "format": "p2pkh", "pattern": "^1[1-9A-Za-z]", "value": round(res.operations / dt / 1e6, 2), "unit": "Mkeys/sec",
                 "seconds": round(dt, 2), "dispatches": res.operations // batch, "matches": len(res.matches),
                 "host_threads": usable_cores(),
+                "chip_frac": None, "roofline": host_roofline(res.operations / dt, usable_cores()),
                 "note": "the reference's only mode; bound by Base58Check encoding + regex on the host cores"})
     return out
+
+
+def host_roofline(strings_per_s, cores):
+    """Roofline of the two legs the HOST bounds (every candidate / every key encoded as Base58Check and walked through the DFA on the worker
+    pool): address strings per second against cores / 0.73 us — two SHA-256 compressions of the checksum at 263 ns each on one EPYC 9575F core
+    plus ~0.2 us of base conversion and DFA walk (profiles/r04_permissive.txt).  The device is idle most of the time in these legs."""
+    peak = cores / 0.73e-6
+    return {"bound": "host-cpu", "achieved": round(strings_per_s / 1e6, 2), "peak": round(peak / 1e6, 2), "unit": "M address strings/s",
+            "frac": round(strings_per_s / peak, 4), "traffic": None, "cores": cores,
+            "note": "Base58Check + DFA per string on the host's worker pool: 2 x 263 ns SHA-256 + ~0.2 us per core (profiles/r04_permissive.txt)"}
 
 
 def parse_cpulist(text):

@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
 cp $GRAFT_REPO_ROOT/vgen_amd/libvgen_hip.so /tmp/libA.so
 cd /tmp && export TMPDIR=/tmp
-B="--format ethereum --pattern ^0xdead --ci --batch 3145728 --steps 16 --warmup 4 --frames 1 --sustained-seconds 0 --no-other-configs --no-cpu-baseline"
+B="--format ethereum --pattern ^0xdead --ci --batch 3145728 --steps 16 --warmup 4 --frames 1 --sustained-seconds 0 --no-other-configs --no-cpu-baseline --multi-leg-seconds 0"   # (no in-process multi-device leg under the profiler: its launches would join the medians)
 for T in intree "$@"; do
   if [ $T != intree ]; then cp $GRAFT_REPO_ROOT/vgen_amd/libvgen_hip.so.$T $GRAFT_REPO_ROOT/vgen_amd/libvgen_hip.so; fi
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE \

@@ -4,7 +4,7 @@
 # Each pass is its own rocprofv3 run (--pmc with --kernel-trace only; the program directly after `--`).
 # Output: gpurun_out/<tag>/pmc_keys.json  (copy to profiles/pmc_keys.json, which bench.py reads)
 TAG=${1:-pmc_keys}
-MODES=${2:-"keys p2tr"}
+MODES=${2:-"keys random random_endo p2tr"}   # all four: bench.py prices its entries from every one of them
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -30,6 +30,14 @@ for bits in 16 20 22 26; do
   run keys${bits}_sq $SQ -- random
   run keys${bits}_fetch FETCH_SIZE -- random
   run keys${bits}_tcc TCC_HIT_sum TCC_MISS_sum -- random
+done
+# the 29-bit signed-window table (8 additions; what long scans move to): the random-key path and the taproot path over it
+export VGEN_GTAB_BITS=29
+for m in keys29:random p2tr29:p2tr; do
+  run ${m%%:*}_sq $SQ -- ${m##*:}
+  run ${m%%:*}_fetch FETCH_SIZE -- ${m##*:}
+  run ${m%%:*}_write WRITE_SIZE -- ${m##*:}
+  run ${m%%:*}_tcc TCC_HIT_sum TCC_MISS_sum -- ${m##*:}
 done
 unset VGEN_GTAB_BITS
 python3 $GRAFT_REPO_ROOT/tools/pmc_keys_summarize.py $OUT > $OUT/pmc_keys.json

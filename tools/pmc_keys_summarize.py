@@ -86,7 +86,7 @@ def main(root):
            "how": "rocprofv3 --kernel-trace --pmc, one pass per counter group (tools/pmc_keys.sh), frames = 1, kernels serialised; "
                   "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x 32); bytes = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, "
                   "uncalibrated for 16-byte-per-lane gathers of 64-byte sectors (ratios between table widths are what to read)"}
-    for mode in ("keys", "random", "random_endo", "p2tr", "keys16", "keys20", "keys22", "keys24", "keys26"):
+    for mode in ("keys", "random", "random_endo", "p2tr", "keys16", "keys20", "keys22", "keys24", "keys26", "keys29", "p2tr29"):
         if os.path.isdir(os.path.join(root, f"{mode}_sq")):
             res[mode] = summarize(root, mode)
     if os.path.exists(os.path.join(root, "failed.txt")):

@@ -9,7 +9,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export VGEN_LONE_VARIANT=0   # the counters are of the steady-state kernel, not of the twin that frames = 1 contexts launch otherwise
-B="--steps 16 --warmup 4 --frames 1 --sustained-seconds 0 --no-other-configs --no-cpu-baseline"
+B="--steps 16 --warmup 4 --frames 1 --sustained-seconds 0 --no-other-configs --no-cpu-baseline --multi-leg-seconds 0"   # (no in-process multi-device leg under the profiler: its launches would join the medians)
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE \
   -d $OUT/passA -o p -- python3 $GRAFT_REPO_ROOT/bench.py --batch 4194304 $B > $OUT/passA.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE \
