@@ -8,7 +8,7 @@ ROUNDS=${ROUNDS:-2}
 cp vgen_amd/libvgen_hip.so /tmp/libA.so
 for T in "$@"; do
   cp vgen_amd/libvgen_hip.so.$T vgen_amd/libvgen_hip.so
-  echo "== parity $T: $(python tests/manual/gpu_smoke.py ${ARGS%% *} 32768 2>&1 | grep -c 'mismatches 0 /') of 4 starts clean"
+  echo "== parity $T: $(VGEN_LONE_VARIANT=0 python tests/manual/gpu_smoke.py ${ARGS%% *} 32768 2>&1 | grep -c 'mismatches 0 /') of 4 starts clean"
 done
 for R in $(seq 1 $ROUNDS); do
   for T in A "$@"; do

@@ -325,8 +325,11 @@ seq_bwd_kernel(const SeqArgs args) {
     constexpr int NW = PayloadWords<FMT>::value;
     // PARK: the lane's table point R_u and the running inverse live in LDS between their uses instead of in 27 registers (LDS reads
     // issue beside the VALU, not through it), so that the prefilter kernels of the compressed-key formats fit VG_SEQ_WAVES_P2PKH > 4
-    constexpr bool PARK = VG_PARK && !FULL && !ENDO && !LONE && (FMT == VGF_P2PKH || FMT == VGF_P2WPKH);
-    __shared__ u32 rpark[PARK ? 17 * WG : 1];   // (R.y's top limb stays in a register: 26 KB of LDS per workgroup lets six share a CU)
+    // PARK2 (VG_PARK=2): nothing of the lane's state stays in registers across a key — R_u is re-read from the offset table (L2-resident, coalesced)
+    // where it is needed, the running inverse and the step's 1/dx wait in LDS (18 KB per workgroup: eight workgroups share a CU).
+    constexpr int PARKM = (!FULL && !ENDO && !LONE && (FMT == VGF_P2PKH || FMT == VGF_P2WPKH)) ? VG_PARK : 0;
+    constexpr bool PARK = PARKM == 1, PARK2 = PARKM == 2;
+    __shared__ u32 rpark[PARK ? 17 * WG : PARK2 ? 9 * WG : 1];   // (PARK: R.y's top limb stays in a register: 26 KB of LDS per workgroup lets six share a CU)
     const int tid = threadIdx.x;
     const GenTables gtab{args.gtab, args.gtab16, args.gtab_bits};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache / HBM)
     u32 *dfa_lds = dyn_lds;
@@ -374,14 +377,17 @@ seq_bwd_kernel(const SeqArgs args) {
         for (int i = 0; i < 9; i++) sib.n[i] = args.pre[(size_t)((S - 1) * 9 + i) * lanes + (u ^ 1u)];
         fe_mul(inv, ip, sib);
     }
-    if (ENDO || PARK) __syncthreads();   // every lane has read its pair's inverse: the tree's LDS now parks the x of the point in hand (PARK: the running inverse)
+    if (ENDO || PARK || PARK2) __syncthreads();   // every lane has read its pair's inverse: the tree's LDS now parks the x of the point in hand (PARK: the running inverse)
 
     fe rx, ry;
+    if (!PARK2) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        rx.n[i] = args.rtab[(size_t)i * lanes + u];
-        ry.n[i] = args.rtab[(size_t)(9 + i) * lanes + u];
+        for (int i = 0; i < 9; i++) {
+            rx.n[i] = args.rtab[(size_t)i * lanes + u];
+            ry.n[i] = args.rtab[(size_t)(9 + i) * lanes + u];
+        }
     }
+    if (PARK2) lds_park_fe(tree, WG, tid, inv);
     if (PARK) {
         lds_park_fe(rpark, WG, tid, rx);
         {
@@ -405,6 +411,13 @@ seq_bwd_kernel(const SeqArgs args) {
             lds_unpark_fe(rpark, WG, tid, rx);
             lds_unpark_fe(tree, WG, tid, inv);
         }
+        if (PARK2) {
+            const u32 *rt = args.rtab + u;
+            asm volatile("" : "+v"(rt));   // (an address the compiler cannot recognise as the loop invariant it is: the loads stay here)
+#pragma unroll
+            for (int i = 0; i < 9; i++) rx.n[i] = rt[(size_t)i * lanes];
+            lds_unpark_fe(tree, WG, tid, inv);
+        }
 #pragma unroll
         for (int i = 0; i < 9; i++) dx.n[i] = rx.n[i] + q.nqx[i];
         if (j > 0) {
@@ -413,13 +426,14 @@ seq_bwd_kernel(const SeqArgs args) {
             for (int i = 0; i < 9; i++) pj.n[i] = pre[(size_t)((j - 1) * 9 + i) * lanes];
             fe_mul(idx, inv, pj);
             fe_mul(inv, inv, dx);
-            if (PARK) lds_park_fe(tree, WG, tid, inv);
+            if (PARK || PARK2) lds_park_fe(tree, WG, tid, inv);
         } else {
             idx = inv;
         }
+        if (PARK2) lds_park_fe(rpark, WG, tid, idx);
         // -R.x and -R.y are recomputed where needed (9 subtractions each) instead of living in 18 registers
         // across the loop; the empty asm keeps the compiler from hoisting them back out as loop invariants.
-        if (!PARK) {
+        if (!PARK && !PARK2) {
 #pragma unroll
             for (int i = 0; i < 9; i++) {
                 asm volatile("" : "+v"(rx.n[i]));
@@ -427,16 +441,29 @@ seq_bwd_kernel(const SeqArgs args) {
             }
         }
         fe nsum, nqy;   // -(R.x + Q.x) (magnitude 3) and -Q.y, shared by the +R and -R results
-        fe_neg(nsum, rx, 1);
+        if (!PARK2) fe_neg(nsum, rx, 1);
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            nsum.n[i] += q.nqx[i];
+            if (!PARK2) nsum.n[i] += q.nqx[i];
             nqy.n[i] = q.nqy[i];
         }
 #pragma unroll 1
         for (int sgn = 0; sgn < 2; sgn++) {
             // +R: dy = R.y - Q.y ; -R: dy = -R.y - Q.y
             fe dy, lam, x3, t, y3;
+            if (PARK2) {
+                const u32 *rt = args.rtab + u;
+                asm volatile("" : "+v"(rt));
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    rx.n[i] = rt[(size_t)i * lanes];
+                    ry.n[i] = rt[(size_t)(9 + i) * lanes];
+                }
+                fe_neg(nsum, rx, 1);
+#pragma unroll
+                for (int i = 0; i < 9; i++) nsum.n[i] += q.nqx[i];
+                lds_unpark_fe(rpark, WG, tid, idx);
+            }
             if (PARK) {
                 lds_vu32 *b = (lds_vu32 *)(rpark + 9 * WG);
 #pragma unroll
