@@ -71,7 +71,7 @@ typedef enum vgen_format {
                                  vgen_frame_dispatch_ms report durations (bench.py); without it a dispatch is
                                  three kernels and one copy, and the host loop is ~10 us per step cheaper */
 
-#define VGEN_MAX_BATCH 16777216u   /* 2^24 keys per dispatch (the rate is flat from 2^20 up: DESIGN.md, batch sweep) */
+#define VGEN_MAX_BATCH 16777216u   /* 2^24 keys per dispatch (the rate is flat from 2^20 up: profiles/r02_batch_sweep.txt) */
 
 typedef struct vgen_params {
     uint32_t struct_size;  /* = sizeof(vgen_params) */

@@ -112,7 +112,7 @@ def test_known_answers():
 
 def test_the_instruction_count_is_the_floor():
     # 64 SHA-256 rounds and 160 RIPEMD-160 steps with everything the padded 33-byte message fixes folded away; the count
-    # DESIGN.md §4 quotes (hipcc's own schedule of core/hash.h: 2 211)
+    # EXPERIMENTS.md (the hash pair as a scheduled block) quotes (hipcc's own schedule of core/hash.h: 2 211)
     p, _, _ = g.prog_pub33_h160()
     c = p.census()
     assert sum(c.values()) == 2196

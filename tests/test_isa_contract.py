@@ -12,7 +12,7 @@ one of them fails the CPU suite instead of silently costing throughput:
   * the short first-half kernels of a dispatch raise their issue priority (s_setprio);
   * the hash pair of the headline kernel is the scheduled block device/hashgen.py writes — its instructions in the
     generator's order, one `s_nop 0` yield after every third — not a schedule of hipcc's;
-  * no instantiation uses more registers or scratch than the committed table profiles/r04_kernel_resources.txt.
+  * no instantiation uses more registers or scratch than the committed table profiles/r05_kernel_resources.txt.
 
 Reference counterpart of the code under test: src/shaders/search.wgsl:2-31 (one storage write per key, no compaction).
 """
@@ -25,8 +25,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ISA = os.path.join(ROOT, "build", "lib", "device", "kernels.s")
 SRC = os.path.join(ROOT, "vgen_amd", "csrc", "device", "kernels.hip")
-HEADLINE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0ELb0EEEvNS_7SeqArgsE"
-LONE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0ELb1EEEvNS_7SeqArgsE"   # its twin for contexts with one frame in flight
+HEADLINE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0ELb0ELb0EEEvNS_7SeqArgsE"
+LONE = "_ZN2vg14seq_bwd_kernelILi0ELb0ELb0ELb1ELb0EEEvNS_7SeqArgsE"   # its twin for contexts with one frame in flight
 
 
 def parse_isa(txt):
@@ -100,8 +100,9 @@ def test_headline_kernel_budget(isa):
 
 
 def test_match_compaction_is_one_atomic_per_wave(isa):
-    with_match = [s for s in isa if re.search(r"(seq_bwd_kernelILi[0245]|keys_bwd_kernelILi[0245]|p2tr_finish_kernel|p2tr_out_kernel)", s)]
-    assert len(with_match) == 16 + 1 + 16 + 2 + 2, sorted(with_match)   # + 1: the one-frame twin of the headline kernel
+    with_match = [s for s in isa if re.search(r"(seq_bwd_kernelILi[0245]|keys_bwd_kernelILi[0245]|p2tr_finish_kernel|p2tr_out_kernel|seq_hash_kernel)", s)
+                  and not re.search(r"seq_bwd_kernelILi\dELb\dELb\dELb\dELb1E", s)]   # (the SPLIT form of seq_bwd_kernel only parks points: seq_hash_kernel reports)
+    assert len(with_match) == 16 + 1 + 16 + 2 + 2 + 4, sorted(with_match)   # + 1: the one-frame twin of the headline kernel; + 4: seq_hash_kernel (A/B switch VGEN_SPLIT)
     bad = []
     for sym in with_match:
         bad += check_match_path(sym, isa[sym])
@@ -121,7 +122,7 @@ def test_match_compaction_is_written_in_the_source():
     rest = src.replace(body, "")
     code = "\n".join(line.split("//")[0] for line in rest.split("\n"))
     assert "atomicAdd" not in code and "__hip_atomic" not in code and "atomic_fetch" not in code
-    assert code.count("match_slot(args.mhdr, hit, args.match_base)") == 6
+    assert code.count("match_slot(args.mhdr, hit, args.match_base)") == 7
 
 
 def test_the_checker_rejects_a_per_lane_or_system_scope_atomic():
@@ -181,14 +182,14 @@ def test_chain_kernels_raise_their_priority(isa):
 
 def test_register_and_scratch_budgets_against_the_committed_table(isa):
     table = {}
-    for line in open(os.path.join(ROOT, "profiles", "r04_kernel_resources.txt")):
+    for line in open(os.path.join(ROOT, "profiles", "r05_kernel_resources.txt")):
         m = re.match(r"(\S+)\tVGPRs: (\d+)\tScratchSize: (\d+)", line)
         if m:
             table[m.group(1)] = (int(m.group(2)), int(m.group(3)))
     assert len(table) >= 45
     for sym, k in isa.items():
         short = sym.replace("_ZN2vg", "", 1)
-        assert short in table, f"{sym}: not in profiles/r04_kernel_resources.txt (tools/kernel_resources.py regenerates it)"
+        assert short in table, f"{sym}: not in profiles/r05_kernel_resources.txt (tools/kernel_resources.py regenerates it)"
         v, s = table[short]
         assert k["vgpr"] <= v, f"{sym}: {k['vgpr']} VGPRs, committed {v}"
         assert k["scratch"] <= s, f"{sym}: {k['scratch']} B scratch, committed {s}"

@@ -6,7 +6,7 @@
 // per 2^20 keys (profiles/pmc_keys.json).  An AFFINE addition costs 1 M + 1 S + 1 M once 1/(x2 - x1) is known, and the
 // inverses of a whole batch cost ~3 M each when they share one inversion (Montgomery's trick: prefix products per lane, a
 // product tree per workgroup, one root per workgroup inverted by seq_inv_kernel's divsteps): ~6.5 M per addition, a 1.6x
-// ceiling — IF the accumulators of all keys can wait somewhere while the shared inversion happens.  DESIGN.md 4 rejected
+// ceiling — IF the accumulators of all keys can wait somewhere while the shared inversion happens.  EXPERIMENTS.md (round 3) rejected
 // this on a traffic estimate (the accumulators and prefix products park in HBM: ~3 KB per key); this probe builds it and
 // measures it, with the fusion that gives the idea its best shot:
 //

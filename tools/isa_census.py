@@ -29,7 +29,7 @@ def cost(op, mixed=True):
 
 
 def main():
-    name = sys.argv[1] if len(sys.argv) > 1 else "seq_bwd_kernelILi0ELb0"
+    name = sys.argv[1] if len(sys.argv) > 1 else "seq_bwd_kernelILi0ELb0ELb0ELb0ELb0"
     os.makedirs("/tmp/isa", exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include",
                            "-Wno-pass-failed", "--cuda-device-only", "-S", f"{ROOT}/vgen_amd/csrc/device/kernels.hip",

@@ -7,7 +7,7 @@ emitted list is the floor of the computation: 6 rotates + 4 three-input booleans
 + 2 rotates + 2 additions per RIPEMD-160 step.  The list is register-allocated by a linear scan (a pair lives in 28 VGPRs
 and one SGPR for literals) and written out as ONE `asm` statement per hash, so the order below IS the order the SIMD sees.
 
-Two things are decided here rather than by hipcc, both measured in the real kernels on the MI355X (DESIGN.md §4,
+Two things are decided here rather than by hipcc, both measured in the real kernels on the MI355X (DESIGN.md §3-4, EXPERIMENTS.md;
 profiles/r04_hash_blocks_ab.txt):
   * the ORDER: the dependency order of the round functions.  hipcc interleaves rounds for instruction-level parallelism,
     which a SIMD holding four waves does not need; spreading dependent neighbours apart (`spread`) changes nothing either.

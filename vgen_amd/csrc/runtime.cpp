@@ -82,7 +82,7 @@ bool mem_allows(vgen_ctx *c, uint64_t extra, bool table, bool by_name, std::stri
 // twelve queues with no environment variable and whether or not the host initialised HIP first); on a runtime with
 // fewer levels the surplus streams share queues, which vgen_get_topology reports as `oversubscribed`.
 // [CU-masked streams (hipExtStreamCreateWithCUMask) also get a queue each and measured 2-3 % faster at 12-20 frames,
-// but their teardown is broken on ROCm 7.2 — see DESIGN.md "two events" — and they are not part of the library.]
+// but their teardown is broken on ROCm 7.2 — see EXPERIMENTS.md "Two events of round 2" — and they are not part of the library.]
 
 // Creates the stream of frame i (no locking here).
 int create_stream(vgen_ctx *c, uint32_t i, hipStream_t *out, std::string &err) {
