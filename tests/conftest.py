@@ -15,6 +15,16 @@ HOOKS_SO = os.path.join(ROOT, "tests", "native", "libvgen_hip_hooks.so")
 HOOKS_CLI = os.path.join(ROOT, "tests", "native", "vgen-hip-hooks")
 
 
+def locked_make(*args):
+    """`make <args>` under a lock file: test modules of different pytest-xdist workers run the same Makefiles (the product's, the
+    oracle's, tests/native) when the tree is stale, and two makes writing the same objects side by side fail."""
+    import fcntl
+    import subprocess
+    with open(os.path.join(ROOT, "tests", "native", ".make.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", *args])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

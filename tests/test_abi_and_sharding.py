@@ -43,7 +43,10 @@ def test_fault_injection_is_not_part_of_the_shipped_library():
     assert "vgen_debug" not in open(os.path.join(ROOT, "INTEGRATION.md")).read()
     # the environment variables the shipped library does read are the documented ones
     env = set(re.findall(rb"VGEN_[A-Z0-9_]+", blob))
-    read = {b"VGEN_SEQ_S", b"VGEN_GTAB_BITS", b"VGEN_TRACE_CREATE", b"VGEN_LONE_VARIANT"}                       # getenv'ed (INTEGRATION.md lists them)
+    read = {b"VGEN_SEQ_S", b"VGEN_GTAB_BITS", b"VGEN_TRACE_CREATE", b"VGEN_LONE_VARIANT",                      # getenv'ed, once, at vgen_create (INTEGRATION.md lists them)
+            b"VGEN_LONE_MAX_OTHERS", b"VGEN_SPLIT", b"VGEN_HASH_KPL"}                                            # ... the A/B switches of round 5 among them
+    for name in read:
+        assert name.decode() in open(os.path.join(ROOT, "INTEGRATION.md")).read(), name
     named_in_messages = {b"VGEN_FLAG_ENDO", b"VGEN_FLAG_TIMING", b"VGEN_SCAN_RANDOM_KEYS"}    # ABI constants quoted in error texts
     assert read <= env <= read | named_in_messages, env
     # ... and the test build has both hooks

@@ -12,6 +12,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 P = 2**256 - 2**32 - 977
 M29 = (1 << 29) - 1
@@ -19,7 +21,7 @@ M29 = (1 << 29) - 1
 
 @pytest.fixture(scope="module")
 def core():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    locked_make("-s", "-C", os.path.join(HERE, "native"))
     return ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
 
 

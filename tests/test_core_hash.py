@@ -6,6 +6,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 from oracle import pyoracle as vo
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -14,7 +16,7 @@ N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 
 @pytest.fixture(scope="module")
 def core():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    locked_make("-s", "-C", os.path.join(HERE, "native"))
     return ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
 
 

@@ -16,6 +16,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 from test_core_field import M29, P, W0, W1, check_mag1, check_weak, limbs_of, rand_limbs, val
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +31,7 @@ H_PUB33, H_PUB65, H_SCRIPT22, H_KECCAK = range(4)
 
 @pytest.fixture(scope="module")
 def dev():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native"), "libcoredev.so"])
+    locked_make("-s", "-C", os.path.join(HERE, "native"), "libcoredev.so")
     lib = ctypes.CDLL(os.path.join(HERE, "native", "libcoredev.so"))
     assert lib.coredev_device_count() >= 1, "no HIP device: the gpu-marked tests need an MI355X"
     return lib

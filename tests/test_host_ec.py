@@ -8,6 +8,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 from oracle import pyoracle as vo
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -17,7 +19,7 @@ N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
 
 @pytest.fixture(scope="module")
 def core():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    locked_make("-s", "-C", os.path.join(HERE, "native"))
     lib = ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
     lib.core_stride_table.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
     return lib

@@ -14,6 +14,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 from oracle import pyoracle as vo
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -22,7 +24,7 @@ KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 
 @pytest.fixture(scope="module")
 def core():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native")])
+    locked_make("-s", "-C", os.path.join(HERE, "native"))
     lib = ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
     lib.core_filter_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint, ctypes.c_char_p, ctypes.c_int,
                                       ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]

@@ -16,6 +16,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 NATIVE = os.path.join(HERE, "native")
 SCENARIOS = ["range_scan", "stop_flag", "checkpoint", "multi_context", "ring_growth", "failure_takeover", "random_keys",
@@ -24,8 +26,8 @@ SCENARIOS = ["range_scan", "stop_flag", "checkpoint", "multi_context", "ring_gro
 
 @pytest.fixture(scope="module")
 def runs():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "..", "oracle")])
-    subprocess.check_call(["make", "-s", "-j4", "-C", NATIVE, "sanitizers"])
+    locked_make("-s", "-C", os.path.join(HERE, "..", "oracle"))
+    locked_make("-s", "-j4", "-C", NATIVE, "sanitizers")
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1",
                UBSAN_OPTIONS="print_stacktrace=1")
     procs = {k: subprocess.Popen([os.path.join(NATIVE, f"fake_driver_{k}")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,

@@ -22,6 +22,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ISA = os.path.join(ROOT, "build", "lib", "device", "kernels.s")
 SRC = os.path.join(ROOT, "vgen_amd", "csrc", "device", "kernels.hip")
@@ -51,7 +53,7 @@ def count(body, pat):
 @pytest.fixture(scope="module")
 def isa():
     # (a no-op when __graft_entry__.build() has just run; ~1 min of hipcc otherwise)
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "vgen_amd", "csrc"), "../../build/lib/device/kernels.s"])
+    locked_make("-s", "-C", os.path.join(ROOT, "vgen_amd", "csrc"), "../../build/lib/device/kernels.s")
     return parse_isa(open(ISA).read())
 
 

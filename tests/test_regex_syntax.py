@@ -14,6 +14,8 @@ import subprocess
 
 import pytest
 
+from conftest import locked_make
+
 from oracle import pyoracle as vo
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -21,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def core():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "native"), "libcoretest.so"])
+    locked_make("-s", "-C", os.path.join(HERE, "native"), "libcoretest.so")
     return ctypes.CDLL(os.path.join(HERE, "native", "libcoretest.so"))
 
 

@@ -114,7 +114,7 @@ struct SeqArgs {
     uint32_t fmt;              // VGF_* of the context (the DFA path needs the exact address format)
     uint32_t hash_kpl;         // split form: keys per lane of seq_hash_kernel (a divisor of 2S)
     uint32_t endo;             // seq_bwd: test the six endomorphism / negation images of every point (kernels.hip: ENDO)
-    uint32_t lone;             // seq_bwd: this context keeps ONE frame in flight (frames = 1): launch the variant without issue-slot yields
+    uint32_t lone;             // seq_bwd: at most one other frame of the context was in flight when this dispatch was issued: launch the variant without issue-slot yields
     // P2TR only: the tweaked points Q = P + t*G of a dispatch wait for a second shared inversion.
     uint32_t *tq;              // [2S key steps][27][lanes]: X(Q), Z(Q), running product of the lane's Z's
     uint32_t *tq_flag;         // [2S][lanes]: 1 = the key has an address (valid tweak, Q finite)

@@ -308,7 +308,8 @@ struct SeqWaves {
 // endomorphism / negation images — (x, +-y), (beta x, +-y), (beta^2 x, +-y), the public keys of k, lambda k, lambda^2 k and
 // their negations — so six keys are hashed for one point's arithmetic plus two multiplications by beta.  Image `variant`
 // = s * 3 + e (e = power of beta, s = negated) of key index i is reported / dumped at variant * n + i.
-// LONE (P2PKH / P2WPKH with a prefilter only): the variant for contexts that keep one frame in flight, see payload_from_point.
+// LONE (P2PKH / P2WPKH with a prefilter only): the variant for dispatches issued while at most one other frame of the context is in flight
+// (runtime.cpp: rt_dispatch), see payload_from_point.
 // SPLIT (the compressed-key formats without ENDO): the kernel stops at the affine point — it parks the eight words of x and the
 // key's prefix byte (0x02 | parity of y) per key in args.xs and leaves hashes, filter and output to seq_hash_kernel, which runs one
 // key per lane at eight waves per SIMD (see there).
@@ -1784,7 +1785,7 @@ static hipError_t launch_bwd(const SeqArgs &a, hipStream_t stream) {
     if (full && a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), true, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     else if (full) hipLaunchKernelGGL((seq_bwd_kernel<FMT, true>), dim3(a.groups), dim3(WG), a.dfa_bytes, stream, a);
     else if (a.endo && FMT != VGF_P2TR) hipLaunchKernelGGL((seq_bwd_kernel<(FMT == VGF_P2TR ? VGF_P2PKH : FMT), false, true>), dim3(a.groups), dim3(WG), 0, stream, a);
-    else if (a.lone && FMT == VGF_P2PKH) hipLaunchKernelGGL((seq_bwd_kernel<VGF_P2PKH, false, false, true>), dim3(a.groups), dim3(WG), 0, stream, a);   // one frame in flight: the twin without yields
+    else if (a.lone && FMT == VGF_P2PKH) hipLaunchKernelGGL((seq_bwd_kernel<VGF_P2PKH, false, false, true>), dim3(a.groups), dim3(WG), 0, stream, a);   // (nearly) alone on the device: the twin without yields
     else hipLaunchKernelGGL((seq_bwd_kernel<FMT, false>), dim3(a.groups), dim3(WG), 0, stream, a);
     return hipGetLastError();
 }
