@@ -182,6 +182,17 @@ def test_chain_kernels_raise_their_priority(isa):
         assert prio and prio[0] < first_valu + 40, (name, prio, first_valu)
 
 
+def test_no_per_key_kernel_touches_scratch(isa):
+    """Round 5: the instantiations that spilled 12 - 16 bytes per lane at their 128-register cap (the uncompressed-key format, the
+    six-image on-device matcher) keep the running inverse in LDS instead (kernels.hip: PARKI); since then no kernel on the per-key
+    path has a private segment.  Only the two generator-table builders (run once per table) keep theirs."""
+    for sym, k in isa.items():
+        if "gen_table_combine" in sym or "gen_combine_signed" in sym:
+            continue
+        assert k["scratch"] == 0, f"{sym}: {k['scratch']} B scratch"
+        assert count(k["body"], "scratch_") == 0, sym
+
+
 def test_register_and_scratch_budgets_against_the_committed_table(isa):
     table = {}
     for line in open(os.path.join(ROOT, "profiles", "r05_kernel_resources.txt")):

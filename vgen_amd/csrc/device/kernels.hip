@@ -40,6 +40,9 @@
 #ifndef VG_PARK
 #define VG_PARK 0
 #endif
+#ifndef VG_PARKI
+#define VG_PARKI 1
+#endif
 #define VG_HASH_BLOCKS 1   // core/dfa_eval.h: base58_checksum runs as a scheduled block too (hash_blocks.inc below)
 #include "../core/dfa_eval.h"
 #include "../core/ec.h"
@@ -330,7 +333,10 @@ seq_bwd_kernel(const SeqArgs args) {
     // where it is needed, the running inverse and the step's 1/dx wait in LDS (18 KB per workgroup: eight workgroups share a CU).
     constexpr int PARKM = (!FULL && !ENDO && !LONE && (FMT == VGF_P2PKH || FMT == VGF_P2WPKH)) ? VG_PARK : 0;
     constexpr bool PARK = PARKM == 1, PARK2 = PARKM == 2;
-    __shared__ u32 rpark[PARK ? 17 * WG : PARK2 ? 9 * WG : 1];   // (PARK: R.y's top limb stays in a register: 26 KB of LDS per workgroup lets six share a CU)
+    // PARKI: the instantiations that would otherwise spill a few registers at their 128-register cap (the uncompressed-key format: a second
+    // SHA-256 block's sixteen message words; the six-image on-device matcher) keep the running inverse in 9 KB of LDS of its own instead
+    constexpr bool PARKI = VG_PARKI && !PARK && !PARK2 && !LONE && (FMT == VGF_P2PKH_UNCOMPRESSED || (FMT == VGF_P2PKH && FULL && ENDO));
+    __shared__ u32 rpark[PARK ? 17 * WG : (PARK2 || PARKI) ? 9 * WG : 1];   // (PARK: R.y's top limb stays in a register: 26 KB of LDS per workgroup lets six share a CU)
     const int tid = threadIdx.x;
     const GenTables gtab{args.gtab, args.gtab16, args.gtab_bits};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache / HBM)
     u32 *dfa_lds = dyn_lds;
@@ -389,6 +395,7 @@ seq_bwd_kernel(const SeqArgs args) {
         }
     }
     if (PARK2) lds_park_fe(tree, WG, tid, inv);
+    if (PARKI) lds_park_fe(rpark, WG, tid, inv);
     if (PARK) {
         lds_park_fe(rpark, WG, tid, rx);
         {
@@ -412,6 +419,7 @@ seq_bwd_kernel(const SeqArgs args) {
             lds_unpark_fe(rpark, WG, tid, rx);
             lds_unpark_fe(tree, WG, tid, inv);
         }
+        if (PARKI) lds_unpark_fe(rpark, WG, tid, inv);
         if (PARK2) {
             const u32 *rt = args.rtab + u;
             asm volatile("" : "+v"(rt));   // (an address the compiler cannot recognise as the loop invariant it is: the loads stay here)
@@ -428,6 +436,7 @@ seq_bwd_kernel(const SeqArgs args) {
             fe_mul(idx, inv, pj);
             fe_mul(inv, inv, dx);
             if (PARK || PARK2) lds_park_fe(tree, WG, tid, inv);
+            if (PARKI) lds_park_fe(rpark, WG, tid, inv);
         } else {
             idx = inv;
         }
