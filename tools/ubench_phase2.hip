@@ -1,0 +1,183 @@
+// ubench_phase2.hip — what does an instruction of one class cost beside instructions of another class on the same SIMD?
+//
+// Follow-up of tools/ubench_phase.hip (profiles/r05_phase_ubench.jsonl: with the waves of a SIMD barrier-locked, v_add_u32 alone issues at 2.0
+// cycles, v_alignbit_b32 and v_mad_u64_u32 alone at 4.0, and every mix of add and alignbit in runs of up to 64 at 3.9 - 4.0 PER INSTRUCTION: beside
+// half-rate instructions the full-rate ones cost four cycles as well).  Here:
+//   (1) which SIMD the waves of a 256 / 512 / 1024-thread workgroup land on (s_getreg HW_ID);
+//   (2) uniform streams with a class ratio other than 1:1 (7:1, 3:1, 1:3, 15:1 ... of full-rate : half-rate), every wave the same;
+//   (3) waves SPECIALISED by class: of the four waves of a SIMD, the `split` lowest run one stream, the others another.
+// Time is taken per block of 1 024 instructions per wave between workgroup barriers; reported as SIMD cycles per block and per wave-instruction.
+// Build: python3 tools/ubench_phase2_gen.py tools/ubench_phase2_blocks.inc && hipcc --offload-arch=gfx950 -O3 tools/ubench_phase2.hip -o tools/ubench_phase2
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+constexpr int CHAINS = 8;
+constexpr int BLOCK_INSTR = 1024;
+
+#include "ubench_phase2_blocks.inc"
+
+#define RUN_BLOCK(S)                                                                                                                  \
+    asm volatile(S : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(acc[0]),   \
+                 "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])                     \
+                 : "v"(y), "v"(z)                                                                                                     \
+                 : "vcc")
+
+__device__ __forceinline__ uint32_t hw_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    return v;
+}
+
+__global__ void k_map(uint32_t *out) {
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = hw_id();
+}
+
+// rank of this wave among the waves of its workgroup that sit on the same SIMD (by wave index)
+__device__ __forceinline__ uint32_t simd_rank(uint32_t *lds) {
+    const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t simd = (hw_id() >> 4) & 3u;
+    if ((threadIdx.x & 63) == 0) lds[wave] = simd;
+    __syncthreads();
+    uint32_t r = 0;
+    for (uint32_t v = 0; v < nw; v++) r += (v < wave && lds[v] == simd) ? 1u : 0u;
+    return __builtin_amdgcn_readfirstlane(r);
+}
+
+#define KERNEL_PROLOGUE                                                                       \
+    __shared__ uint32_t lds[16];                                                              \
+    uint32_t x[CHAINS], y = threadIdx.x | 1u, z = threadIdx.x * 2654435761u + 12345u;         \
+    uint64_t acc[CHAINS];                                                                     \
+    _Pragma("unroll") for (int c = 0; c < CHAINS; c++) {                                      \
+        x[c] = threadIdx.x * 747796405u + c * 2891336453u + blockIdx.x;                       \
+        acc[c] = ((uint64_t)x[c] << 32) | (x[c] ^ 0x9E3779B9u);                               \
+    }                                                                                         \
+    const uint32_t rank = simd_rank(lds);                                                     \
+    __syncthreads();                                                                          \
+    const unsigned long long c0 = clock64();
+
+#define KERNEL_EPILOGUE                                                                                       \
+    __syncthreads();                                                                                          \
+    const unsigned long long c1 = clock64();                                                                  \
+    uint32_t r = rank;                                                                                        \
+    _Pragma("unroll") for (int c = 0; c < CHAINS; c++) r ^= x[c] ^ (uint32_t)acc[c] ^ (uint32_t)(acc[c] >> 32); \
+    if (r == 0x12345678u) out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                     \
+    if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = c1 - c0;
+
+// every wave the same stream
+#define UNIFORM(NAME, S)                                                                                        \
+    __global__ void __launch_bounds__(1024) NAME(uint32_t *out, int iters, int split, unsigned long long *clk) { \
+        KERNEL_PROLOGUE                                                                                         \
+        _Pragma("unroll 1") for (int it = 0; it < iters; it++) {                                                \
+            __builtin_amdgcn_s_barrier();                                                                       \
+            RUN_BLOCK(S);                                                                                       \
+        }                                                                                                       \
+        KERNEL_EPILOGUE                                                                                         \
+    }
+
+// the `split` lowest-ranked waves of every SIMD run S0, the others S1
+#define ROLES(NAME, S0, S1)                                                                                     \
+    __global__ void __launch_bounds__(1024) NAME(uint32_t *out, int iters, int split, unsigned long long *clk) { \
+        KERNEL_PROLOGUE                                                                                         \
+        if ((int)rank < split) {                                                                                \
+            _Pragma("unroll 1") for (int it = 0; it < iters; it++) {                                            \
+                __builtin_amdgcn_s_barrier();                                                                   \
+                RUN_BLOCK(S0);                                                                                  \
+            }                                                                                                   \
+        } else {                                                                                                \
+            _Pragma("unroll 1") for (int it = 0; it < iters; it++) {                                            \
+                __builtin_amdgcn_s_barrier();                                                                   \
+                RUN_BLOCK(S1);                                                                                  \
+            }                                                                                                   \
+        }                                                                                                       \
+        KERNEL_EPILOGUE                                                                                         \
+    }
+
+UNIFORM(u_A, BLK_A)
+UNIFORM(u_R, BLK_R)
+UNIFORM(u_M, BLK_M)
+UNIFORM(u_B, BLK_B)
+UNIFORM(u_X, BLK_X)
+UNIFORM(u_S, BLK_S)
+UNIFORM(u_T, BLK_T)
+UNIFORM(u_A63R1, BLK_A63R1)
+UNIFORM(u_A31R1, BLK_A31R1)
+UNIFORM(u_A15R1, BLK_A15R1)
+UNIFORM(u_A7R1, BLK_A7R1)
+UNIFORM(u_A3R1, BLK_A3R1)
+UNIFORM(u_A1R3, BLK_A1R3)
+UNIFORM(u_B3R1, BLK_B3R1)
+UNIFORM(u_A3M1, BLK_A3M1)
+UNIFORM(u_A7M1, BLK_A7M1)
+UNIFORM(u_A3T1, BLK_A3T1)
+ROLES(r_R_A, BLK_R, BLK_A)
+ROLES(r_A_R, BLK_A, BLK_R)
+ROLES(r_M_A, BLK_M, BLK_A)
+ROLES(r_R_M, BLK_R, BLK_M)
+
+typedef void (*kern_t)(uint32_t *, int, int, unsigned long long *);
+
+static void run(const char *name, kern_t k, int split, int wg, int iters, uint32_t *dout, unsigned long long *dclk, int cus) {
+    hipLaunchKernelGGL(k, dim3(cus), dim3(wg), 0, 0, dout, 4, split, dclk);
+    CHECK(hipDeviceSynchronize());
+    unsigned long long best = ~0ull;
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(k, dim3(cus), dim3(wg), 0, 0, dout, iters, split, dclk);
+        CHECK(hipDeviceSynchronize());
+        unsigned long long c;
+        CHECK(hipMemcpy(&c, dclk, 8, hipMemcpyDeviceToHost));
+        if (c < best) best = c;
+    }
+    const double per_block = (double)best / iters;
+    printf("{\"stream\":\"%s\",\"split\":%d,\"waves_per_simd\":%d,\"cycles_per_block\":%.0f,\"cycles_per_waveinstr\":%.3f}\n", name, split, wg / 256, per_block,
+           per_block / (BLOCK_INSTR * (wg / 256)));
+    fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 64;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    uint32_t *dout;
+    unsigned long long *dclk;
+    CHECK(hipMalloc(&dout, (size_t)cus * 1024 * sizeof(uint32_t)));
+    CHECK(hipMalloc(&dclk, 16));
+    for (int wg : {256, 512, 1024}) {
+        std::vector<uint32_t> h(32);
+        CHECK(hipMemset(dout, 0, 32 * 4));
+        hipLaunchKernelGGL(k_map, dim3(2), dim3(wg), 0, 0, dout);
+        CHECK(hipMemcpy(h.data(), dout, 32 * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < 2; b++) {
+            printf("# workgroup of %d threads, block %d: wave -> (cu, simd, wave slot):", wg, b);
+            for (int w = 0; w < wg / 64; w++) printf(" %d:(%u,%u,%u)", w, (h[b * 16 + w] >> 8) & 15u, (h[b * 16 + w] >> 4) & 3u, h[b * 16 + w] & 15u);
+            printf("\n");
+        }
+    }
+#define U(K) run(#K, K, 4, 1024, iters, dout, dclk, cus)
+    U(u_A); U(u_R); U(u_M); U(u_B); U(u_X); U(u_S); U(u_T);
+    U(u_A63R1); U(u_A31R1); U(u_A15R1); U(u_A7R1); U(u_A3R1); U(u_A1R3); U(u_B3R1); U(u_A3M1); U(u_A7M1); U(u_A3T1);
+    for (int split : {1, 2, 3}) run("older:alignbit younger:add", r_R_A, split, 1024, iters, dout, dclk, cus);
+    for (int split : {1, 2, 3}) run("older:add younger:alignbit", r_A_R, split, 1024, iters, dout, dclk, cus);
+    for (int split : {1, 2, 3}) run("older:mad64 younger:add", r_M_A, split, 1024, iters, dout, dclk, cus);
+    for (int split : {2}) run("older:alignbit younger:mad64", r_R_M, split, 1024, iters, dout, dclk, cus);
+    // two waves per SIMD
+    run("u_A", u_A, 4, 512, iters, dout, dclk, cus);
+    run("u_R", u_R, 4, 512, iters, dout, dclk, cus);
+    run("u_A3R1", u_A3R1, 4, 512, iters, dout, dclk, cus);
+    run("older:alignbit younger:add", r_R_A, 1, 512, iters, dout, dclk, cus);
+    run("older:add younger:alignbit", r_A_R, 1, 512, iters, dout, dclk, cus);
+    return 0;
+}

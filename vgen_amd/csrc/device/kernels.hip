@@ -289,6 +289,9 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 #ifndef VG_SEQ_WAVES_HASH
 #define VG_SEQ_WAVES_HASH 8    // seq_hash_kernel: the generated hash block needs 28 registers + the key's nine words
 #endif
+#ifndef VG_BASE_PRIO
+#define VG_BASE_PRIO 0
+#endif
 #ifndef VG_EC_PRIO
 #define VG_EC_PRIO 0
 #endif
@@ -319,6 +322,9 @@ struct SeqWaves {
 template <int FMT, bool FULL, bool ENDO = false, bool LONE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL>::value, SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL>::value)))
 seq_bwd_kernel(const SeqArgs args) {
+#if VG_BASE_PRIO
+    if (!LONE && !SPLIT) __builtin_amdgcn_s_setprio(VG_BASE_PRIO);
+#endif
 #if VG_EC_PRIO
     if (SPLIT) __builtin_amdgcn_s_setprio(VG_EC_PRIO);   // the point arithmetic has the memory bubbles: it goes first when it can issue, the hash waves fill in
 #endif
