@@ -76,14 +76,20 @@ def test_every_emitted_function_has_a_case():
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("grouped,window,distance", [(False, 0, 1), (True, 0, 1), (False, 8, 1), (False, 16, 2)])
-def test_blocks_compute_the_hashes(name, grouped, window, distance):
+@pytest.mark.parametrize("grouped,window,distance,class_window", [(False, 0, 1, 0), (True, 0, 1, 0), (False, 8, 1, 0), (False, 16, 2, 0),
+                                                                  (False, 0, 1, 1), (False, 0, 1, 4), (False, 0, 1, 40), (True, 0, 1, 8)])
+def test_blocks_compute_the_hashes(name, grouped, window, distance, class_window):
     rng = random.Random(hash((name, grouped, window)) & 0xFFFF)
     p, _, _ = {**g.PROGRAMS, **g.OPTIONAL}[name](grouped)
     if window:
         g.spread(p, window, distance)
+    if class_window:
+        n = len(p.ins)
+        runs = g.by_class(p, class_window)
+        assert sum(runs) == n == len(p.ins)
     reg, nreg = g.allocate(p)
-    assert nreg <= (80 if "keccak" in name else 40)     # the pair fits beside the point arithmetic's registers
+    if class_window <= 8:     # (wider windows are an option of the A/B; what ships is DEFAULT_CLASS_WINDOW)
+        assert nreg <= (80 if "keccak" in name else 40)     # the pair fits beside the point arithmetic's registers
     assert sorted(reg[i] for i in p.inputs) == list(range(len(p.inputs)))
     for _ in range(12):
         m, want = CASES[name](rng)
@@ -127,13 +133,51 @@ def test_asm_text_shape():
     lines = re.findall(r'"([^"]*)\\n\\t"', body)
     valu = [l for l in lines if l.startswith("v_")]
     assert len(valu) == 2196
-    assert sum(l == "s_nop 0" for l in lines) == 731          # one yield per three VALU instructions
+    # the shipped form (round 5): runs by issue class, a priority change at every class boundary, no yields
+    assert "s_nop 0" not in lines
+    level, changes = None, 0
     for a, b in zip(lines, lines[1:]):
-        assert not (a == "s_nop 0" and b == "s_nop 0")
-    # VOP3 instructions never carry a 32-bit literal on gfx9: constants come through the SGPR operand or are inline
-    for l in valu:
+        assert not (a.startswith("s_setprio") and b.startswith("s_setprio"))
+    for l in lines:
+        if l.startswith("s_setprio"):
+            level, changes = int(l.split()[1]), changes + 1
+        elif l.startswith("v_"):
+            assert level == (1 if l.startswith(("v_alignbit_b32", "v_add3_u32", "v_perm_b32")) else 0), l
+    assert lines[-1] == "s_setprio 1" and 500 < changes < 800
+    # VOP3 instructions never carry a 32-bit literal on gfx9: constants come through the SGPR operand or are inline; the s_mov that
+    # loads the SGPR sits directly in front of its reader
+    for i, l in enumerate(lines):
         if l.startswith(("v_add3_u32", "v_bitop3_b32", "v_perm_b32", "v_alignbit_b32")):
             assert not re.search(r"0x[0-9a-f]{8}", l.split(" bitop3:")[0]), l
+        if l.startswith("s_mov_b32"):
+            assert "%[k]" in lines[i + 1], (l, lines[i + 1])
     assert '"=&s"(k)' in body and body.count('"+v"') == 9
-    # no yields: the option the A/B used
+    # the round-4 form, still generated for the A/B: dependency order, one yield per three VALU instructions, no priority changes
+    old = g.generate(yields="every:3", prio=None, class_window=0)
+    body = old[old.index("void hash160_pub33_block("):old.index("void hash160_script22_block(")]
+    lines = re.findall(r'"([^"]*)\\n\\t"', body)
+    assert sum(l == "s_nop 0" for l in lines) == 731 and not any(l.startswith("s_setprio") for l in lines)
     assert "s_nop" not in g.generate(yields="none")
+
+
+def test_runs_by_issue_class_respect_the_dependencies_and_the_window():
+    """by_class only ever moves an instruction in front of instructions it does not depend on, and never further than its window."""
+    for window in (1, 4, 12):
+        p, _, _ = g.prog_pub33_h160()
+        orig = list(p.ins)
+        index = {ins[1]: i for i, ins in enumerate(orig)}
+        runs = g.by_class(p, window)
+        seen = set(p.inputs)
+        for pos, (op, d, srcs, imm) in enumerate(p.ins):
+            assert all(g.known(x) or x in seen for x in srcs)
+            seen.add(d)
+        # an instruction is emitted no later than `window` places after everything older than it has gone
+        done = set()
+        for op, d, srcs, imm in p.ins:
+            oldest_open = min(i for i in range(len(orig)) if orig[i][1] not in done)
+            assert index[d] < oldest_open + window
+            done.add(d)
+        if window == 1:
+            assert p.ins == orig
+        else:
+            assert len(runs) < 800 and max(runs) >= 8

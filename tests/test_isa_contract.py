@@ -143,23 +143,39 @@ def test_the_checker_rejects_a_per_lane_or_system_scope_atomic():
 
 
 def test_the_hash_pair_is_the_generated_block_in_the_generators_order(isa):
-    """The order of the hash instructions and the yields between them are design decisions measured on the MI355X
-    (profiles/r04_hash_blocks_ab.txt): the assembly must contain the generator's list verbatim, modulo register names."""
+    """The order of the hash instructions — runs of half-rate and of full-rate instructions — and the wave-priority changes between the
+    runs are design decisions measured on the MI355X (profiles/r05_prio_ab.txt): the assembly must contain the generator's list verbatim,
+    modulo register names."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "vgen_amd", "csrc", "device"))
     import hashgen as g
     p, _, _ = g.prog_pub33_h160()
+    g.by_class(p, g.DEFAULT_CLASS_WINDOW)
     reg, _ = g.allocate(p)
-    want = [re.sub(r"%\[\w+\]", "R", l) for l in g.asm_lines(p, reg)[0]]
+    prio = tuple(int(x) for x in g.DEFAULT_PRIO.split(":"))
+    want = [re.sub(r"%\[\w+\]", "R", l) for l in g.asm_lines(p, reg, g.DEFAULT_YIELD, prio)[0]]
     norm = []
     for l in isa[HEADLINE]["body"]:
         l = l.split(";")[0].strip()
-        if re.match(r"(v_|s_nop|s_mov_b32)", l):
+        if re.match(r"(v_|s_nop|s_mov_b32|s_setprio)", l):
             norm.append(re.sub(r"\b[vs]\d+\b", "R", l))
     first = next(i for i, l in enumerate(norm) if l == want[0] and norm[i:i + 8] == want[:8])
     got = norm[first:first + len(want)]
     assert got == want
-    assert sum(l == "s_nop 0" for l in want) == 731 and sum(l.startswith("v_") for l in want) == 2196
+    assert sum(l.startswith("v_") for l in want) == 2196 and "s_nop 0" not in want
+    # every half-rate run at priority 1, every full-rate run at 0, and the block leaves at the kernel's own level
+    level = None
+    for l in want:
+        if l.startswith("s_setprio"):
+            level = int(l.split()[1])
+        elif l.startswith("v_"):
+            half = l.startswith(("v_alignbit_b32", "v_add3_u32", "v_perm_b32"))
+            assert level == (1 if half else 0), l
+    assert want[-1] == "s_setprio 1" and 500 < sum(l.startswith("s_setprio") for l in want) < 800
+    # the kernel itself runs at priority 1 from its first instructions on (the point arithmetic's multiply-adds take first places too)
+    body = [l.split(";")[0].strip() for l in isa[HEADLINE]["body"]]
+    first_valu = next(i for i, l in enumerate(body) if l.startswith("v_"))
+    assert any(l == "s_setprio 1" for l in body[:first_valu + 40])
     # and the block appears once: the loop over a lane's keys is not unrolled around it
     assert count(isa[HEADLINE]["body"], r"v_alignbit_b32") < 2 * 868
 
@@ -169,7 +185,7 @@ def test_the_one_frame_twin_carries_no_yields(isa):
     wave that has its SIMD to itself pays four cycles per yield.  Same budget as the headline kernel."""
     k = isa[LONE]
     assert k["vgpr"] <= 128 and k["scratch"] == 0
-    assert count(k["body"], r"s_nop") < 100 < 700 < count(isa[HEADLINE]["body"], r"s_nop")
+    assert count(k["body"], r"s_nop") < 100 and count(k["body"], r"s_setprio") == 0 and count(isa[HEADLINE]["body"], r"s_setprio") > 500
     assert count(k["body"], r"v_alignbit_b32") >= 868
 
 

@@ -662,7 +662,14 @@ def function_source(name, grouped=False, yields="every:3", window=0, distance=1,
     return src
 
 
-def generate(grouped=False, yields="every:3", window=0, distance=1, overrides=None, extra=(), prio=None, class_window=0):
+# What the Makefile builds (round 5): runs by issue class over a window of 4 (29 VGPRs), half-rate runs at wave priority 1, full-rate runs at 0,
+# back to 1 - the level the scan kernels run their point arithmetic at - on the way out; no yields (a priority change gives the slot away as well).
+# The round-4 blocks are `--class-window 0 --prio none --yield every:3`.
+DEFAULT_CLASS_WINDOW, DEFAULT_PRIO, DEFAULT_YIELD = 4, "1:0:1", "none"
+
+
+def generate(grouped=False, yields=DEFAULT_YIELD, window=0, distance=1, overrides=None, extra=(),
+             prio=tuple(int(x) for x in DEFAULT_PRIO.split(":")), class_window=DEFAULT_CLASS_WINDOW):
     src = "// GENERATED by device/hashgen.py (`make -C vgen_amd/csrc hashblocks`) - do not edit.\n"
     src += "// The address hashes of the scan kernels as single asm statements of gfx950 instructions; see hashgen.py.\n\n"
     for name in list(PROGRAMS) + list(extra):
@@ -680,10 +687,11 @@ def main(argv):
         mode, n = opt("--filler", "").split(":")
         FILLER = (mode, int(n))
     overrides = dict(a.split("=", 1) for i, a in enumerate(argv) if i and argv[i - 1] == "--yield-for")   # --yield-for name=mode
-    sys.stdout.write(generate(opt("--order", "natural") == "grouped", opt("--yield", "every:3"),
+    sys.stdout.write(generate(opt("--order", "natural") == "grouped", opt("--yield", DEFAULT_YIELD),
                               int(opt("--window", "0")), int(opt("--distance", "1")), overrides,
                               [a for i, a in enumerate(argv) if i and argv[i - 1] == "--with"],
-                              tuple(int(x) for x in opt("--prio", "").split(":")) if "--prio" in argv else None, int(opt("--class-window", "0"))))
+                              None if opt("--prio", DEFAULT_PRIO) == "none" else tuple(int(x) for x in opt("--prio", DEFAULT_PRIO).split(":")),
+                              int(opt("--class-window", str(DEFAULT_CLASS_WINDOW)))))
 
 
 if __name__ == "__main__":

@@ -289,8 +289,12 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 #ifndef VG_SEQ_WAVES_HASH
 #define VG_SEQ_WAVES_HASH 8    // seq_hash_kernel: the generated hash block needs 28 registers + the key's nine words
 #endif
+// Wave priority by issue class (round 5; tools/ubench_phase*.hip, tools/issue_model.py): a SIMD fills each 4-cycle issue slot with the next
+// instruction of its highest-priority ready wave and, behind it, one FULL-RATE instruction of another wave.  Half-rate instructions and the
+// multiply-adds of the point arithmetic only ever take the first place, so the scan kernels run at priority 1 and the generated hash blocks drop
+// to 0 for their runs of full-rate instructions (device/hashgen.py), which then ride in the second places: 13.2 -> 15.5 Gkeys/s.
 #ifndef VG_BASE_PRIO
-#define VG_BASE_PRIO 0
+#define VG_BASE_PRIO 1
 #endif
 #ifndef VG_EC_PRIO
 #define VG_EC_PRIO 0
@@ -660,6 +664,9 @@ struct HashWaves {   // the Base58Check encoder + DFA walk of the P2PKH matcher 
 template <int FMT, bool FULL>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(HashWaves<FMT, FULL>::value, HashWaves<FMT, FULL>::value)))
 seq_hash_kernel(const SeqArgs args) {
+#if VG_BASE_PRIO
+    __builtin_amdgcn_s_setprio(VG_BASE_PRIO);
+#endif
     static_assert(FMT == VGF_P2PKH || FMT == VGF_P2SH_P2WPKH, "compressed-key formats (P2WPKH shares P2PKH's payload)");
     extern __shared__ u32 dfa_lds[];   // FULL: the DFA blob
     const int tid = threadIdx.x;
@@ -1124,6 +1131,9 @@ __global__ void __launch_bounds__(KEYS_WG) keys_fwd_kernel(const KeysArgs args) 
 // reported / dumped at variant * vstride + i, vstride = the context's batch size).
 template <int FMT, bool FULL, bool ENDO = false>
 __global__ void __launch_bounds__(KEYS_WG) keys_bwd_kernel(const KeysArgs args) {
+#if VG_BASE_PRIO
+    __builtin_amdgcn_s_setprio(VG_BASE_PRIO);   // (the level the hash blocks return to; see VG_BASE_PRIO)
+#endif
     __shared__ u32 tree[9 * KEYS_WG];
     __shared__ u32 ypark[ENDO && (FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM) ? 9 * KEYS_WG : 1];   // ENDO: the point's y
     extern __shared__ u32 dfa_lds[];    // FULL: the DFA blob
