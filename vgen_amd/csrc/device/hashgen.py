@@ -76,6 +76,9 @@ def known(v):
     return isinstance(v, int)
 
 
+SPLIT_KADD = None   # (m, n): m of every n `acc + v + K` sums as two v_add_u32 instead of s_mov + v_add3_u32 (--split-kadd m:n)
+
+
 class Program:
     """A straight-line list of instructions over virtual registers.
 
@@ -144,6 +147,11 @@ class Program:
             acc = self.emit("add3", (acc, rest[0], rest[1]))
             rest = rest[2:]
         if rest and kc:
+            # acc + v + K: one half-rate v_add3 behind an s_mov of K, or (SPLIT_KADD: every n-th of them) two full-rate adds, the second
+            # with K as a literal - a place in the FIRST half of an issue slot traded for two in the second halves (see by_class)
+            self.kadds = getattr(self, "kadds", 0) + 1
+            if SPLIT_KADD and not inline_const(kc) and self.kadds % SPLIT_KADD[1] < SPLIT_KADD[0]:
+                return self.emit("add", (self.emit("add", (acc, rest[0])), kc))
             return self.emit("add3", (acc, rest[0], kc))
         if rest:
             return self.emit("add", (acc, rest[0]))
@@ -344,10 +352,12 @@ def prog_keccak_addr(grouped=False):
     return p, "const u32 xw[8], const u32 yw[8]", prologue
 
 
+# keccak_addr_block: in round 4, in dependency order, the block ran no faster than hipcc's rolled rounds (same 5 003 instructions per key); as runs by
+# issue class with the priority changes it is worth +28 % on every Ethereum configuration (profiles/r05_keccak_ab.txt): 1 351 half-rate funnel
+# shifts against 2 844 full-rate booleans, which now ride in the second places of the issue slots.
 PROGRAMS = {"hash160_pub33_block": prog_pub33_h160, "hash160_script22_block": prog_script22_h160,
-            "hash160_pub65_block": prog_pub65_h160, "base58_check_block": prog_base58_check}
-# Not emitted unless asked for (--with NAME): measured and not shipped (profiles/r04_hash_blocks_ab.txt; kernels.hip VG_KECCAK_BLOCK)
-OPTIONAL = {"keccak_addr_block": prog_keccak_addr}
+            "hash160_pub65_block": prog_pub65_h160, "base58_check_block": prog_base58_check, "keccak_addr_block": prog_keccak_addr}
+OPTIONAL = {}    # (--with NAME: blocks generated for an A/B only)
 # yields per function where they differ from the default
 YIELDS = {"keccak_addr_block": "none"}
 
@@ -681,7 +691,9 @@ def main(argv):
     def opt(name, default):
         return argv[argv.index(name) + 1] if name in argv else default
 
-    global YIELD_INSN, FILLER
+    global YIELD_INSN, FILLER, SPLIT_KADD
+    if "--split-kadd" in argv:
+        SPLIT_KADD = tuple(int(x) for x in opt("--split-kadd", "").split(":"))
     YIELD_INSN = opt("--yield-insn", YIELD_INSN)
     if "--filler" in argv:
         mode, n = opt("--filler", "").split(":")

@@ -40,6 +40,9 @@
 #ifndef VG_PARK
 #define VG_PARK 0
 #endif
+#ifndef VG_KECCAK_BLOCK
+#define VG_KECCAK_BLOCK 1   // Ethereum: Keccak-f as a generated block in runs by issue class (payload_from_point)
+#endif
 #ifndef VG_PARKI
 #define VG_PARKI 1
 #endif
@@ -61,7 +64,7 @@ constexpr int WG = SEQ_WG;   // 256 lanes per workgroup
 #define VG_SEQ_WAVES_P2TR 2
 #endif
 #ifndef VG_SEQ_WAVES_ETH
-#define VG_SEQ_WAVES_ETH 3
+#define VG_SEQ_WAVES_ETH 4
 #endif
 
 // ---- LDS / lane helpers ---------------------------------------------------------------------------------
@@ -174,9 +177,8 @@ __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_cano
     } else {  // VGF_ETHEREUM
         u32 yw[8];
         fe_to_words(y_canon, yw);
-#ifdef VG_KECCAK_BLOCK   // A/B only (hashgen.py --with keccak_addr_block): Keccak-f as one block of 4 195 instructions in 74 registers measured
-        // +0.7 % with a prefilter, -14 % on six images per point and -8 % under the on-device DFA (33 KB of straight-line code per
-        // copy against hipcc's rolled rounds; same instruction count: 5 003 per key either way) - profiles/r04_hash_blocks_ab.txt
+#if VG_KECCAK_BLOCK   // Keccak-f as one generated block of 4 195 instructions in runs by issue class (device/hashgen.py): +28 % on every Ethereum
+        // configuration (profiles/r05_keccak_ab.txt).  In dependency order without the priority changes (round 4) it only matched hipcc's rolled rounds.
         keccak_addr_block(xw, yw, out);
 #else
         keccak256_pub64_addr(xw, yw, out);
@@ -302,9 +304,10 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 #ifndef VG_SEQ_WAVES_HASH_FULL
 #define VG_SEQ_WAVES_HASH_FULL 6
 #endif
-template <int FMT, bool FULL>
+template <int FMT, bool FULL, bool ENDO = false>
 struct SeqWaves {
-    static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? VG_SEQ_WAVES_ETH
+    // (Ethereum: four waves since the Keccak block and the running inverse in LDS; the six-image on-device matcher would spill there: three)
+    static constexpr int value = FMT == VGF_P2TR ? VG_SEQ_WAVES_P2TR : FMT == VGF_ETHEREUM ? (FULL && ENDO ? 3 : VG_SEQ_WAVES_ETH)
                                  : FULL ? VG_SEQ_WAVES_FULL20 : FMT == VGF_P2SH_P2WPKH ? VG_SEQ_WAVES_P2SH
                                  : FMT == VGF_P2PKH_UNCOMPRESSED ? VG_SEQ_WAVES_UNCOMP : VG_SEQ_WAVES_P2PKH;
 };
@@ -324,7 +327,7 @@ struct SeqWaves {
 // key's prefix byte (0x02 | parity of y) per key in args.xs and leaves hashes, filter and output to seq_hash_kernel, which runs one
 // key per lane at eight waves per SIMD (see there).
 template <int FMT, bool FULL, bool ENDO = false, bool LONE = false, bool SPLIT = false>
-__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL>::value, SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL>::value)))
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL, ENDO>::value, SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL, ENDO>::value)))
 seq_bwd_kernel(const SeqArgs args) {
 #if VG_BASE_PRIO
     if (!LONE && !SPLIT) __builtin_amdgcn_s_setprio(VG_BASE_PRIO);
@@ -345,7 +348,7 @@ seq_bwd_kernel(const SeqArgs args) {
     constexpr bool PARK = PARKM == 1, PARK2 = PARKM == 2;
     // PARKI: the instantiations that would otherwise spill a few registers at their 128-register cap (the uncompressed-key format: a second
     // SHA-256 block's sixteen message words; the six-image on-device matcher) keep the running inverse in 9 KB of LDS of its own instead
-    constexpr bool PARKI = VG_PARKI && !PARK && !PARK2 && !LONE && (FMT == VGF_P2PKH_UNCOMPRESSED || (FMT == VGF_P2PKH && FULL && ENDO));
+    constexpr bool PARKI = VG_PARKI && !PARK && !PARK2 && !LONE && (FMT == VGF_P2PKH_UNCOMPRESSED || FMT == VGF_ETHEREUM || (FMT == VGF_P2PKH && FULL && ENDO));
     __shared__ u32 rpark[PARK ? 17 * WG : (PARK2 || PARKI) ? 9 * WG : 1];   // (PARK: R.y's top limb stays in a register: 26 KB of LDS per workgroup lets six share a CU)
     const int tid = threadIdx.x;
     const GenTables gtab{args.gtab, args.gtab16, args.gtab_bits};   // P2TR: fixed-window generator tables, read from global memory (L2 / Infinity Cache / HBM)
