@@ -903,23 +903,31 @@ def main():
     if pmc:
         roofline["issue"] = {k: pmc[k] for k in ("valu_busy", "valu_instr_per_key", "valu_instr_per_key_all_kernels", "waves_per_simd",
                                                  "source", "how") if k in pmc}
-        # The same bound from wall time: VALU instructions retired per second (instructions per key from the counters x the
-        # keys per second of this run) against (a) one wave64 VALU instruction per SIMD every 4 cycles at the measured shader
-        # clock — the issue rate of the instruction classes that make up ~60 % of the mix (v_alignbit, v_add3, v_mad_u64_u32,
-        # v_bfe ...: 35-38 T lane-instructions/s in profiles/r01_ubench_valu.jsonl) — and (b) the price the mix would have if
-        # every instruction issued at its own class's rate (0.6 x 4.15 + 0.4 x 2.3 = 3.4 cycles; v_add / v_xor / v_bitop3
-        # issue in 2.2-2.4 in streams of their own kind).  Until round 4 (a) was what the kernel reached (0.98); with the hash
-        # pair as scheduled blocks with issue-slot yields (device/hashgen.py) the steady state runs ABOVE it, so (b) is the ceiling.
+        # The same from wall time, against the issue stage as the probes of round 5 measured it (tools/ubench_phase*.hip, tools/issue_model.py): a SIMD
+        # fills one 4-cycle slot with the next instruction of its highest-priority ready wave and, behind it, one FULL-RATE instruction of another wave;
+        # multiply-adds fill a slot alone.  A key therefore needs at least X + max(C, (C + S) / 2) slots (profiles/r05_issue_classes.json: the static
+        # census of the kernel by issue class) — the kernel-level ceiling `frac_of_slot_bound` is measured against.  Until round 4 every instruction
+        # of the mixed stream cost a slot of its own (3.8 cycles per instruction); with the hash blocks as runs by issue class and the priority
+        # changes between them (device/hashgen.py) the steady state retires ~1.3 instructions per slot.
         ipk = pmc.get("valu_instr_per_key_all_kernels")
         rate_keys = (sustained["value"] if sustained else value) * 1e6 / world
         if ipk and not args.endo:
             mhz = shader_mhz or region_mhz or 2400.0
-            peak_t = N_SIMD * mhz * 1e6 / 4.0 * 64 / 1e12
+            slots_per_s = N_SIMD * mhz * 1e6 / 4.0
+            slots_per_key = slots_per_s / (rate_keys / 64.0)
             roofline["issue"].update({"valu_lane_instr_per_s_T": round(rate_keys * ipk / 1e12, 2),
-                                      "issue_peak_T_at_4_cycles_per_wave_instr": round(peak_t, 2),
-                                      "frac_of_issue_peak": round(rate_keys * ipk / 1e12 / peak_t, 4),
-                                      "simd_cycles_per_valu_instr_steady_state": round(4.0 * peak_t / (rate_keys * ipk / 1e12), 3),
-                                      "frac_of_ideal_mix_3p4_cycles": round(rate_keys * ipk / 1e12 / (peak_t * 4.0 / 3.4), 4)})
+                                      "simd_cycles_per_valu_instr_steady_state": round(4.0 * slots_per_key / ipk, 3),
+                                      "issue_slots_per_key_steady_state": round(slots_per_key, 1),
+                                      "valu_per_issue_slot_steady_state": round(ipk / slots_per_key, 3)})
+            try:
+                cls = json.load(open(os.path.join(ROOT, "profiles", "r05_issue_classes.json")))
+                floor = cls["issue_slots_per_key_at_least"] * ipk / cls["per_key"]["valu"]     # (+ the chain kernels' share, priced like the rest)
+                roofline["issue"].update({"classes_per_key": cls["per_key"], "issue_slots_per_key_at_least": round(floor, 1),
+                                          "frac_of_slot_bound": round(floor / slots_per_key, 4),
+                                          "slot_model": "slots >= X + max(C, (C + S) / 2): X exclusive (v_mad_u64_u32), C half-rate (first place of a slot only), "
+                                                        "S full-rate (either place); profiles/r05_issue_classes.json, tools/issue_model.py"})
+            except (OSError, ValueError, KeyError):
+                pass
 
     out = {
         "metric": "Mkeys/sec (keys tried per second)", "value": round(value, 2), "unit": "Mkeys/sec", "n_gpus": world,
