@@ -33,7 +33,7 @@ constexpr int BLOCK_INSTR = 1024;
     asm volatile(S : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(acc[0]),   \
                  "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])                     \
                  : "v"(y), "v"(z)                                                                                                     \
-                 : "vcc")
+                 : "vcc", "s30")
 
 __device__ __forceinline__ uint32_t hw_id() {
     uint32_t v;

@@ -76,6 +76,8 @@ def known(v):
     return isinstance(v, int)
 
 
+CLASS_MAX_RUN = 0   # (--class-max-run n: by_class changes class after n instructions if the other class has work)
+CLASS_DISTANCE = 0  # (--class-distance d: by_class prefers instructions that do not read one of the last d results)
 SPLIT_KADD = None   # (m, n): m of every n `acc + v + K` sums as two v_add_u32 instead of s_mov + v_add3_u32 (--split-kadd m:n)
 
 
@@ -454,7 +456,7 @@ def spread(p, window=24, distance=1):
 HALF_RATE = {"alignbit", "add3", "bswap"}
 
 
-def by_class(p, window=40):
+def by_class(p, window=40, distance=0):
     """Reorder p.ins into alternating runs of half-rate and full-rate instructions: greedy list scheduling that stays in the
     current class while any instruction of it within `window` places of the oldest unscheduled one has its operands ready
     (the window bounds the extra register pressure).  asm_lines(prio=...) then raises the wave's priority for the half-rate
@@ -465,21 +467,26 @@ def by_class(p, window=40):
     producer = {d: i for i, (_, d, _, _) in enumerate(ins)}
     preds = [[producer[s] for s in srcs if not known(s) and s in producer] for _, _, srcs, _ in ins]
     done = [False] * n
-    order, runs = [], []
+    order, runs, pos = [], [], {}
     head, cls = 0, None
     while len(order) < n:
         while head < n and done[head]:
             head += 1
         ready = [i for i in range(head, min(n, head + window)) if not done[i] and all(done[q] for q in preds[i])]
         same = [i for i in ready if (ins[i][0] in HALF_RATE) == cls]
+        if same and CLASS_MAX_RUN and runs and runs[-1] >= CLASS_MAX_RUN and len(same) < len(ready):
+            same = []      # (A/B only: cap the run although more of its class are ready)
         if same:
-            pick = same[0]
+            # (distance > 0, A/B only: prefer an instruction that does not read one of the last `distance` results)
+            far = [i for i in same if all(len(order) - pos[q] > distance for q in preds[i])] if distance else same
+            pick = (far or same)[0]
             runs[-1] += 1
         else:
             pick = ready[0]
             cls = ins[pick][0] in HALF_RATE
             runs.append(1)
         done[pick] = True
+        pos[pick] = len(order)
         order.append(pick)
     p.ins = [ins[i] for i in order]
     return runs
@@ -630,7 +637,7 @@ def add_filler(lines, mode, n):
 def function_source(name, grouped=False, yields="every:3", window=0, distance=1, prio=None, class_window=0):
     p, params, prologue = {**PROGRAMS, **OPTIONAL}[name](grouped)
     left = spread(p, window, distance) if window else None
-    runs = by_class(p, class_window) if class_window else None
+    runs = by_class(p, class_window, CLASS_DISTANCE) if class_window else None
     reg, nreg = allocate(p)
     lines, valu, salu, nyield = asm_lines(p, reg, yields, prio)
     filler = FILLER if name == "hash160_pub33_block" else None
@@ -691,7 +698,9 @@ def main(argv):
     def opt(name, default):
         return argv[argv.index(name) + 1] if name in argv else default
 
-    global YIELD_INSN, FILLER, SPLIT_KADD
+    global YIELD_INSN, FILLER, SPLIT_KADD, CLASS_DISTANCE, CLASS_MAX_RUN
+    CLASS_MAX_RUN = int(opt("--class-max-run", "0"))
+    CLASS_DISTANCE = int(opt("--class-distance", "0"))
     if "--split-kadd" in argv:
         SPLIT_KADD = tuple(int(x) for x in opt("--split-kadd", "").split(":"))
     YIELD_INSN = opt("--yield-insn", YIELD_INSN)

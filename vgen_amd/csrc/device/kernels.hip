@@ -301,6 +301,9 @@ __global__ void __launch_bounds__(64) seq_inv_kernel(u32 *root, u32 groups) {
 #ifndef VG_EC_PRIO
 #define VG_EC_PRIO 0
 #endif
+#ifndef VG_EC_SPRIO
+#define VG_EC_SPRIO 0
+#endif
 #ifndef VG_SEQ_WAVES_HASH_FULL
 #define VG_SEQ_WAVES_HASH_FULL 6
 #endif
@@ -498,11 +501,16 @@ seq_bwd_kernel(const SeqArgs args) {
             for (int i = 0; i < 9; i++) dy.n[i] += q.nqy[i];   // magnitude <= 3
             fe_mul(lam, dy, idx);
             fe_sqr_add(x3, lam, nsum);            // lam^2 - R.x - Q.x, weakly normalised
+            // VG_EC_SPRIO (A/B): the carry chains between the multiplications are runs of full-rate instructions: at priority 0 they can ride
+            // behind other waves' half-rate instructions like the hash blocks' full-rate runs do
+            if (VG_EC_SPRIO && !LONE) __builtin_amdgcn_s_setprio(0);
             fe_canonicalize_product(x3);
             fe_neg(t, x3, 1);
 #pragma unroll
             for (int i = 0; i < 9; i++) t.n[i] += q.qx[i];                                  // magnitude 3
+            if (VG_EC_SPRIO && !LONE) __builtin_amdgcn_s_setprio(VG_BASE_PRIO);
             fe_mul_add(y3, lam, t, nqy);          // lam*(Q.x - x3) - Q.y
+            if (VG_EC_SPRIO && !LONE) __builtin_amdgcn_s_setprio(0);
             if (FMT == VGF_P2PKH || FMT == VGF_P2WPKH || FMT == VGF_P2SH_P2WPKH)
                 y3.n[0] = fe_parity_weak(y3);     // a compressed key takes only the parity of y (bit 0 is all that is read)
             else
