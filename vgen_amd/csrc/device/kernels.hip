@@ -333,7 +333,10 @@ template <int FMT, bool FULL, bool ENDO = false, bool LONE = false, bool SPLIT =
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL, ENDO>::value, SPLIT ? VG_SEQ_WAVES_EC : SeqWaves<FMT, FULL, ENDO>::value)))
 seq_bwd_kernel(const SeqArgs args) {
 #if VG_BASE_PRIO
-    if (!LONE && !SPLIT) __builtin_amdgcn_s_setprio(VG_BASE_PRIO);
+    // (the one-frame twin too: its launches share SIMDs with the steady-state kernel's whenever a burst of dispatches starts, and at priority 0 they
+    //  would only ever be served when no other wave has anything to issue - the in-order host loop then waits on them: second completion of a burst
+    //  at 831 us instead of ~540)
+    if (!SPLIT) __builtin_amdgcn_s_setprio(VG_BASE_PRIO);
 #endif
 #if VG_EC_PRIO
     if (SPLIT) __builtin_amdgcn_s_setprio(VG_EC_PRIO);   // the point arithmetic has the memory bubbles: it goes first when it can issue, the hash waves fill in
