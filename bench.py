@@ -971,8 +971,8 @@ def main():
                                        "frac": None if w_bwd is None else round(N * K6 * w_bwd / (lone * 1e-3) / 1e12 / PEAK_TLANEOPS, 4),
                                        "keys_per_s_equivalent": round(N * K6 / (lone * 1e-3) / 1e6, 1),
                                        "variant": "a dispatch issued while at most one other frame of its context is in flight launches seq_bwd_kernel<.., LONE> (P2PKH / P2WPKH prefilter only): hipcc's "
-                                                  "schedule of the hash pair, because a wave that has its SIMD to itself pays 4 cycles for every issue-slot yield of "
-                                                  "the steady-state kernel (that kernel alone at 2^20 keys: 0.129 ms, profiles/r04_hash_blocks_ab.txt)"}
+                                                  "schedule of the hash pair, because a wave that has its SIMD to itself pays 4 cycles for every priority change of "
+                                                  "the steady-state kernel's hash blocks (that kernel alone at 2^20 keys: 0.132 ms, profiles/r05_prio_ab.txt)"}
         except Exception as e:   # noqa: BLE001  (an auxiliary leg never costs the headline line)
             roofline["lone_launch"] = {"error": f"{type(e).__name__}: {e}"}
         # time-to-first-match (the second half of BASELINE.json's metric): a `generate -c 1` style scan

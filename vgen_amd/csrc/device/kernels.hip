@@ -130,7 +130,7 @@ __device__ __forceinline__ u32 match_slot(DevMatchHeader *hdr, bool hit, u32 mat
 // ---- the address hashes as scheduled instruction blocks ----------------------------------------------------
 // hash160_pub33_block / hash160_script22_block / hash160_pub65_block / base58_check_block: one asm statement each, generated by
 // device/hashgen.py from the same round functions as core/hash.h (the Makefile writes hash_blocks.inc).  The order of the
-// instructions and the issue-slot yields between them are part of the kernel's design, not hipcc's.
+// instructions — runs by issue class — and the wave-priority changes between the runs are part of the kernel's design, not hipcc's.
 #include "hash_blocks.inc"
 
 // ---- payload per format -----------------------------------------------------------------------------
@@ -153,7 +153,7 @@ struct PayloadWords {
 // whose payload is a hash of the key itself (the taproot output key needs a scalar multiplication and a shared inversion
 // of its own: p2tr_tweak_kernel / p2tr_out_kernel below).
 // LONE: hipcc's own schedule of core/hash.h instead of the block — for launches that have the chip to themselves (one wave per
-// SIMD), where the compiler's interleaving of rounds wins and every yield costs four cycles (113 against 133 us at 2^20 keys).
+// SIMD), where the compiler's interleaving of rounds wins and every priority change costs four cycles (111 against ~130 us at 2^20 keys).
 template <int FMT, bool LONE = false>
 __device__ __forceinline__ bool payload_from_point(const fe &x, const fe &y_canon, u32 *out) {
     static_assert(FMT != VGF_P2TR, "taproot payloads come from p2tr_tweak_kernel / p2tr_out_kernel");

@@ -1211,7 +1211,7 @@ int rt_dispatch(vgen_ctx *c, uint32_t frame, const uint8_t start_key_be[32]) {
     a.groups = c->groups;
     a.n = c->batch;
     a.s = S;
-    // The twin without issue-slot yields serves launches that will have their SIMDs (nearly) to themselves: decided by what is
+    // The twin without priority changes (hipcc's schedule of the hash pair) serves launches that will have their SIMDs (nearly) to themselves: decided by what is
     // IN FLIGHT when this dispatch is issued — at most lone_max_others other frames of this context —, not by how many frames the
     // context was created with: a caller that keeps one or two dispatches going on a 12-frame context (the reference's own loop keeps
     // 2, src/gpu.rs:399) gets the kernel that is 17 % faster alone, and so do the first dispatches of a burst.
