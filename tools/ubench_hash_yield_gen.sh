@@ -9,7 +9,7 @@ for i in 0 1 2 3 4 5; do
   M="${MODES[$i]}"; INSN="s_nop 0"; FILL=""
   case "$M" in *"+"*) FILL="--filler ${M#*+}"; M="${M%%+*}";; esac   # "mode+seq:N" / "mode+mix:N": N multiply-adds after / spread through the block
   case "$M" in *"|"*) INSN="${M#*|}"; M="${M%%|*}";; esac            # "mode|instruction": another yield instruction
-  python3 ../vgen_amd/csrc/device/hashgen.py --yield "$M" --yield-insn "$INSN" $FILL > hb_$i.inc
+  python3 ../vgen_amd/csrc/device/hashgen.py --class-window 0 --prio none --yield "$M" --yield-insn "$INSN" $FILL > hb_$i.inc   # (round 4's dependency order: the yields' own A/B)
   echo "#define HB_LABEL_$i \"block ${MODES[$i]}\"" >> hb_labels.h
   if [ -n "$FILL" ]; then echo "#define HB_CALL_$i(p, x, h, f) hb$i::hash160_pub33_block(p, x, f, h)" >> hb_labels.h
   else echo "#define HB_CALL_$i(p, x, h, f) hb$i::hash160_pub33_block(p, x, h)" >> hb_labels.h; fi
