@@ -78,6 +78,7 @@ def known(v):
 
 CLASS_MAX_RUN = 0   # (--class-max-run n: by_class changes class after n instructions if the other class has work)
 CLASS_DISTANCE = 0  # (--class-distance d: by_class prefers instructions that do not read one of the last d results)
+SPLIT_ADD3 = None   # (m, n): m of every n three-variable sums as two v_add_u32 (--split-add3 m:n)
 SPLIT_KADD = None   # (m, n): m of every n `acc + v + K` sums as two v_add_u32 instead of s_mov + v_add3_u32 (--split-kadd m:n)
 
 
@@ -146,7 +147,11 @@ class Program:
             return kc
         acc, rest = vs[0], vs[1:]
         while len(rest) >= 2:
-            acc = self.emit("add3", (acc, rest[0], rest[1]))
+            self.add3s = getattr(self, "add3s", 0) + 1
+            if SPLIT_ADD3 and self.add3s % SPLIT_ADD3[1] < SPLIT_ADD3[0]:      # (A/B: a three-input sum as two full-rate adds)
+                acc = self.emit("add", (self.emit("add", (acc, rest[0])), rest[1]))
+            else:
+                acc = self.emit("add3", (acc, rest[0], rest[1]))
             rest = rest[2:]
         if rest and kc:
             # acc + v + K: one half-rate v_add3 behind an s_mov of K, or (SPLIT_KADD: every n-th of them) two full-rate adds, the second
@@ -698,7 +703,9 @@ def main(argv):
     def opt(name, default):
         return argv[argv.index(name) + 1] if name in argv else default
 
-    global YIELD_INSN, FILLER, SPLIT_KADD, CLASS_DISTANCE, CLASS_MAX_RUN
+    global YIELD_INSN, FILLER, SPLIT_KADD, SPLIT_ADD3, CLASS_DISTANCE, CLASS_MAX_RUN
+    if "--split-add3" in argv:
+        SPLIT_ADD3 = tuple(int(x) for x in opt("--split-add3", "").split(":"))
     CLASS_MAX_RUN = int(opt("--class-max-run", "0"))
     CLASS_DISTANCE = int(opt("--class-distance", "0"))
     if "--split-kadd" in argv:
