@@ -7,21 +7,24 @@ emitted list is the floor of the computation: 6 rotates + 4 three-input booleans
 + 2 rotates + 2 additions per RIPEMD-160 step.  The list is register-allocated by a linear scan (a pair lives in 28 VGPRs
 and one SGPR for literals) and written out as ONE `asm` statement per hash, so the order below IS the order the SIMD sees.
 
-Two things are decided here rather than by hipcc, both measured in the real kernels on the MI355X (DESIGN.md §3-4, EXPERIMENTS.md;
-profiles/r04_hash_blocks_ab.txt):
-  * the ORDER: the dependency order of the round functions.  hipcc interleaves rounds for instruction-level parallelism,
-    which a SIMD holding four waves does not need; spreading dependent neighbours apart (`spread`) changes nothing either.
-  * the YIELDS: an `s_nop 0` after every third VALU instruction.  The wave gives up one issue slot; with four or more
-    waves on a SIMD (the scan's steady state) the chip retires 5-6 % more keys per second (12.4 -> 13.1 Gkeys/s; the hash
-    pair alone: +5.7 % at four waves per SIMD, +9.3 % at eight, tools/ubench_hash_yield.hip); one yield per 2..4
-    instructions is the plateau, a yield after every instruction loses again.  A launch that has the chip to itself at ONE
-    wave per SIMD (2^20 keys, frames = 1) would pay 4 cycles per yield (+17 % on seq_bwd_kernel's 110 us): such contexts
-    launch a twin of the kernel that keeps hipcc's schedule of core/hash.h (kernels.hip: LONE).
+Two things are decided here rather than by hipcc, both measured in the real kernels on the MI355X (EXPERIMENTS.md):
+  * the ORDER: alternating RUNS of half-rate (v_alignbit, v_add3, v_perm) and of full-rate instructions (VOP2 add / shift, v_bitop3), made by
+    a list scheduler over a window of 4 places of the dependency order (`by_class`; 29 registers instead of 28).
+  * the PRIORITY: an `s_setprio` at every class boundary — half-rate runs at wave priority 1 (the level the kernels' point arithmetic runs
+    at), full-rate runs at 0.  A gfx950 SIMD fills a 4-cycle issue slot with the next instruction of its highest-priority ready wave and, behind
+    it, ONE full-rate instruction of another wave; half-rate instructions only take the first place.  Under age-only arbitration the oldest
+    wave owns that place and a mixed stream costs 4 cycles per instruction, the full-rate ones included (tools/ubench_phase*.hip); with the
+    priorities the full-rate runs of three waves ride behind the fourth's half-rate run: the hash pair alone 18.6 -> 23.4 Gpairs/s at four
+    waves per SIMD, the scan 13.2 -> 15.5 Gkeys/s (profiles/r05_prio_ab.txt).  Round 4's form — dependency order with an `s_nop 0` after every
+    third instruction, which makes the oldest wave skip a slot now and then (+5.7 %) — is `--class-window 0 --prio none --yield every:3`.
+    A launch that has the chip to itself at ONE wave per SIMD pays 4 cycles per priority change: such dispatches launch a twin of the kernel
+    that keeps hipcc's schedule of core/hash.h (kernels.hip: LONE).
 
 The same instruction lists run in Python (`evaluate`, `evaluate_allocated`) for the CPU test-suite: tests/test_hashgen.py
 checks them, before and after register allocation, against hashlib and the oracle.
 
-usage: python3 hashgen.py [--order natural|grouped] [--class-window W --prio HALF:FULL] [--yield every:N|dep|none] [--yield-for FUNCTION=MODE] [--with FUNCTION] [--window W --distance D] > hash_blocks.inc
+usage: python3 hashgen.py [--order natural|grouped] [--class-window W] [--prio HALF:FULL[:EXIT]|none] [--class-max-run N] [--class-distance D]
+       [--split-kadd m:n] [--split-add3 m:n] [--yield every:N|dep|none] [--yield-for FUNCTION=MODE] [--with FUNCTION] [--window W --distance D] > hash_blocks.inc
 Algorithms restated from core/hash.h (reference: src/shaders/sha256.wgsl:43-170, src/shaders/ripemd160.wgsl:10-100)."""
 import sys
 
