@@ -80,7 +80,7 @@ typedef struct vgen_params {
                               multiple of 8192, at most VGEN_MAX_BATCH; 0 selects 1048576 */
     uint32_t format;       /* vgen_format */
     uint32_t frames;       /* dispatches that may be in flight; reference uses 2 (gpu.rs:399); 0 -> 12; max 20.  One dispatch is one wave per SIMD, so throughput grows with the frames
-                              in flight: 7.4 / 11.4 / 12.0 / 12.1 Gkeys/s at 2 / 4 / 8 / 12 (P2PKH, 2^20 keys each).  The
+                              in flight: 9.7 / 14.7 / 15.4 / 16.5 Gkeys/s at 2 / 4 / 8 / 12 (P2PKH, 2^20 keys each; round 5).  The
                               first twelve frames get a hardware queue each (vgen_get_topology), whatever
                               GPU_MAX_HW_QUEUES is; multiples of 4 balance the queue pools */
     uint32_t match_cap;    /* match records kept per dispatch in filter mode; 0 -> 4096 */
