@@ -54,7 +54,7 @@ def test_what_the_probes_say_in_words():
     assert meas["A1R1_P"] < 2.1 and meas["SHA_G"] < 3.05 and meas["SHA_P2"] < 3.2
     # priority on the WRONG class does nothing
     assert meas["A4R4_LO"] > 3.8
-    assert im.slot_bound(0, 1, 1) == 1 and im.slot_bound(1, 0, 0) == 1 and im.slot_bound(442, 1365, 1143.5) == 1807
+    assert im.slot_bound(0, 1, 1) == 1 and im.slot_bound(1, 0, 0) == 1 and im.slot_bound(512, 1299, 1139.5) == 1811
 
 
 def test_the_class_census_is_the_one_of_this_build():
